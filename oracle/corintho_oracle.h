@@ -1,0 +1,101 @@
+/* corintho_oracle.h -- CPU ORACLE (test infrastructure, NOT the product).
+ *
+ * A plain-C restatement of the reference's self-play hot path
+ * (maxjiang216/corintho-ai: corintho_ai/cpp/src/{game,move,node,trainmc,
+ * selfplayer,trainer}.cpp).  Every function cites the reference lines it
+ * follows.  It keeps the reference's data structures (pointer-linked 64-byte
+ * style nodes, sorted sibling lists, per-node edge arrays, new/delete per
+ * node) on purpose: the product under corintho_ai_amd/ uses a different
+ * layout, so agreement between the two is meaningful.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library.  Nothing under corintho_ai_amd/ links or calls it.
+ *
+ * Parity status: the game-rule layer is pinned against the reference's own
+ * known-answer tests (tests/cpp/{game,move,node}_test.cpp, restated in
+ * tests/test_oracle_reference_tests.py).  For the search layer the reference
+ * holds only property tests (no golden vectors) and the reference itself is
+ * unbuildable in this image (it needs Microsoft GSL headers, which are
+ * absent, and stand-ins are not allowed): search parity is pinned by those
+ * property tests and by line-by-line restatement -- "parity unpinned" beyond
+ * that.  See DESIGN.md.
+ */
+#ifndef CORINTHO_ORACLE_H
+#define CORINTHO_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CO_GAME_STATE_SIZE 70
+#define CO_NUM_MOVES 96
+#define CO_NUM_SYMMETRIES 8
+
+/* ---- game-rule layer (game.cpp, move.cpp) ---- */
+/* pieces[6]: P1 base/column/capital, P2 base/column/capital (game.h:127-131) */
+int co_legal_moves(uint64_t board, const int8_t pieces[6], int to_play,
+                   uint32_t mask_out[3]); /* returns is_lines */
+void co_do_move(uint64_t *board, int8_t pieces[6], int *to_play, int move_id);
+void co_write_game_state(uint64_t board, const int8_t pieces[6], int to_play,
+                         float out[CO_GAME_STATE_SIZE]);
+/* node.cpp:256-271: 0 none, 1 loss, 2 draw for the side to move */
+int co_terminal_result(uint64_t board, const int8_t pieces[6], int to_play);
+/* move codec (move.cpp:11-42): out = {is_place, piece, row_from, col_from,
+ * row_to, col_to} */
+void co_decode_move(int move_id, int out[6]);
+int co_encode_place(int row, int col, int piece);
+int co_encode_move(int r0, int c0, int r1, int c1);
+/* tables */
+const uint32_t *co_line_breakers(void);   /* [102][3] */
+const float *co_gamma_samples(void);      /* [1024]  */
+const int32_t *co_space_symmetries(void); /* [8][16] */
+const int32_t *co_move_symmetries(void);  /* [8][96] */
+
+/* ---- mt19937 (libstdc++ std::mt19937) ---- */
+typedef struct co_mt19937 co_mt19937;
+co_mt19937 *co_mt_create(uint32_t seed);
+uint32_t co_mt_next(co_mt19937 *g);
+void co_mt_destroy(co_mt19937 *g);
+
+/* ---- Trainer (trainer.h:22-53) ---- */
+typedef struct co_trainer co_trainer;
+co_trainer *co_trainer_create(int num_games, int seed, int max_searches,
+                              int searches_per_eval, float c_puct,
+                              float epsilon, int num_threads, int testing);
+void co_trainer_destroy(co_trainer *t);
+int co_trainer_num_requests(const co_trainer *t, int to_play);
+int co_trainer_num_samples(const co_trainer *t);
+float co_trainer_score(const co_trainer *t);
+float co_trainer_avg_mate_length(const co_trainer *t);
+void co_trainer_write_requests(const co_trainer *t, float *game_states,
+                               int to_play);
+void co_trainer_write_samples(const co_trainer *t, float *game_states,
+                              float *eval_samples, float *prob_samples);
+int co_trainer_do_iteration(co_trainer *t, const float *eval,
+                            const float *probs, int to_play);
+/* Disable the staggered start (trainer.cpp:184-186).  Per-game results do not
+ * depend on it; the device engine's fused mode runs without it. */
+void co_trainer_set_stagger(co_trainer *t, int on);
+
+/* ---- introspection used by the parity tests ---- */
+/* per game: result code (util.h:57-64) or 0 while running */
+int co_trainer_game_result(const co_trainer *t, int game);
+int co_trainer_game_to_play(const co_trainer *t, int game);
+int co_trainer_game_num_requests(const co_trainer *t, int game);
+int co_trainer_game_num_samples(const co_trainer *t, int game);
+int co_trainer_game_done(const co_trainer *t, int game);
+/* Per-ply trace, appended at every chooseMove (selfplayer.cpp:234-244):
+ *   [to_play, depth, root_visits, root_result, root_eval_bits, n_children,
+ *    {move, visits, eval_bits, result, all_visited} x n_children, choice]
+ * Returns the number of int32 words; copies min(cap, words). */
+void co_trainer_enable_trace(co_trainer *t, int on);
+int co_trainer_trace(const co_trainer *t, int game, int32_t *out, int cap);
+/* counters summed over games: [searches, leaf_evals, nodes_created, plies] */
+void co_trainer_counters(const co_trainer *t, int64_t out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
