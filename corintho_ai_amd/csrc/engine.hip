@@ -1,0 +1,708 @@
+// engine.hip -- host side of the self-play pool and the C ABI (include/corintho_hip.h).
+//
+// Mirrors the reference Trainer (corintho_ai/cpp/src/trainer.cpp) method by
+// method; the per-game work of every method runs in the kernels of kernels.h.
+// Compat mode keeps the reference protocol (the caller evaluates the network
+// between doIteration calls, main.pyx:123-187); fused mode (nn_*.hip) keeps
+// the whole loop on the device.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <memory>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "../../include/corintho_hip.h"
+#include "kernels.h"
+#include "nn.h"
+#include "rt.h"
+
+#ifdef CO_EMU
+thread_local int co_emu_block_idx = 0;
+#endif
+
+static thread_local std::string g_last_error;
+extern "C" const char *ca_last_error(void) { return g_last_error.c_str(); }
+
+#define CA_TRY try {
+#define CA_CATCH                          \
+  }                                       \
+  catch (const std::exception &e) {       \
+    g_last_error = e.what();              \
+    return CA_ERR_DEVICE;                 \
+  }
+
+struct EngineError : std::runtime_error {
+  int code;
+  EngineError(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+extern "C" int ca_device_check(int device) {
+#ifdef CO_EMU
+  (void)device;
+  return CA_OK;
+#else
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= device) {
+    g_last_error = "no HIP device " + std::to_string(device) + " visible";
+    return CA_ERR_DEVICE;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
+    g_last_error = "hipGetDeviceProperties failed";
+    return CA_ERR_DEVICE;
+  }
+  if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos) {
+    g_last_error = std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
+    return CA_ERR_DEVICE;
+  }
+  return CA_OK;
+#endif
+}
+
+template <typename T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  void alloc(size_t count) {
+    release();
+    n = count;
+    rt_malloc((void **)&p, count * sizeof(T));
+  }
+  void release() {
+    if (p) rt_free(p);
+    p = nullptr;
+    n = 0;
+  }
+  ~DevBuf() { release(); }
+};
+
+struct ca_trainer {
+  ca_config cfg;
+  int G = 0, spe = 0;
+  rt_stream_t stream;
+  EngineParams P;
+  DevBuf<GameCtl> games;
+  DevBuf<TreeCtl> trees;
+  DevBuf<uint4> arena;
+  DevBuf<uint32_t> pend_leaf, pend_path, rng;
+  DevBuf<int32_t> pend_depth, req_offset, trace, all_done;
+  DevBuf<float> req, nn_in, nn_eval, nn_probs, samples;
+  /* host state */
+  int64_t iterations = 0;
+  int32_t trainer_iteration = 0; /* Trainer::searches_done_ (train mode only) */
+  int scan_valid_for = -99;      /* to_play the current req_offset/nn_in describe */
+  int32_t last_total = 0;
+  bool finished = false;
+  std::vector<GameCtl> host_games;
+  bool host_games_valid = false;
+  /* fused mode */
+  std::unique_ptr<CoNet> nets[2];
+  double mcts_ms = 0, nn_ms = 0, pack_ms = 0;
+  int64_t mcts_launches = 0, nn_launches = 0, nn_rows = 0;
+
+  ~ca_trainer() { rt_stream_destroy(stream); }
+
+  void init(const ca_config &c) {
+    cfg = c;
+    if (cfg.max_searches <= 0) cfg.max_searches = 1600;
+    if (cfg.searches_per_eval <= 0) cfg.searches_per_eval = 16;
+    if (cfg.c_puct <= 0.0f) cfg.c_puct = 1.0f;
+    G = cfg.num_games;
+    spe = cfg.searches_per_eval;
+    rt_set_device(cfg.device);
+    rt_stream_create(&stream);
+    uint32_t cap = cfg.arena_units;
+    if (cap == 0) {
+      /* a tree gains at most one node per simulation on its own turns; a node is
+       * 2 + (legal moves) units, ~34 on average.  Sized for ~20 own turns of
+       * typical growth; overflow is detected and reported, never silent. */
+      uint64_t nodes = (uint64_t)cfg.max_searches * 14 + 64;
+      cap = (uint32_t)std::min<uint64_t>(nodes * 40, 0x7FFFFFF0ull);
+    }
+    size_t T = (size_t)2 * G;
+    games.alloc(G);
+    trees.alloc(T);
+    arena.alloc(T * ((size_t)cap + CO_ARENA_PAD));
+    pend_leaf.alloc((size_t)G * spe);
+    pend_depth.alloc((size_t)G * spe);
+    pend_path.alloc((size_t)G * spe * CO_PATH_MAX);
+    rng.alloc((size_t)G * CO_MT_N);
+    req.alloc((size_t)G * spe * CO_STATE_STRIDE);
+    req_offset.alloc((size_t)G + 1);
+    nn_in.alloc((size_t)G * spe * CO_STATE_STRIDE);
+    nn_eval.alloc((size_t)G * spe);
+    nn_probs.alloc((size_t)G * spe * CO_NUM_MOVES);
+    if (!cfg.testing) samples.alloc((size_t)G * CO_MAX_PLIES * CO_SAMPLE_FLOATS);
+    if (cfg.trace) trace.alloc((size_t)G * CO_TRACE_CAP);
+    all_done.alloc(1);
+
+    /* Trainer::initialize (trainer.cpp:238-256): game i is seeded with the i-th
+     * output of mt19937(seed), in global game order */
+    int total = cfg.total_games > 0 ? cfg.total_games : G;
+    std::mt19937 gen((uint32_t)cfg.seed);
+    std::vector<uint32_t> seeds(total);
+    for (int i = 0; i < total; ++i) seeds[i] = (uint32_t)gen();
+    std::vector<uint32_t> st((size_t)G * CO_MT_N);
+    std::vector<GameCtl> hg(G);
+    std::vector<TreeCtl> ht(T);
+    for (int g = 0; g < G; ++g) {
+      uint32_t *x = &st[(size_t)g * CO_MT_N];
+      x[0] = seeds[cfg.game_base + g];
+      for (int i = 1; i < CO_MT_N; ++i) x[i] = 1812433253u * (x[i - 1] ^ (x[i - 1] >> 30)) + (uint32_t)i;
+      memset(&hg[g], 0, sizeof(GameCtl));
+      hg[g].parity = (cfg.game_base + g) % 2;
+      hg[g].rng_idx = CO_MT_N;
+    }
+    for (size_t t = 0; t < T; ++t) {
+      ht[t].root = CO_NONE;
+      ht[t].searches_done = 0;
+      ht[t].units_used = 0;
+      ht[t].peak_units = 0;
+    }
+    rt_h2d(rng.p, st.data(), st.size() * 4, stream);
+    rt_h2d(games.p, hg.data(), hg.size() * sizeof(GameCtl), stream);
+    rt_h2d(trees.p, ht.data(), ht.size() * sizeof(TreeCtl), stream);
+    rt_sync(stream);
+
+    memset(&P, 0, sizeof P);
+    P.num_games = G;
+    P.max_searches = cfg.max_searches;
+    P.searches_per_eval = spe;
+    P.c_puct = cfg.c_puct;
+    P.epsilon = cfg.epsilon;
+    P.testing = cfg.testing;
+    size_t div = (size_t)total / (size_t)cfg.max_searches;
+    if (div < 1) div = 1;
+    P.stagger_div = cfg.no_stagger ? 0 : (int32_t)div;
+    P.iteration = 0;
+    P.to_play = -1;
+    P.game_base = cfg.game_base;
+    P.cap_units = cap;
+    P.trace_on = cfg.trace;
+    P.games = games.p;
+    P.trees = trees.p;
+    P.arena = arena.p;
+    P.pend_leaf = pend_leaf.p;
+    P.pend_depth = pend_depth.p;
+    P.pend_path = pend_path.p;
+    P.rng = rng.p;
+    P.req = req.p;
+    P.req_offset = req_offset.p;
+    P.nn_eval = nn_eval.p;
+    P.nn_probs = nn_probs.p;
+    P.nn_in = nn_in.p;
+    P.samples = samples.p;
+    P.trace = trace.p;
+    P.all_done = all_done.p;
+  }
+
+  /* offsets + compact batch for model `to_play` (K4) */
+  void pack(int to_play) {
+    if (scan_valid_for == to_play) return;
+    P.to_play = to_play;
+    RT_LAUNCH(co_k_scan, 1, CO_WAVE, stream, P);
+    RT_LAUNCH(co_k_compact, G, CO_WAVE, stream, P);
+    int32_t tot_done[2];
+    rt_d2h(&tot_done[0], req_offset.p + G, 4, stream);
+    rt_d2h(&tot_done[1], all_done.p, 4, stream);
+    rt_sync(stream);
+    last_total = tot_done[0];
+    finished = tot_done[1] != 0;
+    scan_valid_for = to_play;
+  }
+
+  void fetch_games() {
+    if (host_games_valid) return;
+    host_games.resize(G);
+    rt_d2h(host_games.data(), games.p, (size_t)G * sizeof(GameCtl), stream);
+    rt_sync(stream);
+    host_games_valid = true;
+  }
+
+  void check_errors() {
+    fetch_games();
+    for (int g = 0; g < G; ++g) {
+      if (host_games[g].error) {
+        char buf[256];
+        int e = host_games[g].error;
+        snprintf(buf, sizeof buf, "game %d reported engine error 0x%x (%s%s%s%s)", g, e,
+                 (e & CO_ERR_ARENA_FULL) ? "search-tree arena full: raise ca_config.arena_units; " : "",
+                 (e & CO_ERR_PATH_TOO_DEEP) ? "search path deeper than CO_PATH_MAX; " : "",
+                 (e & CO_ERR_TOO_MANY_PLIES) ? "game longer than CO_MAX_PLIES; " : "",
+                 (e & CO_ERR_INTERNAL) ? "internal inconsistency; " : "");
+        throw EngineError(CA_ERR_ENGINE, buf);
+      }
+    }
+  }
+
+  /* Trainer::doIteration (trainer.cpp:164-236), compat protocol */
+  bool do_iteration(const float *evals, const float *probs, int to_play) {
+    if (to_play != 0 && to_play != 1) to_play = -1;
+    if (iterations > 0) {
+      pack(to_play); /* offsets the reference computes at entry */
+      if (last_total > 0) {
+        if (!evals || !probs) throw EngineError(CA_ERR_ARG, "doIteration: null evaluations/probabilities");
+        rt_h2d(nn_eval.p, evals, (size_t)last_total * 4, stream);
+        rt_h2d(nn_probs.p, probs, (size_t)last_total * CO_NUM_MOVES * 4, stream);
+      }
+    } else {
+      rt_memset(req_offset.p, 0, ((size_t)G + 1) * 4, stream);
+    }
+    P.to_play = to_play;
+    P.iteration = trainer_iteration;
+    RT_LAUNCH(co_k_mcts_step, G, CO_WAVE, stream, P);
+    if (to_play == -1) ++trainer_iteration;
+    ++iterations;
+    ++mcts_launches;
+    scan_valid_for = -99;
+    host_games_valid = false;
+    pack(to_play);
+    check_errors();
+    return finished;
+  }
+
+  int32_t num_requests(int to_play) {
+    if (to_play != 0 && to_play != 1) to_play = -1;
+    pack(to_play);
+    return last_total;
+  }
+
+  void write_requests(float *out, int to_play) {
+    if (to_play != 0 && to_play != 1) to_play = -1;
+    pack(to_play);
+    if (last_total == 0) return;
+    std::vector<float> tmp((size_t)last_total * CO_STATE_STRIDE);
+    rt_d2h(tmp.data(), nn_in.p, tmp.size() * 4, stream);
+    rt_sync(stream);
+    for (int r = 0; r < last_total; ++r)
+      memcpy(out + (size_t)r * CO_GAME_STATE_SIZE, &tmp[(size_t)r * CO_STATE_STRIDE], CO_GAME_STATE_SIZE * 4);
+  }
+
+  int32_t num_samples() {
+    fetch_games();
+    int32_t n = 0;
+    for (int g = 0; g < G; ++g) n += host_games[g].n_samples;
+    return n;
+  }
+
+  /* SelfPlayer::score (selfplayer.cpp:57-64) + Trainer::score (trainer.cpp:59-68) */
+  static float game_score(const GameCtl &gc) {
+    if (gc.result == CO_RESULT_LOSS) return 0.0f;
+    if (gc.result == CO_RESULT_WIN) return 1.0f;
+    return 0.5f;
+  }
+  float score() {
+    fetch_games();
+    /* colour alternates with the GLOBAL game index (trainer.cpp:61-66) */
+    float s = 0;
+    for (int g = 0; g < G; ++g)
+      if ((cfg.game_base + g) % 2 == 0) s += game_score(host_games[g]);
+    for (int g = 0; g < G; ++g)
+      if ((cfg.game_base + g) % 2 == 1) s = (float)((double)s + (1.0 - (double)game_score(host_games[g])));
+    return s / (float)(size_t)G;
+  }
+  float avg_mate_length() {
+    fetch_games();
+    int32_t total = 0;
+    for (int g = 0; g < G; ++g) {
+      const GameCtl &gc = host_games[g];
+      total += gc.mate_turn == 0 ? 0 : gc.n_samples - gc.mate_turn + 1; /* selfplayer.cpp:66-71 */
+    }
+    return (float)total / (float)(size_t)G;
+  }
+
+  void write_samples(float *gs, float *ev, float *pr) {
+    if (cfg.testing) throw EngineError(CA_ERR_STATE, "writeSamples in testing mode");
+    fetch_games();
+    std::vector<int32_t> off(G + 1, 0);
+    for (int g = 0; g < G; ++g) off[g + 1] = off[g] + host_games[g].n_samples;
+    size_t n = (size_t)off[G];
+    if (n == 0) return;
+    DevBuf<int32_t> d_off;
+    DevBuf<float> d_gs, d_ev, d_pr;
+    d_off.alloc(G + 1);
+    d_gs.alloc(n * 8 * CO_GAME_STATE_SIZE);
+    d_ev.alloc(n * 8);
+    d_pr.alloc(n * 8 * CO_NUM_MOVES);
+    rt_h2d(d_off.p, off.data(), off.size() * 4, stream);
+    RT_LAUNCH(co_k_write_samples, G, CO_WAVE, stream, P, (const int32_t *)d_off.p, d_gs.p, d_ev.p, d_pr.p);
+    rt_d2h(gs, d_gs.p, d_gs.n * 4, stream);
+    rt_d2h(ev, d_ev.p, d_ev.n * 4, stream);
+    rt_d2h(pr, d_pr.p, d_pr.n * 4, stream);
+    rt_sync(stream);
+  }
+
+  void export_samples(float *state_policy, float *outcome) {
+    if (cfg.testing) throw EngineError(CA_ERR_STATE, "export_samples in testing mode");
+    fetch_games();
+    std::vector<float> all((size_t)G * CO_MAX_PLIES * CO_SAMPLE_FLOATS);
+    rt_d2h(all.data(), samples.p, all.size() * 4, stream);
+    rt_sync(stream);
+    size_t row = 0;
+    for (int g = 0; g < G; ++g) {
+      int n = host_games[g].n_samples;
+      for (int i = 0; i < n; ++i, ++row) {
+        memcpy(state_policy + row * CO_SAMPLE_FLOATS, &all[((size_t)g * CO_MAX_PLIES + i) * CO_SAMPLE_FLOATS],
+               CO_SAMPLE_FLOATS * 4);
+        float e = host_games[g].result == CO_RESULT_DRAW ? 0.0f : 1.0f;
+        if ((n - 1 - i) & 1) e = (float)((double)e * -1.0);
+        outcome[row] = e;
+      }
+    }
+  }
+
+  /* Trainer::writeScores (trainer.cpp:115-162) */
+  void write_scores(const char *file) {
+    fetch_games();
+    size_t n = (size_t)G;
+    std::vector<float> scores(n);
+    for (size_t i = 0; i < n; i += 2) scores[i] = game_score(host_games[i]);
+    for (size_t i = 1; i < n; i += 2) scores[i] = (float)(1.0 - (double)game_score(host_games[i]));
+    FILE *f = fopen(file, "w");
+    if (!f) throw EngineError(CA_ERR_IO, std::string("cannot open ") + file);
+    const char *who[2] = {"First", "Second"};
+    for (int side = 0; side < 2; ++side) {
+      int wins = 0, draws = 0;
+      for (size_t i = side; i < n; i += 2) {
+        if (scores[i] == 1.0f) ++wins;
+        else if (scores[i] == 0.5f) ++draws;
+      }
+      size_t half = n / 2;
+      auto ratio = [&](size_t k) { return (double)((float)k / (float)half); };
+      fprintf(f, "%s player wins: %d / %zu = %g\n", who[side], wins, half, ratio(wins));
+      fprintf(f, "%s player draws: %d / %zu = %g\n", who[side], draws, half, ratio(draws));
+      fprintf(f, "%s player losses: %zu / %zu = %g\n", who[side], half - wins - draws, half, ratio(half - wins - draws));
+    }
+    fclose(f);
+  }
+
+  /* ------------------------------------------------------------ fused mode */
+  void set_net(int slot, int kind, const float *weights, size_t n) {
+    if (slot < 0 || slot > 1) throw EngineError(CA_ERR_ARG, "net slot must be 0 or 1");
+    nets[slot].reset(co_net_create(kind, weights, n, (size_t)G * spe, stream));
+    if (!nets[slot]) throw EngineError(CA_ERR_ARG, "unknown net kind or bad weight count");
+  }
+
+  void net_forward_rows(int slot, const float *d_in, int32_t rows_cap, const int32_t *d_rows, float *d_eval,
+                        float *d_probs) {
+    nets[slot]->forward(d_in, rows_cap, d_rows, d_eval, d_probs, stream);
+  }
+
+  bool run(int64_t max_iterations) {
+    if (!nets[0]) throw EngineError(CA_ERR_STATE, "ca_trainer_run: no network set (ca_trainer_set_net)");
+    if (cfg.testing && !nets[1]) throw EngineError(CA_ERR_STATE, "arena mode needs both networks");
+    rt_event_t e0, e1, e2, e3;
+    rt_event_create(&e0);
+    rt_event_create(&e1);
+    rt_event_create(&e2);
+    rt_event_create(&e3);
+    int to_play = cfg.testing ? 0 : -1;
+    if (iterations == 0) rt_memset(req_offset.p, 0, ((size_t)G + 1) * 4, stream);
+    int64_t it = 0;
+    const int poll = 4;
+    int idle_flips = 0;
+    while (!finished && (max_iterations <= 0 || it < max_iterations)) {
+      /* main.pyx:142-168: doIteration -> requests -> predict */
+      P.to_play = to_play;
+      P.iteration = trainer_iteration;
+      rt_event_record(e0, stream);
+      RT_LAUNCH(co_k_mcts_step, G, CO_WAVE, stream, P);
+      rt_event_record(e1, stream);
+      RT_LAUNCH(co_k_scan, 1, CO_WAVE, stream, P);
+      RT_LAUNCH(co_k_compact, G, CO_WAVE, stream, P);
+      rt_event_record(e2, stream);
+      int slot = (cfg.testing && to_play == 0) ? 1 : 0; /* get_predictions, main.pyx:74-81 */
+      net_forward_rows(slot, nn_in.p, G * spe, req_offset.p + G, nn_eval.p, nn_probs.p);
+      rt_event_record(e3, stream);
+      if (to_play == -1) ++trainer_iteration;
+      ++iterations;
+      ++it;
+      ++mcts_launches;
+      ++nn_launches;
+      bool poll_now = cfg.testing || (it % poll) == 0;
+      if (poll_now) {
+        int32_t tot_done[2];
+        rt_d2h(&tot_done[0], req_offset.p + G, 4, stream);
+        rt_d2h(&tot_done[1], all_done.p, 4, stream);
+        rt_sync(stream);
+        finished = tot_done[1] != 0;
+        mcts_ms += rt_event_elapsed_ms(e0, e1);
+        pack_ms += rt_event_elapsed_ms(e1, e2);
+        nn_ms += rt_event_elapsed_ms(e2, e3);
+        if (cfg.testing && !finished) {
+          /* main.pyx:150-154: flip the model when it has no request */
+          if (tot_done[0] == 0) {
+            to_play = 1 - to_play;
+            if (++idle_flips > 4) throw EngineError(CA_ERR_ENGINE, "arena: no model has requests");
+          } else {
+            idle_flips = 0;
+          }
+        }
+        if (!cfg.testing && !finished && tot_done[0] == 0)
+          throw EngineError(CA_ERR_ENGINE, "No requests during training"); /* main.pyx:161-163 */
+      }
+    }
+    rt_sync(stream);
+    rt_event_destroy(e0);
+    rt_event_destroy(e1);
+    rt_event_destroy(e2);
+    rt_event_destroy(e3);
+    scan_valid_for = -99;
+    host_games_valid = false;
+    /* refresh the done flag */
+    {
+      P.to_play = to_play;
+      scan_valid_for = -99;
+      pack(to_play);
+    }
+    check_errors();
+    return finished;
+  }
+};
+
+/* ------------------------------------------------------------------- C ABI */
+#define CA_GUARD(...)                     \
+  try {                                   \
+    __VA_ARGS__;                          \
+    return CA_OK;                         \
+  } catch (const EngineError &e) {        \
+    g_last_error = e.what();              \
+    return e.code;                        \
+  } catch (const std::exception &e) {     \
+    g_last_error = e.what();              \
+    return CA_ERR_DEVICE;                 \
+  }
+
+extern "C" int ca_trainer_create(const ca_config *cfg, ca_trainer **out) {
+  if (!cfg || !out) {
+    g_last_error = "null argument";
+    return CA_ERR_ARG;
+  }
+  *out = nullptr;
+  /* the asserts of trainer.cpp:25-34, as errors */
+  if (cfg->num_games <= 0 || cfg->max_searches < 0 || cfg->searches_per_eval < 0 || cfg->epsilon < 0.0f ||
+      cfg->epsilon > 1.0f || cfg->num_logged != 0 ||
+      (cfg->max_searches > 0 && cfg->searches_per_eval > cfg->max_searches) ||
+      (cfg->total_games > 0 && cfg->game_base + cfg->num_games > cfg->total_games) || cfg->game_base < 0) {
+    g_last_error = "ca_trainer_create: invalid configuration (num_logged must be 0 on device)";
+    return CA_ERR_ARG;
+  }
+  int rc = ca_device_check(cfg->device);
+  if (rc != CA_OK) return rc;
+  ca_trainer *t = nullptr;
+  try {
+    t = new ca_trainer();
+    t->init(*cfg);
+  } catch (const std::exception &e) {
+    g_last_error = e.what();
+    delete t;
+    return CA_ERR_DEVICE;
+  }
+  *out = t;
+  return CA_OK;
+}
+
+extern "C" void ca_trainer_destroy(ca_trainer *t) { delete t; }
+
+extern "C" int ca_trainer_num_requests(ca_trainer *t, int to_play, int32_t *out) { CA_GUARD(*out = t->num_requests(to_play)) }
+extern "C" int ca_trainer_num_samples(ca_trainer *t, int32_t *out) { CA_GUARD(*out = t->num_samples()) }
+extern "C" int ca_trainer_score(ca_trainer *t, float *out) { CA_GUARD(*out = t->score()) }
+extern "C" int ca_trainer_avg_mate_length(ca_trainer *t, float *out) { CA_GUARD(*out = t->avg_mate_length()) }
+extern "C" int ca_trainer_write_requests(ca_trainer *t, float *gs, int to_play) { CA_GUARD(t->write_requests(gs, to_play)) }
+extern "C" int ca_trainer_write_samples(ca_trainer *t, float *gs, float *ev, float *pr) { CA_GUARD(t->write_samples(gs, ev, pr)) }
+extern "C" int ca_trainer_write_scores(ca_trainer *t, const char *file) { CA_GUARD(t->write_scores(file)) }
+extern "C" int ca_trainer_do_iteration(ca_trainer *t, const float *ev, const float *pr, int to_play, int32_t *all_done) {
+  CA_GUARD(*all_done = t->do_iteration(ev, pr, to_play) ? 1 : 0)
+}
+extern "C" int ca_trainer_set_net(ca_trainer *t, int slot, int kind, const float *w, size_t n) { CA_GUARD(t->set_net(slot, kind, w, n)) }
+extern "C" int ca_trainer_run(ca_trainer *t, int64_t max_iterations, int32_t *all_done) {
+  CA_GUARD(*all_done = t->run(max_iterations) ? 1 : 0)
+}
+extern "C" int ca_trainer_export_samples(ca_trainer *t, float *sp, float *oc) { CA_GUARD(t->export_samples(sp, oc)) }
+
+extern "C" int ca_trainer_net_forward(ca_trainer *t, int slot, const float *states, int32_t n, float *evals, float *probs) {
+  CA_GUARD({
+    if (slot < 0 || slot > 1 || !t->nets[slot]) throw EngineError(CA_ERR_STATE, "net slot not set");
+    DevBuf<float> d_in, d_ev, d_pr;
+    DevBuf<int32_t> d_n;
+    d_in.alloc((size_t)n * CO_STATE_STRIDE);
+    d_ev.alloc(n);
+    d_pr.alloc((size_t)n * CO_NUM_MOVES);
+    d_n.alloc(1);
+    std::vector<float> pad((size_t)n * CO_STATE_STRIDE, 0.0f);
+    for (int r = 0; r < n; ++r)
+      memcpy(&pad[(size_t)r * CO_STATE_STRIDE], states + (size_t)r * CO_GAME_STATE_SIZE, CO_GAME_STATE_SIZE * 4);
+    rt_h2d(d_in.p, pad.data(), pad.size() * 4, t->stream);
+    rt_h2d(d_n.p, &n, 4, t->stream);
+    std::unique_ptr<CoNet> tmp;
+    CoNet *net = t->nets[slot].get();
+    if ((size_t)n > net->max_rows()) throw EngineError(CA_ERR_ARG, "net_forward: more rows than num_games*searches_per_eval");
+    net->forward(d_in.p, n, d_n.p, d_ev.p, d_pr.p, t->stream);
+    rt_d2h(evals, d_ev.p, (size_t)n * 4, t->stream);
+    rt_d2h(probs, d_pr.p, (size_t)n * CO_NUM_MOVES * 4, t->stream);
+    rt_sync(t->stream);
+  })
+}
+
+extern "C" int ca_expand_samples(int device, const float *state_policy, const float *outcome, int32_t n, float *gs, float *ev,
+                                 float *pr) {
+  /* host-side K7 for gathered shards: same gathers as co_k_write_samples */
+  (void)device;
+  static const int32_t SS[8][16] = CO_SPACE_SYM_INIT;
+  static const int32_t MS[8][96] = CO_MOVE_SYM_INIT;
+  for (int32_t i = 0; i < n; ++i) {
+    const float *st = state_policy + (size_t)i * CO_SAMPLE_FLOATS;
+    const float *pol = st + CO_GAME_STATE_SIZE;
+    for (int k = 0; k < 8; ++k) {
+      float *g = gs + ((size_t)i * 8 + k) * CO_GAME_STATE_SIZE;
+      float *p = pr + ((size_t)i * 8 + k) * CO_NUM_MOVES;
+      for (int j = 0; j < 64; ++j) g[j] = st[SS[k][j / 4] * 4 + j % 4];
+      for (int j = 64; j < CO_GAME_STATE_SIZE; ++j) g[j] = st[j];
+      for (int j = 0; j < CO_NUM_MOVES; ++j) p[j] = pol[MS[k][j]];
+      ev[(size_t)i * 8 + k] = outcome[i];
+    }
+  }
+  return CA_OK;
+}
+
+extern "C" int ca_trainer_stats(ca_trainer *t, ca_stats *out) {
+  CA_GUARD({
+    t->fetch_games();
+    memset(out, 0, sizeof *out);
+    for (int g = 0; g < t->G; ++g) {
+      out->searches += t->host_games[g].searches;
+      out->evals += t->host_games[g].evals;
+      out->nodes += t->host_games[g].nodes;
+      out->plies += t->host_games[g].plies;
+    }
+    std::vector<TreeCtl> ht((size_t)2 * t->G);
+    rt_d2h(ht.data(), t->trees.p, ht.size() * sizeof(TreeCtl), t->stream);
+    rt_sync(t->stream);
+    for (auto &x : ht) out->peak_arena_units = std::max<int64_t>(out->peak_arena_units, x.peak_units);
+    out->iterations = t->iterations;
+    out->mcts_ms = t->mcts_ms;
+    out->nn_ms = t->nn_ms;
+    out->pack_ms = t->pack_ms;
+    out->mcts_launches = t->mcts_launches;
+    out->nn_launches = t->nn_launches;
+    out->nn_rows = t->nn_rows;
+  })
+}
+
+extern "C" int ca_trainer_game_info(ca_trainer *t, int game, int32_t out[8]) {
+  CA_GUARD({
+    if (game < 0 || game >= t->G) throw EngineError(CA_ERR_ARG, "game index out of range");
+    t->fetch_games();
+    const GameCtl &gc = t->host_games[game];
+    out[0] = gc.to_play; out[1] = gc.done; out[2] = gc.result; out[3] = gc.n_samples;
+    out[4] = gc.done ? 0 : gc.n_pending; out[5] = gc.error; out[6] = gc.mate_turn; out[7] = gc.plies;
+  })
+}
+
+extern "C" int ca_trainer_trace(ca_trainer *t, int game, int32_t *out, int32_t cap, int32_t *n) {
+  CA_GUARD({
+    if (!t->cfg.trace) throw EngineError(CA_ERR_STATE, "trace not enabled");
+    if (game < 0 || game >= t->G) throw EngineError(CA_ERR_ARG, "game index out of range");
+    t->fetch_games();
+    int32_t len = t->host_games[game].trace_len;
+    if (len > CO_TRACE_CAP) throw EngineError(CA_ERR_ENGINE, "trace buffer overflow");
+    *n = len;
+    int32_t c = std::min(len, cap);
+    if (out && c > 0) {
+      rt_d2h(out, t->trace.p + (size_t)game * CO_TRACE_CAP, (size_t)c * 4, t->stream);
+      rt_sync(t->stream);
+    }
+  })
+}
+
+/* ---- stand-alone test entry points */
+struct TmpStream {
+  rt_stream_t s;
+  explicit TmpStream(int device) {
+    rt_set_device(device);
+    rt_stream_create(&s);
+  }
+  ~TmpStream() { rt_stream_destroy(s); }
+};
+
+extern "C" int ca_rules_legal_moves(int device, const uint64_t *boards, const uint32_t *metas, int32_t n, uint32_t *masks,
+                                    int32_t *is_lines) {
+  int rc = ca_device_check(device);
+  if (rc != CA_OK) return rc;
+  CA_GUARD({
+    TmpStream ts(device);
+    DevBuf<uint64_t> b;
+    DevBuf<uint32_t> m, mk;
+    DevBuf<int32_t> ln;
+    b.alloc(n); m.alloc(n); mk.alloc((size_t)n * 3); ln.alloc(n);
+    rt_h2d(b.p, boards, (size_t)n * 8, ts.s);
+    rt_h2d(m.p, metas, (size_t)n * 4, ts.s);
+    RT_LAUNCH(co_k_rules_batch, n, CO_WAVE, ts.s, (const uint64_t *)b.p, (const uint32_t *)m.p, n, mk.p, ln.p);
+    rt_d2h(masks, mk.p, (size_t)n * 12, ts.s);
+    rt_d2h(is_lines, ln.p, (size_t)n * 4, ts.s);
+    rt_sync(ts.s);
+  })
+}
+
+extern "C" int ca_rules_do_move(int device, uint64_t *boards, uint32_t *metas, const int32_t *moves, int32_t n, float *states) {
+  int rc = ca_device_check(device);
+  if (rc != CA_OK) return rc;
+  CA_GUARD({
+    TmpStream ts(device);
+    DevBuf<uint64_t> b;
+    DevBuf<uint32_t> m;
+    DevBuf<int32_t> mv;
+    DevBuf<float> st;
+    b.alloc(n); m.alloc(n); mv.alloc(n); st.alloc((size_t)n * CO_STATE_STRIDE);
+    rt_h2d(b.p, boards, (size_t)n * 8, ts.s);
+    rt_h2d(m.p, metas, (size_t)n * 4, ts.s);
+    rt_h2d(mv.p, moves, (size_t)n * 4, ts.s);
+    RT_LAUNCH(co_k_domove_batch, n, CO_WAVE, ts.s, b.p, m.p, (const int32_t *)mv.p, n, st.p);
+    std::vector<float> tmp((size_t)n * CO_STATE_STRIDE);
+    rt_d2h(boards, b.p, (size_t)n * 8, ts.s);
+    rt_d2h(metas, m.p, (size_t)n * 4, ts.s);
+    rt_d2h(tmp.data(), st.p, tmp.size() * 4, ts.s);
+    rt_sync(ts.s);
+    for (int i = 0; i < n; ++i)
+      memcpy(states + (size_t)i * CO_GAME_STATE_SIZE, &tmp[(size_t)i * CO_STATE_STRIDE], CO_GAME_STATE_SIZE * 4);
+  })
+}
+
+extern "C" int ca_rng_draw(int device, uint32_t seed, int32_t n, int32_t chunk, uint32_t *out) {
+  int rc = ca_device_check(device);
+  if (rc != CA_OK) return rc;
+  CA_GUARD({
+    if (chunk < 1 || chunk > CO_WAVE) throw EngineError(CA_ERR_ARG, "chunk must be 1..64");
+    TmpStream ts(device);
+    std::vector<uint32_t> x(CO_MT_N);
+    x[0] = seed;
+    for (int i = 1; i < CO_MT_N; ++i) x[i] = 1812433253u * (x[i - 1] ^ (x[i - 1] >> 30)) + (uint32_t)i;
+    DevBuf<uint32_t> mt, o;
+    DevBuf<int32_t> idx;
+    mt.alloc(CO_MT_N); o.alloc(n); idx.alloc(1);
+    int32_t i0 = CO_MT_N;
+    rt_h2d(mt.p, x.data(), CO_MT_N * 4, ts.s);
+    rt_h2d(idx.p, &i0, 4, ts.s);
+    RT_LAUNCH(co_k_rng_draw, 1, CO_WAVE, ts.s, mt.p, idx.p, n, chunk, o.p);
+    rt_d2h(out, o.p, (size_t)n * 4, ts.s);
+    rt_sync(ts.s);
+  })
+}
+
+extern "C" int ca_fp_probe(int device, const float *in, int32_t n, float *out) {
+  int rc = ca_device_check(device);
+  if (rc != CA_OK) return rc;
+  CA_GUARD({
+    TmpStream ts(device);
+    DevBuf<float> di, dout;
+    di.alloc((size_t)n * 8); dout.alloc((size_t)n * 8);
+    rt_h2d(di.p, in, (size_t)n * 32, ts.s);
+    RT_LAUNCH(co_k_fp_probe, (n + CO_WAVE - 1) / CO_WAVE, CO_WAVE, ts.s, (const float *)di.p, n, dout.p);
+    rt_d2h(out, dout.p, (size_t)n * 32, ts.s);
+    rt_sync(ts.s);
+  })
+}

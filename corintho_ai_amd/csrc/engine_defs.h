@@ -1,0 +1,119 @@
+// engine_defs.h -- HBM layout of the self-play pool (shared by host and kernels).
+//
+// One process drives one GPU.  G games live in a struct-of-arrays pool:
+//
+//   games[G]        GameCtl   64 B   turn state of one game (SelfPlayer,
+//                                    selfplayer.h:86-111)
+//   trees[2G]       TreeCtl   16 B   one per player (TrainMC, trainmc.h:145-188)
+//   arena[2G][cap]  uint4            the two search trees of game g, as 16-byte
+//                                    units, bump allocated, never freed within a
+//                                    game (a re-root only moves the root offset)
+//   pend_*          per game         the <= searches_per_eval leaves awaiting a
+//                                    network evaluation, each with the path of
+//                                    stat slots from the root
+//   rng[G][624]     uint32           std::mt19937 state of each game
+//   req[G][spe][80] float            leaf states (70 floats, padded to 80)
+//   samples[G][44][166] float        (state, policy) per ply
+//
+// A tree node is a BLOCK of units at offset b of its tree's arena:
+//   unit b+0   {board_lo, board_hi, meta, parent_block}
+//   unit b+1   {self_slot, denominator(f32), 0, 0}
+//   unit b+2+e slot of edge e, e < n_edges, edges in ascending move id:
+//                {child_block | NONE, evaluation(f32),
+//                 move_id:7 | prior:9 | visits:16 (signed), result:8 | all_visited:8}
+//   unit b+2+n (only for a detached root) the root's own stat slot
+// The statistics of a node (Node::evaluation_/visits_/result_/all_visited_,
+// node.h:150-186) live in the SLOT of the edge that leads to it -- in its
+// parent's block -- so that one coalesced 16 B-per-lane load of a block gives
+// the PUCT scan everything it needs (trainmc.cpp:540-600); `self_slot` is the
+// unit offset of that slot.  meta = pieces[6] (3 bits each) | to_play<<18 |
+// depth<<19 (6 bits) | n_edges<<25 (7 bits).
+#pragma once
+#include <stdint.h>
+
+#include "wave.h" /* uint4 */
+
+#define CO_NONE 0xFFFFFFFFu
+#define CO_GAME_STATE_SIZE 70
+#define CO_STATE_STRIDE 80 /* request rows are padded to 80 floats (320 B, 16 B aligned) */
+#define CO_NUM_MOVES 96
+#define CO_NUM_SYMMETRIES 8
+#define CO_MAX_PLIES 44
+#define CO_SAMPLE_FLOATS (CO_GAME_STATE_SIZE + CO_NUM_MOVES)
+#define CO_PATH_MAX 48
+#define CO_MT_N 624
+#define CO_TRACE_CAP 12288
+#define CO_ARENA_PAD 160 /* units readable past the last block (whole-wave block loads) */
+
+/* ref: util.h:57-64 */
+#define CO_RESULT_NONE 0
+#define CO_RESULT_LOSS 1
+#define CO_RESULT_DRAW 2
+#define CO_RESULT_WIN 3
+#define CO_DEDUCED_LOSS 4
+#define CO_DEDUCED_DRAW 5
+#define CO_DEDUCED_WIN 6
+
+/* error bits in GameCtl.error */
+#define CO_ERR_ARENA_FULL 1
+#define CO_ERR_PATH_TOO_DEEP 2
+#define CO_ERR_TOO_MANY_PLIES 4
+#define CO_ERR_INTERNAL 8
+#define CO_ERR_STUCK 16
+
+struct GameCtl {
+  int32_t to_play;    /* SelfPlayer::to_play_ */
+  int32_t done;       /* Trainer::is_done_[i] */
+  int32_t result;     /* SelfPlayer::result_ */
+  int32_t mate_turn;  /* SelfPlayer::mate_turn_ */
+  int32_t n_samples;  /* samples_.size() */
+  int32_t parity;     /* SelfPlayer::parity_ */
+  int32_t error;
+  int32_t n_pending;  /* players_[to_play_].searched_.size() */
+  int32_t rng_idx;    /* position in the mt19937 state, 624 = twist first */
+  int32_t plies;
+  uint32_t searches;  /* counters for the bench: simulations run ... */
+  uint32_t evals;     /* ... leaf evaluations consumed ... */
+  uint32_t nodes;     /* ... nodes created */
+  int32_t trace_len;
+  int32_t pad[2];
+};
+
+struct TreeCtl {
+  uint32_t root;          /* block offset of the root, CO_NONE = uninitialised */
+  int32_t searches_done;  /* TrainMC::searches_done_ */
+  uint32_t units_used;    /* bump pointer */
+  uint32_t peak_units;
+};
+
+struct EngineParams {
+  /* configuration */
+  int32_t num_games;
+  int32_t max_searches;
+  int32_t searches_per_eval;
+  float c_puct;
+  float epsilon;
+  int32_t testing;
+  int32_t stagger_div; /* 0 = no staggered start, else max(G / max_searches, 1) (trainer.cpp:184-186) */
+  int32_t iteration;   /* Trainer::searches_done_ */
+  int32_t to_play;     /* -1 training, 0/1 arena model to move */
+  int32_t game_base;   /* global index of local game 0 (multi-GPU shard): parity = (base + g) % 2 */
+  uint32_t cap_units;  /* arena units per tree */
+  int32_t trace_on;
+  /* pool */
+  GameCtl *games;
+  TreeCtl *trees;
+  uint4 *arena;
+  uint32_t *pend_leaf;  /* [G][spe] */
+  int32_t *pend_depth;  /* [G][spe] */
+  uint32_t *pend_path;  /* [G][spe][CO_PATH_MAX] */
+  uint32_t *rng;        /* [G][624] */
+  float *req;           /* [G][spe][CO_STATE_STRIDE] */
+  int32_t *req_offset;  /* [G+1] exclusive prefix of the active games' request counts; [G] = total */
+  const float *nn_eval;   /* [rows] compact, row = req_offset[g] + k */
+  const float *nn_probs;  /* [rows][96] */
+  float *nn_in;           /* [rows][CO_STATE_STRIDE] compact request rows */
+  float *samples;       /* [G][CO_MAX_PLIES][166] */
+  int32_t *trace;       /* [G][CO_TRACE_CAP] or null */
+  int32_t *all_done;    /* [1] */
+};

@@ -1,0 +1,198 @@
+// kernels.h -- kernel entry points of the self-play pool (wave style, see wave.h).
+//   K3 co_k_mcts_step   one wavefront per game: Trainer::doIteration body
+//   K4 co_k_scan        request offsets (Trainer::doIteration offsets[],
+//                       trainer.cpp:169-174 / :208-215) + all-done flag
+//   K4 co_k_compact     Trainer::writeRequests (trainer.cpp:79-101): per-game
+//                       request rows -> one game-major batch
+//   K7 co_k_write_samples  SelfPlayer::writeSamples (selfplayer.cpp:79-113)
+//   test kernels for the rule layer and the floating-point contract
+#pragma once
+#include "mcts.h"
+
+CO_CONST int32_t CO_SPACE_SYM[8][16] = CO_SPACE_SYM_INIT;
+CO_CONST int32_t CO_MOVE_SYM[8][96] = CO_MOVE_SYM_INIT;
+
+CO_KERNEL co_k_mcts_step(EngineParams P) {
+  int g = CO_BLOCK_IDX;
+  if (g < P.num_games) co_mcts_step_wave(P, g);
+}
+
+/* is game g part of the batch of model `to_play` (trainer.cpp:42-46, 84-98)? */
+CO_DEV int co_game_active(const GameCtl &gc, int to_play) {
+  if (gc.done) return 0;
+  if (to_play == 0 || to_play == 1) return gc.to_play == (to_play + gc.parity) % 2;
+  return 1;
+}
+
+/* single wavefront: lane l owns a contiguous chunk of games */
+CO_KERNEL co_k_scan(EngineParams P) {
+  int G = P.num_games;
+  int chunk = (G + CO_WAVE - 1) / CO_WAVE;
+  LV(int, csum);
+  LV(int, nd);
+  FOR_LANES {
+    int s = 0, notdone = 0;
+    for (int i = 0; i < chunk; ++i) {
+      int g = lane * chunk + i;
+      if (g < G) {
+        GameCtl gc = P.games[g];
+        if (co_game_active(gc, P.to_play)) s += gc.n_pending;
+        notdone += !gc.done;
+      }
+    }
+    L(csum) = s;
+    L(nd) = notdone;
+  }
+  int not_done = WAVE_SUM_I32(nd);
+  /* exclusive scan of the 64 chunk sums (uniform serial loop: 64 adds) */
+  WAVE_SHARED(int, cbase, CO_WAVE + 1);
+  FOR_LANES { cbase[lane + 1] = L(csum); }
+  WAVE_SYNC();
+  int run = 0;
+  LV(int, mybase);
+  FOR_LANES { L(mybase) = 0; }
+  for (int l = 0; l < CO_WAVE; ++l) {
+    int v = cbase[l + 1];
+    FOR_LANES {
+      if (lane == l) L(mybase) = run;
+    }
+    run += v;
+  }
+  FOR_LANES {
+    int s = L(mybase);
+    for (int i = 0; i < chunk; ++i) {
+      int g = lane * chunk + i;
+      if (g < G) {
+        GameCtl gc = P.games[g];
+        P.req_offset[g] = s;
+        if (co_game_active(gc, P.to_play)) s += gc.n_pending;
+      }
+    }
+    if (lane == 0) {
+      P.req_offset[G] = run;
+      P.all_done[0] = not_done == 0;
+    }
+  }
+}
+
+CO_KERNEL co_k_compact(EngineParams P) {
+  int g = CO_BLOCK_IDX;
+  if (g >= P.num_games) return;
+  GameCtl gc = P.games[g];
+  if (!co_game_active(gc, P.to_play)) return;
+  int n = gc.n_pending;
+  const float *src = P.req + (size_t)g * P.searches_per_eval * CO_STATE_STRIDE;
+  float *dst = P.nn_in + (size_t)P.req_offset[g] * CO_STATE_STRIDE;
+  int total = n * CO_STATE_STRIDE;
+  FOR_LANES {
+    for (int i = lane; i < total; i += CO_WAVE) dst[i] = src[i];
+  }
+}
+
+/* one wavefront per game; sample_offset[g] = number of plies of games < g */
+CO_KERNEL co_k_write_samples(EngineParams P, const int32_t *sample_offset, float *game_states, float *eval_samples,
+                             float *prob_samples) {
+  int g = CO_BLOCK_IDX;
+  if (g >= P.num_games) return;
+  GameCtl gc = P.games[g];
+  int n = gc.n_samples;
+  size_t off = (size_t)sample_offset[g];
+  const float *smp = P.samples + (size_t)g * CO_MAX_PLIES * CO_SAMPLE_FLOATS;
+  for (int i = n - 1; i >= 0; --i) {
+    /* the last mover wins unless the game is drawn; sign alternates backwards */
+    float evaluation = gc.result == CO_RESULT_DRAW ? 0.0f : 1.0f;
+    if ((n - 1 - i) & 1) evaluation = (float)((double)evaluation * -1.0);
+    const float *st = smp + (size_t)i * CO_SAMPLE_FLOATS;
+    const float *pol = st + CO_GAME_STATE_SIZE;
+    for (int k = 0; k < CO_NUM_SYMMETRIES; ++k) {
+      float *gs = game_states + ((off + i) * CO_NUM_SYMMETRIES + k) * CO_GAME_STATE_SIZE;
+      float *ps = prob_samples + ((off + i) * CO_NUM_SYMMETRIES + k) * CO_NUM_MOVES;
+      FOR_LANES {
+        gs[lane] = st[CO_SPACE_SYM[k][lane / 4] * 4 + lane % 4];
+        if (lane < CO_GAME_STATE_SIZE - 64) gs[64 + lane] = st[64 + lane];
+        ps[lane] = pol[CO_MOVE_SYM[k][lane]];
+        if (lane < CO_NUM_MOVES - 64) ps[64 + lane] = pol[CO_MOVE_SYM[k][64 + lane]];
+        if (lane == 0) eval_samples[(off + i) * CO_NUM_SYMMETRIES + k] = evaluation;
+      }
+    }
+  }
+}
+
+/* ---- test kernels: the rule layer on a batch of positions, one per wavefront */
+CO_KERNEL co_k_rules_batch(const uint64_t *boards, const uint32_t *metas, int n, uint32_t *masks, int32_t *lines) {
+  int i = CO_BLOCK_IDX;
+  if (i >= n) return;
+  uint32_t lm[3];
+  int l = co_legal_moves(boards[i], metas[i], lm);
+  FOR_LANES {
+    if (lane < 3) masks[i * 3 + lane] = lm[lane];
+    if (lane == 0) lines[i] = l;
+  }
+}
+
+CO_KERNEL co_k_domove_batch(uint64_t *boards, uint32_t *metas, const int32_t *moves, int n, float *states) {
+  int i = CO_BLOCK_IDX;
+  if (i >= n) return;
+  uint64_t b = boards[i];
+  uint32_t m = metas[i];
+  if (moves[i] >= 0) co_do_move(&b, &m, moves[i]);
+  WAVE_SYNC();
+  FOR_LANES {
+    if (lane == 0) {
+      boards[i] = b;
+      metas[i] = m;
+    }
+  }
+  co_write_state(b, m, states + (size_t)i * CO_STATE_STRIDE);
+}
+
+/* mt19937: game 0's generator, `n` outputs through the wave draw path */
+CO_KERNEL co_k_rng_draw(uint32_t *mt, int32_t *idx_io, int n, int chunk, uint32_t *out) {
+  int idx = idx_io[0];
+  int done = 0;
+  while (done < n) {
+    int cnt = n - done < chunk ? n - done : chunk;
+    LV(uint32_t, r);
+    CO_MT_DRAW(mt, idx, cnt, r);
+    FOR_LANES {
+      if (lane < cnt) out[done + lane] = L(r);
+    }
+    done += cnt;
+  }
+  FOR_LANES {
+    if (lane == 0) idx_io[0] = idx;
+  }
+}
+
+/* The floating-point expressions whose exact rounding the search depends on
+ * (trainmc.cpp:230,242,257,266,549,565-568).  One lane per input row:
+ *   in[i]  = {c_puct, visits, eval, prob9, denom, cvisits, sum, eps}
+ *   out[i] = {v_sqrt, u_visited, u_unvisited, scalar, dscalar, 511/x, 1/(float)n} */
+CO_KERNEL co_k_fp_probe(const float *in, int n, float *out) {
+  FOR_LANES {
+    int i = CO_BLOCK_IDX * CO_WAVE + lane;
+    if (i < n) {
+      const float *x = in + (size_t)i * 8;
+      float c_puct = x[0], visits = x[1], eval = x[2], p9 = x[3], denom = x[4], cv = x[5], sum = x[6], eps = x[7];
+      float v_sqrt = (float)((double)c_puct * co_sqrt_f64((double)visits));
+      float prob = p9 * denom;
+      float pv = prob * v_sqrt;
+      double a = -1.0 * (double)eval / (double)cv;
+      double b = (double)pv / ((double)cv + 1.0);
+      float one_minus = (float)1 - eps;
+      float *o = out + (size_t)i * 8;
+      o[0] = v_sqrt;
+      o[1] = (float)(a + b);
+      o[2] = pv;
+      o[3] = (float)(1.0 / (double)sum * (double)one_minus);
+      o[4] = (float)(1.0 / (double)sum * (double)eps);
+      o[5] = 511.0f / sum;
+      o[6] = (float)(1.0 / (double)(float)(int)cv);
+      float xq = p9 * (511.0f / sum);
+      float fl = __builtin_truncf(xq);
+      int q = (int)fl;
+      if (xq - fl >= 0.5f) q += 1;
+      o[7] = (float)q;
+    }
+  }
+}

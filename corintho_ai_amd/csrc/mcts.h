@@ -1,0 +1,848 @@
+// mcts.h -- one wavefront advances one game: select / expand / backup, prior
+// quantisation with Dirichlet noise, move choice, re-rooting and the hand-over
+// between the two players' trees.
+//
+// Semantics follow the reference line by line (file:line cited at each
+// function); the data layout does not (engine_defs.h).  All floating-point
+// expressions keep the reference's mixed float/double evaluation order
+// (SURVEY 7 "hard parts" 1): this file must be compiled with
+// -ffp-contract=off and correctly rounded fp32 division.
+#pragma once
+#include "engine_defs.h"
+#include "rng.h"
+#include "rules.h"
+#include "wave.h"
+
+#ifndef CO_EMU
+#pragma clang fp contract(off)
+#endif
+
+CO_CONST uint32_t CO_GAMMA_BITS[CO_NUM_GAMMA] = CO_GAMMA_BITS_INIT;
+
+#define CO_NEG_INF (-__builtin_huge_valf())
+
+struct CoTree {
+  uint4 *A;      /* arena of this tree */
+  TreeCtl tc;    /* register copy, written back at the end of the step */
+  uint32_t cap;
+};
+
+struct CoWave {
+  int g;
+  GameCtl gc;
+  CoTree tr[2];
+  uint32_t *mt;
+  /* per-game views */
+  uint32_t *pend_leaf;
+  int32_t *pend_depth;
+  uint32_t *pend_path;
+  float *req;
+  float *samples;
+  int32_t *trace;
+  /* config */
+  int max_searches, spe, testing, trace_on;
+  float c_puct, epsilon;
+};
+
+/* ---- slot helpers.  slot = {child, eval bits, mp | visits<<16, result | all_visited<<8} */
+CO_DEV int co_slot_visits(uint4 s) { return (int)(int16_t)(s.z >> 16); }
+CO_DEV uint4 co_slot_set_visits(uint4 s, int v) {
+  s.z = (s.z & 0xFFFFu) | ((uint32_t)(uint16_t)(int16_t)v << 16);
+  return s;
+}
+CO_DEV int co_slot_result(uint4 s) { return (int)(s.w & 0xFFu); }
+CO_DEV int co_slot_all_visited(uint4 s) { return (int)((s.w >> 8) & 1u); }
+CO_DEV uint4 co_slot_set_result(uint4 s, int r) {
+  s.w = (s.w & ~0xFFu) | (uint32_t)r;
+  return s;
+}
+CO_DEV uint4 co_slot_set_all_visited(uint4 s, int a) {
+  s.w = (s.w & ~0x100u) | ((uint32_t)(a & 1) << 8);
+  return s;
+}
+/* node.cpp:96-118 */
+CO_DEV int co_res_terminal(int r) { return r == CO_RESULT_LOSS || r == CO_RESULT_DRAW; }
+CO_DEV int co_res_known(int r) { return r != CO_RESULT_NONE; }
+CO_DEV int co_res_won(int r) { return r == CO_DEDUCED_WIN; }
+CO_DEV int co_res_lost(int r) { return r == CO_RESULT_LOSS || r == CO_DEDUCED_LOSS; }
+CO_DEV int co_res_drawn(int r) { return r == CO_RESULT_DRAW || r == CO_DEDUCED_DRAW; }
+
+/* uniform 16-byte read / single-lane write of one unit */
+CO_DEV uint4 co_load_unit(const uint4 *A, uint32_t off) { return A[off]; }
+CO_DEV void co_store_unit(uint4 *A, uint32_t off, uint4 v) {
+  FOR_LANES {
+    if (lane == 0) A[off] = v;
+  }
+  WAVE_SYNC();
+}
+
+CO_DEV void co_trace_push(CoWave &w, int32_t v) {
+  if (!w.trace_on) return;
+  if (w.gc.trace_len < CO_TRACE_CAP) {
+    int at = w.gc.trace_len;
+    FOR_LANES {
+      if (lane == 0) w.trace[at] = v;
+    }
+  }
+  w.gc.trace_len++;
+}
+
+/* Create the node for position (board, meta_game) -- Node ctors node.cpp:14-39 +
+ * initializeEdges node.cpp:256-283.  self_slot == CO_NONE makes a detached root
+ * that carries its own stat slot.  Returns the block offset (CO_NONE on arena
+ * overflow); *res_out = kResultLoss / kResultDraw / kResultNone. */
+CO_DEV uint32_t co_create_node(CoWave &w, CoTree &t, uint64_t board, uint32_t meta_game, int depth, uint32_t parent,
+                               uint32_t self_slot, int *res_out) {
+  uint32_t lm[3];
+  int is_lines = co_legal_moves(board, meta_game, lm);
+  int n = co_popc32(lm[0]) + co_popc32(lm[1]) + co_popc32(lm[2]);
+  int res = CO_RESULT_NONE;
+  if (n == 0) res = is_lines ? CO_RESULT_LOSS : CO_RESULT_DRAW;
+  *res_out = res;
+  uint32_t units = 2u + (uint32_t)n + (self_slot == CO_NONE ? 1u : 0u);
+  if (t.tc.units_used + units > t.cap) {
+    w.gc.error |= CO_ERR_ARENA_FULL;
+    return CO_NONE;
+  }
+  uint32_t b = t.tc.units_used;
+  t.tc.units_used += units;
+  if (t.tc.units_used > t.tc.peak_units) t.tc.peak_units = t.tc.units_used;
+  w.gc.nodes++;
+  uint32_t own = self_slot == CO_NONE ? b + 2u + (uint32_t)n : self_slot;
+  uint32_t meta = co_meta_make(meta_game, depth, n);
+  uint4 *A = t.A;
+  FOR_LANES {
+    if (lane == 0) A[b] = make_uint4((uint32_t)board, (uint32_t)(board >> 32), meta, parent);
+    if (lane == 1) A[b + 1] = make_uint4(own, 0u, 0u, 0u);
+    if (lane == 2 && self_slot == CO_NONE)
+      A[own] = make_uint4(CO_NONE, 0u, 1u << 16, (uint32_t)res | 0x100u); /* visits 1, all_visited (node.h:164,186) */
+    /* edges in ascending move id: rank = number of legal moves below this id */
+    int id0 = lane;
+    uint32_t wlo = id0 < 32 ? lm[0] : lm[1];
+    if ((wlo >> (id0 & 31)) & 1u) {
+      int rank = id0 < 32 ? co_popc32(lm[0] & ((1u << id0) - 1u))
+                          : co_popc32(lm[0]) + co_popc32(lm[1] & ((1u << (id0 - 32)) - 1u));
+      A[b + 2 + rank] = make_uint4(CO_NONE, 0u, (uint32_t)id0, 0u);
+    }
+    if (lane < 32 && ((lm[2] >> lane) & 1u)) {
+      int rank = co_popc32(lm[0]) + co_popc32(lm[1]) + co_popc32(lm[2] & ((1u << lane) - 1u));
+      A[b + 2 + rank] = make_uint4(CO_NONE, 0u, (uint32_t)(64 + lane), 0u);
+    }
+  }
+  WAVE_SYNC();
+  return b;
+}
+
+/* A leaf asks for a network evaluation: TrainMC writes the state into to_eval_
+ * and records the node in searched_ (trainmc.cpp:684-692, 150-153). */
+CO_DEV void co_request(CoWave &w, uint64_t board, uint32_t meta, uint32_t leaf, int D, const uint32_t *path_slot) {
+  int k = w.gc.n_pending;
+  co_write_state(board, meta, w.req + (size_t)k * CO_STATE_STRIDE);
+  uint32_t *pp = w.pend_path + (size_t)k * CO_PATH_MAX;
+  FOR_LANES {
+    if (lane == 0) {
+      w.pend_leaf[k] = leaf;
+      w.pend_depth[k] = D;
+    }
+    if (lane <= D && lane < CO_PATH_MAX) pp[lane] = path_slot[lane];
+  }
+  WAVE_SYNC();
+  w.gc.n_pending = k + 1;
+}
+
+/* receiveEval for one pending leaf: getFilteredProbs (trainmc.cpp:212-234),
+ * generateDirichlet (:236-246), setProbs (:248-267), backup (:280-295). */
+CO_DEV void co_receive_one(CoWave &w, CoTree &t, int k, float leaf_eval, const float *probs) {
+  uint4 *A = t.A;
+  uint32_t leaf = w.pend_leaf[k];
+  int D = w.pend_depth[k];
+  const uint32_t *pp = w.pend_path + (size_t)k * CO_PATH_MAX;
+  uint4 h0 = co_load_unit(A, leaf);
+  int n = (int)CO_META_NEDGES(h0.z);
+  WAVE_SHARED(float, fp, CO_NUM_MOVES);  /* filtered priors, then weights */
+  WAVE_SHARED(float, dn, CO_NUM_MOVES);  /* dirichlet */
+  WAVE_SHARED(uint32_t, mz, CO_NUM_MOVES); /* slot.z of every edge */
+  /* gather priors of the legal moves (edge order = ascending move id) */
+  for (int base = 0; base < n; base += CO_WAVE) {
+    FOR_LANES {
+      int e = base + lane;
+      if (e < n) {
+        uint32_t z = A[leaf + 2 + e].z;
+        mz[e] = z;
+        fp[e] = probs[z & 127u];
+      }
+    }
+  }
+  /* noise: one 32-bit draw per legal move, in edge order */
+  for (int base = 0; base < n; base += CO_WAVE) {
+    int cnt = n - base < CO_WAVE ? n - base : CO_WAVE;
+    LV(uint32_t, r);
+    CO_MT_DRAW(w.mt, w.gc.rng_idx, cnt, r);
+    FOR_LANES {
+      if (lane < cnt) dn[base + lane] = co_u2f(CO_GAMMA_BITS[L(r) % CO_NUM_GAMMA]);
+    }
+  }
+  WAVE_SYNC();
+  /* the two sums are sequential float additions in edge order */
+  float sum = 0.0f, dsum = 0.0f;
+  for (int e = 0; e < n; ++e) {
+    sum += fp[e];
+    dsum += dn[e];
+  }
+  float one_minus = (float)1 - w.epsilon;
+  float scalar = (float)(1.0 / (double)sum * (double)one_minus);
+  float dscalar = (float)(1.0 / (double)dsum * (double)w.epsilon);
+  LV(float, wt0);
+  LV(float, wt1);
+  LV(float, mxl);
+  FOR_LANES {
+    float m = 0.0f;
+    L(wt0) = 0.0f;
+    L(wt1) = 0.0f;
+    if (lane < n) {
+      float a = fp[lane] * scalar;
+      float d = dn[lane] * dscalar;
+      L(wt0) = a + d;
+      m = L(wt0) > m ? L(wt0) : m;
+    }
+    if (lane + CO_WAVE < n) {
+      float a = fp[lane + CO_WAVE] * scalar;
+      float d = dn[lane + CO_WAVE] * dscalar;
+      L(wt1) = a + d;
+      m = L(wt1) > m ? L(wt1) : m;
+    }
+    L(mxl) = m;
+  }
+  float max_prob = WAVE_MAX_F32(mxl);
+  float denom = 511.0f / max_prob;
+  LV(int, qs);
+  FOR_LANES {
+    int s = 0;
+    for (int h = 0; h < 2; ++h) {
+      int e = lane + h * CO_WAVE;
+      if (e < n) {
+        float x = (h ? L(wt1) : L(wt0)) * denom;
+        /* lround: half away from zero (x >= 0 here; NaN/neg handled like max(1, .)) */
+        float fl = __builtin_truncf(x);
+        int q = (int)fl;
+        if (x - fl >= 0.5f) q += 1;
+        if (!(q >= 1)) q = 1;
+        s += q;
+        uint32_t z = mz[e];
+        A[leaf + 2 + e].z = (z & 0xFFFF007Fu) | ((uint32_t)(q & 511) << 7);
+      }
+    }
+    L(qs) = s;
+  }
+  int final_sum = WAVE_SUM_I32(qs);
+  float denominator = (float)(1.0 / (double)(float)final_sum);
+  FOR_LANES {
+    if (lane == 0) A[leaf + 1].y = co_f2u(denominator);
+  }
+  WAVE_SYNC();
+  /* backup: the node k levels above the leaf receives eval*(-1)^k - 1; every
+   * node on the path becomes searchable again (all_visited := false) */
+  FOR_LANES {
+    if (lane <= D) {
+      int kk = D - lane;
+      float ce = (kk & 1) ? (float)((double)leaf_eval * -1.0) : leaf_eval;
+      float add = (float)((double)ce - 1.0);
+      uint4 s = A[pp[lane]];
+      s.y = co_f2u(co_u2f(s.y) + add);
+      s = co_slot_set_all_visited(s, 0);
+      A[pp[lane]] = s;
+    }
+  }
+  WAVE_SYNC();
+  w.gc.evals++;
+}
+
+/* trainmc.cpp:269-296 */
+CO_DEV void co_receive_eval(CoWave &w, CoTree &t, const float *eval, const float *probs) {
+  int n = w.gc.n_pending;
+  for (int k = 0; k < n; ++k) co_receive_one(w, t, k, eval[k], probs + (size_t)k * CO_NUM_MOVES);
+  w.gc.n_pending = 0;
+}
+
+/* propagateTerminal, trainmc.cpp:497-538 (including the parent-for-child draw
+ * test at :518).  path_* describe root..leaf, D = index of the terminal leaf. */
+CO_DEV void co_propagate_terminal(CoTree &t, const uint32_t *path_block, const uint32_t *path_slot, int D) {
+  uint4 *A = t.A;
+  int d = D;
+  while (d > 0) {
+    int rc = co_slot_result(co_load_unit(A, path_slot[d]));
+    if (co_res_lost(rc)) {
+      --d;
+      uint4 s = co_load_unit(A, path_slot[d]);
+      co_store_unit(A, path_slot[d], co_slot_set_result(s, CO_DEDUCED_WIN));
+    } else {
+      --d;
+      uint32_t pb = path_block[d];
+      int n = (int)CO_META_NEDGES(co_load_unit(A, pb).z);
+      int all_known = 1;
+      for (int base = 0; base < n; base += CO_WAVE) {
+        LV(int, bad);
+        FOR_LANES {
+          int e = base + lane;
+          L(bad) = 0;
+          if (e < n) {
+            uint4 s = A[pb + 2 + e];
+            L(bad) = (s.x == CO_NONE) || !co_res_known(co_slot_result(s));
+          }
+        }
+        if (WAVE_BALLOT(bad)) all_known = 0;
+      }
+      if (!all_known) return;
+      uint4 s = co_load_unit(A, path_slot[d]);
+      int has_draw = co_res_drawn(co_slot_result(s));
+      co_store_unit(A, path_slot[d], co_slot_set_result(s, has_draw ? CO_DEDUCED_DRAW : CO_DEDUCED_LOSS));
+    }
+  }
+}
+
+/* One simulation: TrainMC::search (trainmc.cpp:602-696) with chooseNext
+ * (:540-600) inlined as the lane-parallel edge scan. */
+CO_DEV void co_search(CoWave &w, CoTree &t) {
+  uint4 *A = t.A;
+  WAVE_SHARED(uint32_t, path_block, CO_PATH_MAX);
+  WAVE_SHARED(uint32_t, path_slot, CO_PATH_MAX);
+  uint32_t cur = t.tc.root;
+  ++t.tc.searches_done;
+  w.gc.searches++;
+  uint4 h0 = co_load_unit(A, cur);
+  uint4 h1 = co_load_unit(A, cur + 1);
+  uint32_t cur_slot = h1.x;
+  uint4 cs = co_load_unit(A, cur_slot);
+  int D = 0;
+  FOR_LANES {
+    if (lane == 0) {
+      path_block[0] = cur;
+      path_slot[0] = cur_slot;
+    }
+  }
+  WAVE_SYNC();
+  int leaf_is_new = 0;
+  while (!co_res_terminal(co_slot_result(cs))) {
+    int n = (int)CO_META_NEDGES(h0.z);
+    float denom = co_u2f(h1.y);
+    int visits = co_slot_visits(cs);
+    float v_sqrt = (float)((double)w.c_puct * co_sqrt_f64((double)(float)visits));
+    /* ---- chooseNext: u for every edge, strict first maximum */
+    float best_u = CO_NEG_INF;
+    int best_e = -1;
+    uint4 best_slot = make_uint4(0, 0, 0, 0);
+    for (int base = 0; base < n; base += CO_WAVE) {
+      LV(uint4, ev);
+      LV(float, u);
+      FOR_LANES {
+        int e = base + lane;
+        float uu = CO_NEG_INF;
+        if (e < n) {
+          uint4 s = A[cur + 2 + e];
+          L(ev) = s;
+          float prob = (float)((s.z >> 7) & 511u) * denom;
+          if (s.x != CO_NONE) {
+            int r = co_slot_result(s);
+            if ((!co_res_known(r) || co_res_drawn(r)) && !co_slot_all_visited(s)) {
+              if (co_res_drawn(r)) {
+                uu = prob * v_sqrt;
+              } else {
+                float pv = prob * v_sqrt;
+                float cv = (float)co_slot_visits(s);
+                double a = -1.0 * (double)co_u2f(s.y) / (double)cv;
+                double b = (double)pv / ((double)cv + 1.0);
+                uu = (float)(a + b);
+              }
+            }
+          } else {
+            uu = prob * v_sqrt;
+          }
+        }
+        L(u) = uu;
+      }
+      float mx = WAVE_MAX_F32(u);
+      if (mx > best_u) {
+        LV(int, hit);
+        FOR_LANES { L(hit) = (L(u) == mx); }
+        int le = co_ffs64(WAVE_BALLOT(hit)) - 1;
+        best_u = mx;
+        best_e = base + le;
+        best_slot = WAVE_BCAST(ev, le);
+      }
+    }
+    /* ---- visit the current node (virtual loss on every node of the path) */
+    cs = co_slot_set_visits(cs, visits + 1);
+    cs.y = co_f2u(co_u2f(cs.y) + 1.0f);
+    if (best_e < 0) {
+      /* kNone: nothing searchable below; mark, undo the path, un-count the search */
+      cs = co_slot_set_all_visited(cs, 1);
+      co_store_unit(A, cur_slot, cs);
+      FOR_LANES {
+        if (lane <= D) {
+          uint4 s = A[path_slot[lane]];
+          s = co_slot_set_visits(s, co_slot_visits(s) - 1);
+          s.y = co_f2u(co_u2f(s.y) - 1.0f);
+          A[path_slot[lane]] = s;
+        }
+      }
+      WAVE_SYNC();
+      --t.tc.searches_done;
+      w.gc.searches--;
+      return;
+    }
+    co_store_unit(A, cur_slot, cs);
+    if (D + 1 >= CO_PATH_MAX) {
+      w.gc.error |= CO_ERR_PATH_TOO_DEEP;
+      return;
+    }
+    uint32_t child_slot = cur + 2u + (uint32_t)best_e;
+    if (best_slot.x == CO_NONE) {
+      /* kNew: expand (Node ctor from parent, node.cpp:31-39) */
+      uint64_t board = (uint64_t)h0.x | ((uint64_t)h0.y << 32);
+      uint32_t meta = h0.z;
+      int move = (int)(best_slot.z & 127u);
+      co_do_move(&board, &meta, move);
+      int res;
+      int depth = (int)CO_META_DEPTH(h0.z) + 1;
+      uint32_t nb = co_create_node(w, t, board, meta, depth, cur, child_slot, &res);
+      if (nb == CO_NONE) return;
+      cs = make_uint4(nb, 0u, (best_slot.z & 0xFFFFu) | (1u << 16), (uint32_t)res | 0x100u);
+      co_store_unit(A, child_slot, cs);
+      cur = nb;
+      cur_slot = child_slot;
+      h0 = make_uint4((uint32_t)board, (uint32_t)(board >> 32), co_meta_make(meta, depth, 0), 0u);
+      ++D;
+      FOR_LANES {
+        if (lane == 0) {
+          path_block[D] = cur;
+          path_slot[D] = cur_slot;
+        }
+      }
+      WAVE_SYNC();
+      leaf_is_new = 1;
+      break;
+    }
+    /* kVisited: descend */
+    cur = best_slot.x;
+    cur_slot = child_slot;
+    cs = best_slot;
+    h0 = co_load_unit(A, cur);
+    h1 = co_load_unit(A, cur + 1);
+    ++D;
+    FOR_LANES {
+      if (lane == 0) {
+        path_block[D] = cur;
+        path_slot[D] = cur_slot;
+      }
+    }
+    WAVE_SYNC();
+  }
+  (void)leaf_is_new;
+  int r = co_slot_result(cs);
+  if (co_res_terminal(r)) {
+    /* trainmc.cpp:663-682 */
+    co_propagate_terminal(t, path_block, path_slot, D);
+    float cur_eval = co_res_drawn(r) ? 0.0f : -1.0f;
+    cs = co_load_unit(A, cur_slot); /* propagate may not touch the leaf, but stay literal */
+    cs.y = co_f2u(cur_eval);
+    co_store_unit(A, cur_slot, cs);
+    FOR_LANES {
+      if (lane < D) {
+        int kk = D - lane; /* kk-th ancestor receives eval*(-1)^(kk-1) - 1 */
+        float ce = ((kk - 1) & 1) ? (float)((double)cur_eval * -1.0) : cur_eval;
+        float add = (float)((double)ce - 1.0);
+        uint4 s = A[path_slot[lane]];
+        s.y = co_f2u(co_u2f(s.y) + add);
+        A[path_slot[lane]] = s;
+      }
+    }
+    WAVE_SYNC();
+  } else {
+    /* trainmc.cpp:684-692: default +1 evaluation, queue the leaf */
+    cs.y = co_f2u(1.0f);
+    co_store_unit(A, cur_slot, cs);
+    uint64_t board = (uint64_t)h0.x | ((uint64_t)h0.y << 32);
+    co_request(w, board, h0.z, cur, D, path_slot);
+  }
+}
+
+/* the root asks for its own evaluation (trainmc.cpp:143-167, 198-202) */
+CO_DEV void co_request_root(CoWave &w, CoTree &t) {
+  uint4 *A = t.A;
+  uint32_t root = t.tc.root;
+  uint4 h0 = co_load_unit(A, root);
+  uint4 h1 = co_load_unit(A, root + 1);
+  WAVE_SHARED(uint32_t, one_path, 1);
+  uint32_t self_slot = h1.x;
+  FOR_LANES {
+    if (lane == 0) one_path[0] = self_slot;
+  }
+  WAVE_SYNC();
+  uint64_t board = (uint64_t)h0.x | ((uint64_t)h0.y << 32);
+  co_request(w, board, h0.z, root, 0, one_path);
+}
+
+/* TrainMC::doIteration, trainmc.cpp:139-178.  Returns "turn finished". */
+CO_DEV int co_mc_do_iteration(CoWave &w, CoTree &t, const float *eval, const float *probs) {
+  if (t.tc.root == CO_NONE) {
+    int res;
+    uint32_t b = co_create_node(w, t, 0ull, CO_META_START, 0, CO_NONE, CO_NONE, &res);
+    if (b == CO_NONE) return 0;
+    t.tc.root = b;
+    t.tc.searches_done = 1;
+    co_request_root(w, t);
+    return 0;
+  }
+  uint4 rs = co_load_unit(t.A, co_load_unit(t.A, t.tc.root + 1).x);
+  if (t.tc.searches_done == 0 && co_slot_visits(rs) == 1 && co_slot_all_visited(rs)) {
+    t.tc.searches_done = 1;
+    co_request_root(w, t);
+    return 0;
+  }
+  if (w.gc.n_pending > 0) co_receive_eval(w, t, eval, probs);
+  for (;;) {
+    if (!(w.gc.n_pending < w.spe && t.tc.searches_done < w.max_searches)) break;
+    rs = co_load_unit(t.A, co_load_unit(t.A, t.tc.root + 1).x);
+    if (co_res_known(co_slot_result(rs)) || co_slot_all_visited(rs)) break;
+    if (w.gc.error) break;
+    co_search(w, t);
+  }
+  rs = co_load_unit(t.A, co_load_unit(t.A, t.tc.root + 1).x);
+  return (t.tc.searches_done == w.max_searches || co_res_known(co_slot_result(rs))) && w.gc.n_pending == 0;
+}
+
+/* TrainMC::moveDown, trainmc.cpp:475-495: the chosen child becomes the root.
+ * Nothing is freed: the old root's block stays behind (it still holds the new
+ * root's stat slot). */
+CO_DEV void co_move_down(CoTree &t, uint32_t child_block) {
+  uint4 h0 = co_load_unit(t.A, child_block);
+  h0.w = CO_NONE; /* null_parent */
+  co_store_unit(t.A, child_block, h0);
+  t.tc.root = child_block;
+  t.tc.searches_done = 0;
+}
+
+/* "Reset tree": a fresh root one move below the current one
+ * (trainmc.cpp:398-407, 455-464). */
+CO_DEV void co_reset_tree_to_child(CoWave &w, CoTree &t, int choice) {
+  uint4 h0 = co_load_unit(t.A, t.tc.root);
+  uint64_t board = (uint64_t)h0.x | ((uint64_t)h0.y << 32);
+  uint32_t meta = h0.z;
+  int depth = (int)CO_META_DEPTH(meta) + 1;
+  co_do_move(&board, &meta, choice);
+  int res;
+  uint32_t b = co_create_node(w, t, board, meta, depth, CO_NONE, CO_NONE, &res);
+  if (b == CO_NONE) return;
+  t.tc.root = b;
+  t.tc.searches_done = 0;
+}
+
+/* TrainMC::chooseMove and its four variants, trainmc.cpp:110-137, 298-473.
+ * sample = this ply's (state[70], policy[96]) row, or null in testing mode. */
+CO_DEV int co_choose_move(CoWave &w, CoTree &t, float *sample) {
+  uint4 *A = t.A;
+  uint32_t root = t.tc.root;
+  uint4 h0 = co_load_unit(A, root);
+  uint4 h1 = co_load_unit(A, root + 1);
+  uint4 rs = co_load_unit(A, h1.x);
+  int n = (int)CO_META_NEDGES(h0.z);
+  float denom = co_u2f(h1.y);
+  int rres = co_slot_result(rs);
+  uint64_t board = (uint64_t)h0.x | ((uint64_t)h0.y << 32);
+  float *policy = sample ? sample + CO_GAME_STATE_SIZE : (float *)0;
+  if (!w.testing) {
+    /* state first (70 floats), then a zeroed policy */
+    WAVE_SHARED(float, srow, CO_STATE_STRIDE);
+    co_write_state(board, h0.z, srow);
+    WAVE_SYNC();
+    FOR_LANES {
+      sample[lane] = srow[lane];
+      if (lane < CO_GAME_STATE_SIZE - 64) sample[64 + lane] = srow[64 + lane];
+      policy[lane] = 0.0f;
+      if (lane < CO_NUM_MOVES - 64) policy[64 + lane] = 0.0f;
+    }
+    WAVE_SYNC();
+  }
+  /* children in edge order = the reference's sorted sibling list */
+  WAVE_SHARED(uint4, ch, CO_NUM_MOVES);
+  for (int base = 0; base < n; base += CO_WAVE) {
+    FOR_LANES {
+      int e = base + lane;
+      if (e < n) ch[e] = A[root + 2 + e];
+    }
+  }
+  WAVE_SYNC();
+  if (w.trace_on) {
+    co_trace_push(w, w.gc.to_play);
+    co_trace_push(w, (int)CO_META_DEPTH(h0.z));
+    co_trace_push(w, co_slot_visits(rs));
+    co_trace_push(w, rres);
+    co_trace_push(w, (int32_t)rs.y);
+    int nc = 0;
+    for (int e = 0; e < n; ++e) nc += ch[e].x != CO_NONE;
+    co_trace_push(w, nc);
+    for (int e = 0; e < n; ++e) {
+      if (ch[e].x == CO_NONE) continue;
+      co_trace_push(w, (int)(ch[e].z & 127u));
+      co_trace_push(w, co_slot_visits(ch[e]));
+      co_trace_push(w, (int32_t)ch[e].y);
+      co_trace_push(w, co_slot_result(ch[e]));
+      co_trace_push(w, co_slot_all_visited(ch[e]));
+    }
+  }
+  int choice = 0;
+  int chosen_e = -1;
+  if (co_res_won(rres)) {
+    /* chooseMoveWon :310-335: first child that is lost */
+    for (int e = 0; e < n; ++e) {
+      if (ch[e].x != CO_NONE && co_res_lost(co_slot_result(ch[e]))) {
+        choice = (int)(ch[e].z & 127u);
+        chosen_e = e;
+        break;
+      }
+    }
+  } else if (co_res_lost(rres) || co_res_drawn(rres)) {
+    /* chooseMoveLostDrawn :337-361 */
+    int max_visits = 0;
+    for (int e = 0; e < n; ++e) {
+      if (ch[e].x == CO_NONE) continue;
+      int v = co_slot_visits(ch[e]);
+      if (v > max_visits && (co_res_lost(rres) || !co_res_won(co_slot_result(ch[e])))) {
+        choice = (int)(ch[e].z & 127u);
+        chosen_e = e;
+        max_visits = v;
+      }
+    }
+  } else {
+    /* chooseHighProbMove :298-308 (int32 max_prob, sic) */
+    int32_t max_prob = 0;
+    for (int e = 0; e < n; ++e) {
+      float p = (float)((ch[e].z >> 7) & 511u) * denom;
+      if (p > (float)max_prob) {
+        max_prob = (int32_t)p;
+        choice = (int)(ch[e].z & 127u);
+      }
+    }
+    if ((int)CO_META_DEPTH(h0.z) < 6 && !w.testing) {
+      /* chooseMoveOpening :363-427 */
+      int32_t visits = 0;
+      for (int e = 0; e < n; ++e)
+        if (ch[e].x != CO_NONE && !co_res_won(co_slot_result(ch[e]))) visits += co_slot_visits(ch[e]);
+      float denominator = (float)(1.0 / (double)(float)visits);
+      FOR_LANES {
+        for (int e = lane; e < n; e += CO_WAVE)
+          if (ch[e].x != CO_NONE && !co_res_won(co_slot_result(ch[e])))
+            policy[ch[e].z & 127u] = (float)co_slot_visits(ch[e]) * denominator;
+      }
+      WAVE_SYNC();
+      if (visits == 0) {
+        FOR_LANES {
+          if (lane == 0) policy[choice] = 1.0f;
+        }
+        WAVE_SYNC();
+        co_reset_tree_to_child(w, t, choice);
+        return choice;
+      }
+      int32_t target = (int32_t)(co_mt_next(w.mt, &w.gc.rng_idx) % (uint32_t)visits);
+      int32_t total = 0;
+      for (int e = 0; e < n; ++e) {
+        if (ch[e].x == CO_NONE || co_res_won(co_slot_result(ch[e]))) continue;
+        total += co_slot_visits(ch[e]);
+        if (total > target) {
+          choice = (int)(ch[e].z & 127u);
+          chosen_e = e;
+          break;
+        }
+      }
+      if (chosen_e < 0) {
+        w.gc.error |= CO_ERR_INTERNAL;
+        return choice;
+      }
+      co_move_down(t, ch[chosen_e].x);
+      return choice;
+    }
+    /* chooseMoveNormal :429-473 */
+    int max_visits = 0;
+    float max_eval = 0.0f;
+    for (int e = 0; e < n; ++e) {
+      if (ch[e].x == CO_NONE) continue;
+      int r = co_slot_result(ch[e]);
+      if (co_res_won(r)) continue;
+      float ev = co_u2f(ch[e].y);
+      if (r == CO_RESULT_DRAW || r == CO_DEDUCED_DRAW) ev = 0.0f;
+      int v = co_slot_visits(ch[e]);
+      if (v > max_visits || (v == max_visits && ev > max_eval)) {
+        choice = (int)(ch[e].z & 127u);
+        chosen_e = e;
+        max_visits = v;
+        max_eval = ev;
+      }
+    }
+    if (policy) {
+      FOR_LANES {
+        if (lane == 0) policy[choice] = 1.0f;
+      }
+      WAVE_SYNC();
+    }
+    if (max_visits == 0) {
+      co_reset_tree_to_child(w, t, choice);
+      return choice;
+    }
+    co_move_down(t, ch[chosen_e].x);
+    return choice;
+  }
+  /* won / lost / drawn roots */
+  if (policy) {
+    FOR_LANES {
+      if (lane == 0) policy[choice] = 1.0f;
+    }
+    WAVE_SYNC();
+  }
+  if (chosen_e < 0) {
+    /* the reference would move to the first child here; it cannot happen for a
+     * root whose result was deduced from its children */
+    w.gc.error |= CO_ERR_INTERNAL;
+    return choice;
+  }
+  co_move_down(t, ch[chosen_e].x);
+  return choice;
+}
+
+/* TrainMC::receiveOpponentMove, trainmc.cpp:180-204.  (board, meta) is the
+ * opponent's new root position.  Returns "needs an evaluation". */
+CO_DEV int co_receive_opponent_move(CoWave &w, CoTree &t, int move_choice, uint64_t board, uint32_t meta_game,
+                                    int depth) {
+  uint4 *A = t.A;
+  uint32_t root = t.tc.root;
+  int n = (int)CO_META_NEDGES(co_load_unit(A, root).z);
+  uint32_t found = CO_NONE;
+  for (int base = 0; base < n; base += CO_WAVE) {
+    LV(int, hit);
+    LV(uint32_t, cb);
+    FOR_LANES {
+      int e = base + lane;
+      L(hit) = 0;
+      L(cb) = CO_NONE;
+      if (e < n) {
+        uint4 s = A[root + 2 + e];
+        L(cb) = s.x;
+        L(hit) = (s.x != CO_NONE) && ((int)(s.z & 127u) == move_choice);
+      }
+    }
+    uint64_t m = WAVE_BALLOT(hit);
+    if (m) found = WAVE_BCAST(cb, co_ffs64(m) - 1);
+  }
+  if (found != CO_NONE) {
+    co_move_down(t, found);
+    return 0;
+  }
+  int res;
+  uint32_t b = co_create_node(w, t, board, meta_game, depth, CO_NONE, CO_NONE, &res);
+  if (b == CO_NONE) return 1;
+  t.tc.root = b;
+  co_request_root(w, t);
+  t.tc.searches_done = 1;
+  return 1;
+}
+
+/* SelfPlayer::chooseMoveAndContinue, selfplayer.cpp:246-291 (+ chooseMove
+ * :234-244, endGame :206-232).  Returns "game over". */
+CO_DEV int co_choose_move_and_continue(CoWave &w) {
+  int need_eval = 0;
+  while (!need_eval) {
+    if (w.gc.error) return 0;
+    int p = w.gc.to_play;
+    CoTree &me = w.tr[p];
+    uint4 rs = co_load_unit(me.A, co_load_unit(me.A, me.tc.root + 1).x);
+    if (co_res_known(co_slot_result(rs)) && w.gc.mate_turn == 0) w.gc.mate_turn = w.gc.n_samples + 1;
+    float *sample = (float *)0;
+    if (!w.testing) {
+      if (w.gc.n_samples >= CO_MAX_PLIES) {
+        w.gc.error |= CO_ERR_TOO_MANY_PLIES;
+        return 0;
+      }
+      sample = w.samples + (size_t)w.gc.n_samples * CO_SAMPLE_FLOATS;
+    }
+    int choice = co_choose_move(w, me, sample);
+    if (w.gc.error) return 0;
+    if (!w.testing) w.gc.n_samples++;
+    co_trace_push(w, choice);
+    w.gc.plies++;
+    /* new root of the mover */
+    uint4 h0 = co_load_unit(me.A, me.tc.root);
+    uint4 nrs = co_load_unit(me.A, co_load_unit(me.A, me.tc.root + 1).x);
+    int nres = co_slot_result(nrs);
+    if (co_res_terminal(nres)) {
+      if (nres == CO_RESULT_DRAW) w.gc.result = CO_RESULT_DRAW;
+      else if (p == 1) w.gc.result = CO_RESULT_LOSS;
+      else w.gc.result = CO_RESULT_WIN;
+      return 1;
+    }
+    w.gc.to_play = 1 - p;
+    CoTree &opp = w.tr[1 - p];
+    uint64_t board = (uint64_t)h0.x | ((uint64_t)h0.y << 32);
+    int depth = (int)CO_META_DEPTH(h0.z);
+    if (opp.tc.root == CO_NONE) {
+      /* first move of the second player: createRoot + doIteration */
+      int res;
+      uint32_t b = co_create_node(w, opp, board, h0.z, depth, CO_NONE, CO_NONE, &res);
+      if (b == CO_NONE) return 0;
+      opp.tc.root = b;
+      return co_mc_do_iteration(w, opp, (const float *)0, (const float *)0);
+    }
+    need_eval = co_receive_opponent_move(w, opp, choice, board, h0.z, depth);
+    if (!need_eval) need_eval = !co_mc_do_iteration(w, opp, (const float *)0, (const float *)0);
+  }
+  return 0;
+}
+
+/* SelfPlayer::doIteration, selfplayer.cpp:115-122 */
+CO_DEV int co_sp_do_iteration(CoWave &w, const float *eval, const float *probs) {
+  int done = co_mc_do_iteration(w, w.tr[w.gc.to_play], eval, probs);
+  if (w.gc.error) return 0;
+  if (done) return co_choose_move_and_continue(w);
+  return 0;
+}
+
+/* Trainer::doIteration for game g (trainer.cpp:164-236): the body of the
+ * `omp parallel for`, one wavefront per game. */
+CO_DEV void co_mcts_step_wave(const EngineParams &P, int g) {
+  GameCtl gc = P.games[g];
+  if (gc.done || gc.error) return;
+  if (P.to_play == 0 || P.to_play == 1) {
+    if (gc.to_play != (P.to_play + gc.parity) % 2) return;
+  } else if (P.stagger_div > 0) {
+    if ((P.game_base + g) / P.stagger_div > P.iteration) return;
+  }
+  CoWave w;
+  w.g = g;
+  w.gc = gc;
+  for (int p = 0; p < 2; ++p) {
+    w.tr[p].A = P.arena + (size_t)(2 * g + p) * ((size_t)P.cap_units + CO_ARENA_PAD);
+    w.tr[p].tc = P.trees[2 * g + p];
+    w.tr[p].cap = P.cap_units;
+  }
+  w.mt = P.rng + (size_t)g * CO_MT_N;
+  w.pend_leaf = P.pend_leaf + (size_t)g * P.searches_per_eval;
+  w.pend_depth = P.pend_depth + (size_t)g * P.searches_per_eval;
+  w.pend_path = P.pend_path + (size_t)g * P.searches_per_eval * CO_PATH_MAX;
+  w.req = P.req + (size_t)g * P.searches_per_eval * CO_STATE_STRIDE;
+  w.samples = P.samples ? P.samples + (size_t)g * CO_MAX_PLIES * CO_SAMPLE_FLOATS : (float *)0;
+  w.trace = P.trace ? P.trace + (size_t)g * CO_TRACE_CAP : (int32_t *)0;
+  w.max_searches = P.max_searches;
+  w.spe = P.searches_per_eval;
+  w.testing = P.testing;
+  w.trace_on = P.trace_on && P.trace;
+  w.c_puct = P.c_puct;
+  w.epsilon = P.epsilon;
+  int off = P.req_offset[g];
+  int done = co_sp_do_iteration(w, P.nn_eval + off, P.nn_probs + (size_t)off * CO_NUM_MOVES);
+  if (done) w.gc.done = 1;
+  FOR_LANES {
+    if (lane == 0) {
+      P.games[g] = w.gc;
+      P.trees[2 * g] = w.tr[0].tc;
+      P.trees[2 * g + 1] = w.tr[1].tc;
+    }
+  }
+}

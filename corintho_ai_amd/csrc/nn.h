@@ -1,0 +1,41 @@
+// nn.h -- policy/value network interface of the fused mode.
+//
+// A net evaluates the compact, game-major batch of leaf states produced by K4
+// (rows of CO_STATE_STRIDE floats, 70 used) and writes one value and 96 prior
+// probabilities per row, in the order the search reads them back
+// (main.pyx:70-83 get_predictions: evals[:n] = res[0].flatten(); probs[:n] = res[1]).
+// The row count lives on the device (req_offset[G]); kernels are launched for
+// `rows_cap` rows and workgroups beyond the count exit, so the play loop never
+// waits for the host.  Results of a row depend on that row only (fixed
+// reduction order, no batch-dependent tiling): SURVEY 8e invariant.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include "rt.h"
+
+#define CO_NET_MLP12X100 1
+#define CO_NET_RESCNN4 2
+
+/* mlp12x100 flat weight layout (float32), matching Keras get_weights() order of
+ * wrapper.py:256-271:
+ *   for l in 0..11: kernel[in_l][100], bias[100], gamma[100], beta[100], moving_mean[100], moving_var[100]
+ *   value head: kernel[100][1], bias[1];  policy head: kernel[100][96], bias[96]
+ * in_0 = 70, in_l = 100.  BatchNormalization epsilon = 1e-3 (Keras default). */
+#define CO_MLP_LAYERS 12
+#define CO_MLP_WIDTH 100
+#define CO_MLP_NUM_WEIGHTS (70 * 100 + 500 + 11 * (100 * 100 + 500) + 100 + 1 + 100 * 96 + 96)
+#define CO_BN_EPS 1e-3
+
+struct CoNet {
+  virtual ~CoNet() {}
+  virtual size_t max_rows() const = 0;
+  virtual int kind() const = 0;
+  /* d_rows: device int32 holding the number of valid rows (<= rows_cap) */
+  virtual void forward(const float *d_in, int32_t rows_cap, const int32_t *d_rows, float *d_eval, float *d_probs,
+                       rt_stream_t s) = 0;
+  /* algorithmic flop per row, for the roofline */
+  virtual double flop_per_row() const = 0;
+};
+
+CoNet *co_net_create(int kind, const float *weights, size_t n_floats, size_t max_rows, rt_stream_t s);

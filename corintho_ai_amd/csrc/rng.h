@@ -1,0 +1,74 @@
+// rng.h -- std::mt19937 per game, state in HBM, lane-parallel twist and draw.
+//
+// The reference gives every game one std::mt19937 shared by its two searchers
+// (selfplayer.cpp:23-28) and consumes raw 32-bit outputs: one per legal move
+// of every evaluated leaf (trainmc.cpp:236-246) and one per opening ply
+// (trainmc.cpp:407).  The stream must be reproduced exactly.
+// MT19937-32: n 624, m 397, a 0x9908B0DF, tempering (11; 7,0x9D2C5680;
+// 15,0xEFC60000; 18).  The twist's data dependences (x[i] needs new x[i-227]
+// for i >= 227 and old x[i+1]) allow ten 64-lane chunks in index order.
+#pragma once
+#include "engine_defs.h"
+#include "wave.h"
+
+CO_DEV uint32_t co_mt_temper(uint32_t y) {
+  y ^= y >> 11;
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= y >> 18;
+  return y;
+}
+
+/* mt = this game's 624 state words */
+CO_DEV void co_mt_twist(uint32_t *mt) {
+  for (int c = 0; c < (CO_MT_N + CO_WAVE - 1) / CO_WAVE; ++c) {
+    LV(uint32_t, nv);
+    FOR_LANES {
+      int i = c * CO_WAVE + lane;
+      if (i < CO_MT_N) {
+        int i1 = i + 1 == CO_MT_N ? 0 : i + 1;
+        int im = i + 397 >= CO_MT_N ? i + 397 - CO_MT_N : i + 397;
+        uint32_t y = (mt[i] & 0x80000000u) | (mt[i1] & 0x7fffffffu);
+        L(nv) = mt[im] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+      }
+    }
+    WAVE_SYNC();
+    FOR_LANES {
+      int i = c * CO_WAVE + lane;
+      if (i < CO_MT_N) mt[i] = L(nv);
+    }
+    WAVE_SYNC();
+  }
+}
+
+/* Draw `n` (<= 64) consecutive outputs: lane j < n receives output number j.
+ * `idx` is the game's position in the state (uniform, updated). */
+#define CO_MT_DRAW(mt, idx, n, outvar)                          \
+  do {                                                          \
+    int _done = 0;                                              \
+    while (_done < (n)) {                                       \
+      if ((idx) >= CO_MT_N) {                                   \
+        co_mt_twist(mt);                                        \
+        (idx) = 0;                                              \
+      }                                                         \
+      int _take = (n)-_done;                                    \
+      if (_take > CO_MT_N - (idx)) _take = CO_MT_N - (idx);     \
+      FOR_LANES {                                               \
+        int _j = lane - _done;                                  \
+        if (_j >= 0 && _j < _take) L(outvar) = co_mt_temper((mt)[(idx) + _j]); \
+      }                                                         \
+      (idx) += _take;                                           \
+      _done += _take;                                           \
+    }                                                           \
+  } while (0)
+
+/* one output, uniform */
+CO_DEV uint32_t co_mt_next(uint32_t *mt, int *idx) {
+  if (*idx >= CO_MT_N) {
+    co_mt_twist(mt);
+    *idx = 0;
+  }
+  uint32_t y = co_mt_temper(mt[*idx]);
+  *idx += 1;
+  return y;
+}

@@ -1,0 +1,94 @@
+// rt.h -- the few runtime calls the host engine needs.
+// Product build: HIP runtime (streams, events, async copies).
+// tests/emu build (-DCO_EMU): plain host memory and a block loop, so the same
+// engine code runs the same kernel source on a machine without a GPU.
+#pragma once
+#include <stdexcept>
+#include <string>
+
+#include "wave.h"
+
+#ifdef CO_EMU
+#include <stdlib.h>
+#include <string.h>
+typedef int rt_stream_t;
+struct rt_event_t {
+  int dummy;
+};
+inline void rt_set_device(int) {}
+inline void rt_malloc(void **p, size_t n) {
+  *p = calloc(1, n ? n : 1);
+  if (!*p) throw std::runtime_error("emu: out of memory");
+}
+inline void rt_free(void *p) { free(p); }
+inline void rt_h2d(void *d, const void *h, size_t n, rt_stream_t) { memcpy(d, h, n); }
+inline void rt_d2h(void *h, const void *d, size_t n, rt_stream_t) { memcpy(h, d, n); }
+inline void rt_d2d(void *d, const void *s, size_t n, rt_stream_t) { memcpy(d, s, n); }
+inline void rt_memset(void *d, int v, size_t n, rt_stream_t) { memset(d, v, n); }
+inline void rt_sync(rt_stream_t) {}
+inline void rt_stream_create(rt_stream_t *s) { *s = 0; }
+inline void rt_stream_destroy(rt_stream_t) {}
+inline void rt_event_create(rt_event_t *) {}
+inline void rt_event_destroy(rt_event_t) {}
+inline void rt_event_record(rt_event_t, rt_stream_t) {}
+inline float rt_event_elapsed_ms(rt_event_t, rt_event_t) { return 0.0f; }
+inline void rt_host_alloc(void **p, size_t n) { rt_malloc(p, n); }
+inline void rt_host_free(void *p) { free(p); }
+#define RT_LAUNCH(kernel, grid, block, stream, ...)      \
+  do {                                                   \
+    int _grid = (int)(grid);                             \
+    _Pragma("omp parallel for schedule(dynamic, 1)")     \
+    for (int _b = 0; _b < _grid; ++_b) {                 \
+      co_emu_block_idx = _b;                             \
+      kernel(__VA_ARGS__);                               \
+    }                                                    \
+  } while (0)
+#else
+#include <hip/hip_runtime.h>
+typedef hipStream_t rt_stream_t;
+typedef hipEvent_t rt_event_t;
+inline void rt_check(hipError_t e, const char *what) {
+  if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+}
+#define RT_CHECK(x) rt_check((x), #x)
+inline void rt_set_device(int d) { RT_CHECK(hipSetDevice(d)); }
+inline void rt_malloc(void **p, size_t n) {
+  RT_CHECK(hipMalloc(p, n ? n : 1));
+  RT_CHECK(hipMemset(*p, 0, n ? n : 1));
+}
+inline void rt_free(void *p) {
+  if (p) (void)hipFree(p);
+}
+inline void rt_h2d(void *d, const void *h, size_t n, rt_stream_t s) {
+  if (n) RT_CHECK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s));
+}
+inline void rt_d2h(void *h, const void *d, size_t n, rt_stream_t s) {
+  if (n) RT_CHECK(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s));
+}
+inline void rt_d2d(void *d, const void *s_, size_t n, rt_stream_t s) {
+  if (n) RT_CHECK(hipMemcpyAsync(d, s_, n, hipMemcpyDeviceToDevice, s));
+}
+inline void rt_memset(void *d, int v, size_t n, rt_stream_t s) {
+  if (n) RT_CHECK(hipMemsetAsync(d, v, n, s));
+}
+inline void rt_sync(rt_stream_t s) { RT_CHECK(hipStreamSynchronize(s)); }
+inline void rt_stream_create(rt_stream_t *s) { RT_CHECK(hipStreamCreateWithFlags(s, hipStreamNonBlocking)); }
+inline void rt_stream_destroy(rt_stream_t s) { (void)hipStreamDestroy(s); }
+inline void rt_event_create(rt_event_t *e) { RT_CHECK(hipEventCreate(e)); }
+inline void rt_event_destroy(rt_event_t e) { (void)hipEventDestroy(e); }
+inline void rt_event_record(rt_event_t e, rt_stream_t s) { RT_CHECK(hipEventRecord(e, s)); }
+inline float rt_event_elapsed_ms(rt_event_t a, rt_event_t b) {
+  float ms = 0.0f;
+  RT_CHECK(hipEventElapsedTime(&ms, a, b));
+  return ms;
+}
+inline void rt_host_alloc(void **p, size_t n) { RT_CHECK(hipHostMalloc(p, n ? n : 1, hipHostMallocDefault)); }
+inline void rt_host_free(void *p) {
+  if (p) (void)hipHostFree(p);
+}
+#define RT_LAUNCH(kernel, grid, block, stream, ...)                                           \
+  do {                                                                                        \
+    hipLaunchKernelGGL(kernel, dim3((unsigned)(grid)), dim3((unsigned)(block)), 0, stream, __VA_ARGS__); \
+    RT_CHECK(hipGetLastError());                                                              \
+  } while (0)
+#endif

@@ -1,0 +1,161 @@
+// wave.h -- the wavefront programming layer of the MCTS kernels.
+//
+// The self-play kernels give ONE 64-lane wavefront to one game.  Control flow is
+// wave-uniform by construction; lane parallelism appears only in short
+// "FOR_LANES" sections (edge scans, legal-move generation, prior filtering,
+// state expansion) separated by explicit cross-lane operations (ballot, max,
+// broadcast).  This header names those few operations.
+//
+// Two builds of the same kernel source exist:
+//   * the product: hipcc --offload-arch=gfx950.  LV(T,x) is a register, L(x) is
+//     x, FOR_LANES runs its body once with `lane` = the hardware lane id, the
+//     cross-lane macros are CDNA4 wave intrinsics (64-wide, DPP / ds_bpermute /
+//     v_readlane).
+//   * tests/emu (g++ -DCO_EMU): LV(T,x) is T x[64], FOR_LANES is a loop over
+//     lanes.  It exists so that the kernel LOGIC can be tested and run under
+//     ASan/UBSan on a machine without a GPU.  It is test infrastructure and is
+//     never loaded by the product.
+//
+// Rules for code written against this layer:
+//   - a value used outside FOR_LANES is wave-uniform (identical in all lanes);
+//   - inside one FOR_LANES section a lane never reads memory another lane
+//     writes in the same section (no lockstep assumptions);
+//   - cross-lane data moves only through the WAVE_* macros or through memory
+//     between two sections.
+#pragma once
+#include <stdint.h>
+
+#define CO_WAVE 64
+
+#ifdef CO_EMU
+// ------------------------------------------------------------------ emulation
+#include <math.h>
+#include <string.h>
+struct uint4 {
+  uint32_t x, y, z, w;
+};
+static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
+  uint4 v = {x, y, z, w};
+  return v;
+}
+#define CO_DEV static inline
+#define CO_KERNEL static void
+#define CO_CONST static const
+#define LV(T, x) T x[CO_WAVE]
+#define L(x) x[lane]
+#define LAT(x, i) x[(i)]
+#define FOR_LANES for (int lane = 0; lane < CO_WAVE; ++lane)
+#define WAVE_SHARED(T, x, n) T x[n]
+#define WAVE_SYNC() ((void)0)
+#define UNI_I(x) (x)
+#define UNI_U(x) (x)
+#define UNI_F(x) (x)
+
+static inline uint64_t emu_ballot(const int *p) {
+  uint64_t m = 0;
+  for (int i = 0; i < CO_WAVE; ++i)
+    if (p[i]) m |= 1ull << i;
+  return m;
+}
+static inline float emu_max_f32(const float *p) {
+  float m = p[0];
+  for (int i = 1; i < CO_WAVE; ++i) m = p[i] > m ? p[i] : m;
+  return m;
+}
+static inline int emu_sum_i32(const int *p) {
+  int s = 0;
+  for (int i = 0; i < CO_WAVE; ++i) s += p[i];
+  return s;
+}
+#define WAVE_BALLOT(p) emu_ballot(p)
+#define WAVE_MAX_F32(x) emu_max_f32(x)
+#define WAVE_SUM_I32(x) emu_sum_i32(x)
+#define WAVE_BCAST(x, i) (x[(i)])
+static inline int co_popc64(uint64_t v) { return __builtin_popcountll(v); }
+static inline int co_popc32(uint32_t v) { return __builtin_popcount(v); }
+static inline int co_ffs64(uint64_t v) { return __builtin_ffsll((long long)v); } /* 1-based, 0 if none */
+static inline double co_sqrt_f64(double x) { return sqrt(x); }
+extern thread_local int co_emu_block_idx;
+#define CO_BLOCK_IDX co_emu_block_idx
+
+#else
+// ------------------------------------------------------------------- gfx950
+#include <hip/hip_runtime.h>
+#define CO_DEV __device__ __forceinline__
+#define CO_KERNEL __global__ void
+#define CO_CONST __device__ const
+#define LV(T, x) T x
+#define L(x) x
+#define LAT(x, i) x
+#define FOR_LANES for (int lane = (int)(threadIdx.x & 63), _co_once = 1; _co_once; _co_once = 0)
+#define WAVE_SHARED(T, x, n) __shared__ T x[n]
+// one wave per workgroup: a wave barrier orders LDS traffic of the wave
+#define WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+#define UNI_I(x) __builtin_amdgcn_readfirstlane((int)(x))
+#define UNI_U(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+#define UNI_F(x) __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x)))
+
+__device__ __forceinline__ float co_wave_max_f32(float v) {
+  // butterfly over 64 lanes; max is exact and order independent
+  for (int o = 32; o >= 1; o >>= 1) {
+    float t = __shfl_xor(v, o, 64);
+    v = t > v ? t : v;
+  }
+  return v;
+}
+__device__ __forceinline__ int co_wave_sum_i32(int v) {
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <typename T>
+__device__ __forceinline__ T co_bcast(T v, int i);
+template <>
+__device__ __forceinline__ int co_bcast<int>(int v, int i) {
+  return __shfl(v, i, 64);
+}
+template <>
+__device__ __forceinline__ uint32_t co_bcast<uint32_t>(uint32_t v, int i) {
+  return (uint32_t)__shfl((int)v, i, 64);
+}
+template <>
+__device__ __forceinline__ float co_bcast<float>(float v, int i) {
+  return __shfl(v, i, 64);
+}
+template <>
+__device__ __forceinline__ uint4 co_bcast<uint4>(uint4 v, int i) {
+  uint4 r;
+  r.x = (uint32_t)__shfl((int)v.x, i, 64);
+  r.y = (uint32_t)__shfl((int)v.y, i, 64);
+  r.z = (uint32_t)__shfl((int)v.z, i, 64);
+  r.w = (uint32_t)__shfl((int)v.w, i, 64);
+  return r;
+}
+#define WAVE_BALLOT(p) ((uint64_t)__ballot(p))
+#define WAVE_MAX_F32(x) co_wave_max_f32(x)
+#define WAVE_SUM_I32(x) co_wave_sum_i32(x)
+#define WAVE_BCAST(x, i) co_bcast(x, (i))
+__device__ __forceinline__ int co_popc64(uint64_t v) { return __popcll(v); }
+__device__ __forceinline__ int co_popc32(uint32_t v) { return __popc(v); }
+__device__ __forceinline__ int co_ffs64(uint64_t v) { return __ffsll((unsigned long long)v); }
+__device__ __forceinline__ double co_sqrt_f64(double x) { return __builtin_sqrt(x); }
+#define CO_BLOCK_IDX ((int)blockIdx.x)
+#endif
+
+CO_DEV float co_u2f(uint32_t u) {
+#ifdef CO_EMU
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+#else
+  return __uint_as_float(u);
+#endif
+}
+CO_DEV uint32_t co_f2u(float f) {
+#ifdef CO_EMU
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  return u;
+#else
+  return __float_as_uint(f);
+#endif
+}

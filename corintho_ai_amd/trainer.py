@@ -1,0 +1,166 @@
+"""Host-side mirror of the reference's Trainer for the MI355X engine.
+
+Same names, argument meaning and protocol as the Cython-declared C++ class
+(corintho_ai/python/main.pyx:17-38, corintho_ai/cpp/include/trainer.h:17-81):
+
+    t = Trainer(num_games, log_folder, seed, max_searches, searches_per_eval,
+                c_puct, epsilon, num_logged, num_threads, testing)
+    while not t.doIteration(evals, probs, to_play):
+        n = t.num_requests(to_play); t.writeRequests(game_states, to_play)
+        evals[:n], probs[:n] = model(game_states[:n])
+    t.num_samples(); t.writeSamples(gs, ev, pr); t.score(); t.avg_mate_length()
+
+plus the fused mode (`set_net`, `run`) in which the network runs on the GPU.
+Buffers are caller-owned C-contiguous float32 numpy arrays, as in main.pyx:132-134.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+GAME_STATE_SIZE = 70
+NUM_MOVES = 96
+NUM_SYMMETRIES = 8
+
+NET_MLP12X100 = 1
+NET_RESCNN4 = 2
+
+
+def _f32(a, what):
+    if not isinstance(a, np.ndarray) or a.dtype != np.float32 or not a.flags["C_CONTIGUOUS"]:
+        raise TypeError("%s must be a C-contiguous float32 numpy array" % what)
+    return a.ctypes.data_as(_lib.f32p)
+
+
+class Trainer:
+    def __init__(self, num_games, log_folder="", seed=0, max_searches=1600, searches_per_eval=16, c_puct=1.0,
+                 epsilon=0.25, num_logged=0, num_threads=1, testing=False, *, device=0, stagger=True, arena_units=0,
+                 trace=False, game_base=0, total_games=0, _cdll=None):
+        self._L = _cdll if _cdll is not None else _lib.load()
+        self._t = C.c_void_p()
+        if num_logged:
+            raise ValueError("per-game text logs (num_logged > 0) are not produced by the device engine")
+        cfg = _lib.CaConfig(num_games=num_games, seed=int(seed) & 0x7FFFFFFF if seed >= 0 else int(seed),
+                            max_searches=max_searches, searches_per_eval=searches_per_eval, c_puct=c_puct,
+                            epsilon=epsilon, num_logged=0, num_threads=num_threads, testing=int(bool(testing)),
+                            device=device, no_stagger=int(not stagger), arena_units=arena_units, trace=int(bool(trace)),
+                            game_base=game_base, total_games=total_games)
+        self.num_games = num_games
+        self.searches_per_eval = searches_per_eval
+        self.testing = bool(testing)
+        _lib.check(self._L, self._L.ca_trainer_create(C.byref(cfg), C.byref(self._t)))
+
+    def close(self):
+        if getattr(self, "_t", None) and self._t.value:
+            self._L.ca_trainer_destroy(self._t)
+            self._t = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- reference surface (main.pyx:30-38) ----
+    def num_requests(self, to_play=-1):
+        out = C.c_int32()
+        _lib.check(self._L, self._L.ca_trainer_num_requests(self._t, to_play, C.byref(out)))
+        return out.value
+
+    def num_samples(self):
+        out = C.c_int32()
+        _lib.check(self._L, self._L.ca_trainer_num_samples(self._t, C.byref(out)))
+        return out.value
+
+    def score(self):
+        out = C.c_float()
+        _lib.check(self._L, self._L.ca_trainer_score(self._t, C.byref(out)))
+        return out.value
+
+    def avg_mate_length(self):
+        out = C.c_float()
+        _lib.check(self._L, self._L.ca_trainer_avg_mate_length(self._t, C.byref(out)))
+        return out.value
+
+    def writeRequests(self, game_states, to_play=-1):
+        _lib.check(self._L, self._L.ca_trainer_write_requests(self._t, _f32(game_states, "game_states"), to_play))
+
+    def writeSamples(self, game_states, eval_samples, prob_samples):
+        _lib.check(self._L, self._L.ca_trainer_write_samples(self._t, _f32(game_states, "game_states"),
+                                                             _f32(eval_samples, "eval_samples"),
+                                                             _f32(prob_samples, "prob_samples")))
+
+    def writeScores(self, file):
+        if isinstance(file, str):
+            file = file.encode()
+        _lib.check(self._L, self._L.ca_trainer_write_scores(self._t, file))
+
+    def doIteration(self, evaluations, probabilities, to_play=-1):
+        done = C.c_int32()
+        _lib.check(self._L, self._L.ca_trainer_do_iteration(self._t, _f32(evaluations, "evaluations"),
+                                                            _f32(probabilities, "probabilities"), to_play,
+                                                            C.byref(done)))
+        return bool(done.value)
+
+    # ---- fused mode ----
+    def set_net(self, kind, weights, slot=0):
+        w = np.ascontiguousarray(weights, dtype=np.float32)
+        _lib.check(self._L, self._L.ca_trainer_set_net(self._t, slot, kind, _f32(w, "weights"), w.size))
+
+    def run(self, max_iterations=0):
+        done = C.c_int32()
+        _lib.check(self._L, self._L.ca_trainer_run(self._t, max_iterations, C.byref(done)))
+        return bool(done.value)
+
+    def net_forward(self, states, slot=0):
+        s = np.ascontiguousarray(states, dtype=np.float32)
+        n = s.shape[0]
+        ev = np.zeros(n, np.float32)
+        pr = np.zeros((n, NUM_MOVES), np.float32)
+        _lib.check(self._L, self._L.ca_trainer_net_forward(self._t, slot, _f32(s, "states"), n, _f32(ev, "ev"),
+                                                           _f32(pr, "pr")))
+        return ev, pr
+
+    def export_samples(self):
+        n = self.num_samples()
+        sp = np.zeros((n, GAME_STATE_SIZE + NUM_MOVES), np.float32)
+        oc = np.zeros(n, np.float32)
+        if n:
+            _lib.check(self._L, self._L.ca_trainer_export_samples(self._t, _f32(sp, "sp"), _f32(oc, "oc")))
+        return sp, oc
+
+    # ---- introspection ----
+    def stats(self):
+        s = _lib.CaStats()
+        _lib.check(self._L, self._L.ca_trainer_stats(self._t, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in s._fields_}
+
+    def game_info(self, g):
+        out = (C.c_int32 * 8)()
+        _lib.check(self._L, self._L.ca_trainer_game_info(self._t, g, out))
+        keys = ("to_play", "done", "result", "n_samples", "n_pending", "error", "mate_turn", "plies")
+        return dict(zip(keys, list(out)))
+
+    def trace(self, g):
+        n = C.c_int32()
+        _lib.check(self._L, self._L.ca_trainer_trace(self._t, g, None, 0, C.byref(n)))
+        out = np.zeros(max(n.value, 1), np.int32)
+        _lib.check(self._L, self._L.ca_trainer_trace(self._t, g, out.ctypes.data_as(_lib.i32p), n.value, C.byref(n)))
+        return out[: n.value]
+
+
+def expand_samples(state_policy, outcome, device=0, _cdll=None):
+    """x8 symmetry expansion of gathered (state, policy, outcome) rows ->
+    the three arrays of Trainer::writeSamples (trainer.cpp:103-113)."""
+    L = _cdll if _cdll is not None else _lib.load()
+    sp = np.ascontiguousarray(state_policy, dtype=np.float32)
+    oc = np.ascontiguousarray(outcome, dtype=np.float32)
+    n = sp.shape[0]
+    gs = np.zeros((n * NUM_SYMMETRIES, GAME_STATE_SIZE), np.float32)
+    ev = np.zeros(n * NUM_SYMMETRIES, np.float32)
+    pr = np.zeros((n * NUM_SYMMETRIES, NUM_MOVES), np.float32)
+    if n:
+        _lib.check(L, L.ca_expand_samples(device, _f32(sp, "sp"), _f32(oc, "oc"), n, _f32(gs, "gs"), _f32(ev, "ev"),
+                                          _f32(pr, "pr")))
+    return gs, ev, pr

@@ -1,0 +1,151 @@
+/* corintho_hip.h -- C ABI of libcorintho_hip.so, the MI355X self-play engine.
+ *
+ * Drop-in boundary for the reference's hot path.  The reference exposes a C++
+ * class consumed at source level by Cython
+ * (corintho_ai/python/main.pyx:17-38  `cdef cppclass Trainer`, declared in
+ * corintho_ai/cpp/include/trainer.h:17-81).  Each entry point below replaces
+ * one member of that class; corintho_ai_amd/cpp/trainer.h wraps them back into
+ * a `class Trainer` with the reference's exact signatures, so main.pyx compiles
+ * against it unchanged.
+ *
+ * Conventions: every function returns 0 on success and a negative code on
+ * failure; ca_last_error() gives the message (thread local).  All buffers are
+ * caller-owned host memory, C-contiguous float32, laid out exactly as the
+ * reference lays them out (main.pyx:132-134, 194-198).  No pointer is retained
+ * across calls.  One ca_trainer drives one GPU; it is not thread safe (the
+ * reference is called with the GIL held).
+ */
+#ifndef CORINTHO_HIP_H
+#define CORINTHO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CA_GAME_STATE_SIZE 70 /* util.h:42 kGameStateSize */
+#define CA_NUM_MOVES 96       /* util.h:44 kNumMoves */
+#define CA_NUM_SYMMETRIES 8   /* util.h:48 kNumSymmetries */
+
+#define CA_OK 0
+#define CA_ERR_ARG -1
+#define CA_ERR_DEVICE -2   /* HIP failure, no GPU, extension built for another arch */
+#define CA_ERR_ENGINE -3   /* a game reported an engine error (arena full, ...) */
+#define CA_ERR_STATE -4    /* call made in the wrong state */
+#define CA_ERR_IO -5
+
+typedef struct ca_trainer ca_trainer;
+
+/* Trainer::Trainer arguments (trainer.h:22-25) followed by device options that
+ * have no reference counterpart.  Zero-initialise, then fill. */
+typedef struct ca_config {
+  /* reference ctor arguments, same meaning and defaults as trainer.h:22-25 */
+  int32_t num_games;
+  int32_t seed;
+  int32_t max_searches;       /* default 1600 */
+  int32_t searches_per_eval;  /* default 16 */
+  float c_puct;               /* default 1.0 */
+  float epsilon;              /* default 0.25 */
+  int32_t num_logged;         /* per-game text logs are not produced on device; must be 0 */
+  int32_t num_threads;        /* accepted and ignored (OpenMP width of the reference) */
+  int32_t testing;            /* arena mode: no samples, no opening temperature */
+  /* device options */
+  int32_t device;             /* HIP device ordinal */
+  int32_t no_stagger;         /* 1: start every game at iteration 0 (trainer.cpp:184-186 is a
+                                 memory heuristic; per-game results do not depend on it) */
+  uint32_t arena_units;       /* 16-byte units per search tree; 0 = default from max_searches */
+  int32_t trace;              /* keep a per-ply trace for the parity tests */
+  /* sharding (multi-GPU): this trainer owns games [game_base, game_base+num_games) of a
+   * generation of total_games games; seeds are drawn from the Trainer stream in global
+   * order and parity = global index % 2 (trainer.cpp:243-255).  0/0 = unsharded. */
+  int32_t game_base;
+  int32_t total_games;
+} ca_config;
+
+const char *ca_last_error(void);
+/* 0 if a usable gfx950 device is visible */
+int ca_device_check(int device);
+
+/* Trainer::Trainer (trainer.cpp:18-37) / ~Trainer */
+int ca_trainer_create(const ca_config *cfg, ca_trainer **out);
+void ca_trainer_destroy(ca_trainer *t);
+
+/* int Trainer::num_requests(int to_play) -- trainer.cpp:39-49 */
+int ca_trainer_num_requests(ca_trainer *t, int to_play, int32_t *out);
+/* int Trainer::num_samples() -- trainer.cpp:51-57 */
+int ca_trainer_num_samples(ca_trainer *t, int32_t *out);
+/* float Trainer::score() -- trainer.cpp:59-68 */
+int ca_trainer_score(ca_trainer *t, float *out);
+/* float Trainer::avg_mate_length() -- trainer.cpp:70-77 */
+int ca_trainer_avg_mate_length(ca_trainer *t, float *out);
+/* void Trainer::writeRequests(float *game_states, int to_play) -- trainer.cpp:79-101
+ * game_states: [num_requests(to_play)][70] */
+int ca_trainer_write_requests(ca_trainer *t, float *game_states, int to_play);
+/* void Trainer::writeSamples(float*, float*, float*) -- trainer.cpp:103-113
+ * [n*8][70], [n*8], [n*8][96] with n = num_samples() */
+int ca_trainer_write_samples(ca_trainer *t, float *game_states, float *eval_samples, float *prob_samples);
+/* void Trainer::writeScores(const std::string &file) -- trainer.cpp:115-162 */
+int ca_trainer_write_scores(ca_trainer *t, const char *file);
+/* bool Trainer::doIteration(float eval[], float probs[], int to_play) -- trainer.cpp:164-236
+ * evaluations: [num_requests], probabilities: [num_requests][96] for the rows last
+ * written by writeRequests(to_play); ignored on the first call.  *all_done = return value. */
+int ca_trainer_do_iteration(ca_trainer *t, const float *evaluations, const float *probabilities, int to_play,
+                            int32_t *all_done);
+
+/* ---------------- fused mode (no reference counterpart; opt-in) ----------------
+ * The network runs on the device, so the play loop of main.pyx:123-187 never
+ * leaves the GPU.  Weights are a flat float32 buffer in the layout documented in
+ * corintho_ai_amd/nets.py for each kind. */
+#define CA_NET_MLP12X100 1 /* the reference architecture, wrapper.py:256-271 */
+#define CA_NET_RESCNN4 2   /* the north-star 4-block residual CNN */
+/* slot 0 = best model (training, and arena `to_play == 1`), slot 1 = new model (arena
+ * `to_play == 0`), as get_predictions chooses them (main.pyx:70-83) */
+int ca_trainer_set_net(ca_trainer *t, int slot, int kind, const float *weights, size_t n_floats);
+/* Run the whole generation on the device.  max_iterations 0 = until done. */
+int ca_trainer_run(ca_trainer *t, int64_t max_iterations, int32_t *all_done);
+/* One network evaluation of host rows through the device kernels (numerics tests):
+ * states [n][70] -> evals [n], probs [n][96] */
+int ca_trainer_net_forward(ca_trainer *t, int slot, const float *states, int32_t n, float *evals, float *probs);
+
+/* Un-augmented samples for the multi-GPU gather: n = num_samples() rows of
+ * (state[70], policy[96]) + outcome[n] in game order; the x8 symmetry expansion
+ * is applied after the gather by ca_expand_samples. */
+int ca_trainer_export_samples(ca_trainer *t, float *state_policy /* [n][166] */, float *outcome /* [n] */);
+int ca_expand_samples(int device, const float *state_policy, const float *outcome, int32_t n, float *game_states,
+                      float *eval_samples, float *prob_samples);
+
+/* ---------------- introspection (tests, bench) ---------------- */
+typedef struct ca_stats {
+  int64_t searches;      /* simulations run */
+  int64_t evals;         /* leaf evaluations consumed */
+  int64_t nodes;         /* nodes created */
+  int64_t plies;
+  int64_t iterations;    /* doIteration calls / fused steps */
+  int64_t peak_arena_units; /* high-water mark over all trees */
+  double mcts_ms, nn_ms, pack_ms; /* device time by kernel family (fused mode, HIP events) */
+  int64_t mcts_launches, nn_launches;
+  int64_t nn_rows;       /* rows evaluated by the network kernels */
+} ca_stats;
+int ca_trainer_stats(ca_trainer *t, ca_stats *out);
+/* per-game: {to_play, done, result, n_samples, n_pending, error, mate_turn, plies} */
+int ca_trainer_game_info(ca_trainer *t, int game, int32_t out[8]);
+/* per-ply trace of one game, same record format as the oracle's; returns words via *n */
+int ca_trainer_trace(ca_trainer *t, int game, int32_t *out, int32_t cap, int32_t *n);
+
+/* rule layer on a batch of positions (one wavefront each): legal-move masks + is_lines */
+int ca_rules_legal_moves(int device, const uint64_t *boards, const uint32_t *metas, int32_t n, uint32_t *masks /* [n][3] */,
+                         int32_t *is_lines);
+/* apply moves[i] (or -1 for none) and expand the 70-float state */
+int ca_rules_do_move(int device, uint64_t *boards, uint32_t *metas, const int32_t *moves, int32_t n,
+                     float *states /* [n][70] */);
+/* std::mt19937 through the device draw path: n outputs for `seed`, drawn `chunk` at a time */
+int ca_rng_draw(int device, uint32_t seed, int32_t n, int32_t chunk, uint32_t *out);
+/* floating-point contract probe, see kernels.h co_k_fp_probe: in [n][8] -> out [n][8] */
+int ca_fp_probe(int device, const float *in, int32_t n, float *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

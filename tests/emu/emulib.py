@@ -1,0 +1,19 @@
+"""TEST INFRASTRUCTURE: loads the lane-loop emulation build of the engine
+(tests/emu/libcorintho_emu.so, same kernel source compiled with -DCO_EMU) so the
+CPU test-suite can check kernel logic against the oracle without a GPU."""
+import ctypes as C
+import os
+import subprocess
+
+from corintho_ai_amd import _lib
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_cache = {}
+
+
+def load(asan=False):
+    name = "libcorintho_emu_asan.so" if asan else "libcorintho_emu.so"
+    if name not in _cache:
+        subprocess.check_call(["make", "-s", "-C", _HERE, "asan" if asan else "all"])
+        _cache[name] = _lib.declare(C.CDLL(os.path.join(_HERE, name)))
+    return _cache[name]
