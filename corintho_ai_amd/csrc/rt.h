@@ -54,7 +54,10 @@ inline void rt_check(hipError_t e, const char *what) {
 inline void rt_set_device(int d) { RT_CHECK(hipSetDevice(d)); }
 inline void rt_malloc(void **p, size_t n) {
   RT_CHECK(hipMalloc(p, n ? n : 1));
+  /* hipMemset on device memory may return before it has run, and the engine's
+   * streams are non-blocking: finish the clear before anyone writes the buffer */
   RT_CHECK(hipMemset(*p, 0, n ? n : 1));
+  RT_CHECK(hipDeviceSynchronize());
 }
 inline void rt_free(void *p) {
   if (p) (void)hipFree(p);
