@@ -1,0 +1,270 @@
+#!/usr/bin/env python3
+"""Self-play throughput of the MI355X engine (BASELINE.json metric:
+"self-play games/sec at 400 sims/move").
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One STEP = one whole self-play generation of `--games` games per GPU in fused mode
+(search + network on the device), from the first iteration to the last game
+finishing, plus -- for N > 1 -- the RCCL all-gather of the un-augmented samples.
+Weak scaling: every rank owns `--games` games, a contiguous shard of a generation
+of N x games (seeds and colours follow the global game index, trainer.cpp:243-255).
+The timed region is bracketed by barrier + device synchronisation; the time is the
+max over ranks; rank 0 prints ONE JSON line.
+
+Workload (BASELINE.json configs[1] / SURVEY 8d): 4096 games per GPU, 400
+simulations per move, 16 searches per evaluation, c_puct 1.0, epsilon 0.25,
+random-init weights (seed 0), synthetic = self-generated positions.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md, chip-level parameters (dense fp32 matrix)
+HBM_PEAK_GBS = 8000.0          # ibid.
+BYTES_PER_SIM = 3200.0         # algorithmic bytes per simulation at 400 sims/move
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--games", type=int, default=4096, help="games per GPU")
+    ap.add_argument("--sims", type=int, default=400)
+    ap.add_argument("--spe", type=int, default=16)
+    ap.add_argument("--c-puct", type=float, default=1.0)
+    ap.add_argument("--epsilon", type=float, default=0.25)
+    ap.add_argument("--net", default="mlp12x100", choices=["mlp12x100", "rescnn4"])
+    ap.add_argument("--stagger", action="store_true", help="keep the reference's staggered start")
+    ap.add_argument("--arena-units", type=int, default=0)
+    ap.add_argument("--cpu-games", type=int, default=96, help="games of the bounded CPU-baseline sample (0 = skip)")
+    return ap.parse_args()
+
+
+def host_cores():
+    """cores this process may really use: affinity, cgroup quota, and the GPU box's
+    per-GPU CPU share (16) -- os.cpu_count() reports the whole host"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+            if quota != "max":
+                n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("CORINTHO_CPU_THREADS", "16"))))
+
+
+def cpu_baseline(args, weights):
+    """The oracle (CPU restatement of the reference's OpenMP path) on this box's host
+    cores, with the same network evaluated on the CPU between iterations as the
+    reference's Keras loop does (main.pyx:70-83).  Bounded sample; rank 0, N = 1 only."""
+    from corintho_ai_amd import nets
+    from oracle import oracle as O
+    from tests import harness as H
+
+    cores = host_cores()
+    G = args.cpu_games
+    try:
+        from threadpoolctl import threadpool_limits
+
+        threadpool_limits(limits=cores)  # numpy's BLAS on the same cores
+    except Exception:
+        pass
+    t = O.Trainer(G, seed=12345, max_searches=args.sims, searches_per_eval=args.spe, c_puct=args.c_puct,
+                  epsilon=args.epsilon, num_threads=cores)
+    nn_time = [0.0]
+
+    def net(states):
+        t0 = time.perf_counter()
+        out = nets.mlp12x100_forward_np(weights, states)
+        nn_time[0] += time.perf_counter() - t0
+        return out
+
+    t0 = time.perf_counter()
+    H.play_generation(t, G, args.spe, net)
+    dt = time.perf_counter() - t0
+    return {
+        "value": G / dt,
+        "unit": "games/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": "%d games x %d sims/move, spe %d, oracle/ (OpenMP, %d threads) + numpy fp32 mlp12x100 on the host; "
+                  "%.1f s total, %.1f s of it network" % (G, args.sims, args.spe, cores, dt, nn_time[0]),
+        "mcts_only_games_per_s": G / max(dt - nn_time[0], 1e-9),
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from corintho_ai_amd import NET_MLP12X100, NET_RESCNN4, Trainer, nets
+
+    G = args.games
+    if args.net == "mlp12x100":
+        weights = nets.init_mlp12x100(0)
+        kind = NET_MLP12X100
+        flop_per_row = 2.0 * (70 * 100 + 11 * 100 * 100 + 100 + 100 * 96)
+    else:
+        weights = nets.init_rescnn4(0)
+        kind = NET_RESCNN4
+        flop_per_row = nets.rescnn4_flop_per_row()
+
+    tr = Trainer(G, "", 12345, args.sims, args.spe, args.c_puct, args.epsilon, 0, 1, False, device=local_rank,
+                 stagger=args.stagger, arena_units=args.arena_units, game_base=rank * G, total_games=world * G)
+    tr.set_net(kind, weights)
+
+    gather_buf = None
+    if world > 1:
+        cap = G * 44
+        gather_buf = {
+            "sp": torch.empty((cap, 166), dtype=torch.float32, device="cuda"),
+            "oc": torch.empty((cap,), dtype=torch.float32, device="cuda"),
+            "all_sp": torch.empty((world * cap, 166), dtype=torch.float32, device="cuda"),
+            "all_oc": torch.empty((world * cap,), dtype=torch.float32, device="cuda"),
+            "cnt": torch.zeros((1,), dtype=torch.int32, device="cuda"),
+            "all_cnt": torch.zeros((world,), dtype=torch.int32, device="cuda"),
+            "cap": cap,
+        }
+
+    totals = {"searches": 0, "evals": 0, "plies": 0, "iterations": 0, "mcts_ms": 0.0, "nn_ms": 0.0, "pack_ms": 0.0,
+              "nn_rows": 0, "gather_ms": 0.0, "samples": 0, "peak_arena_units": 0}
+
+    def one_step(step_index, timed):
+        tr.reset(12345 + step_index)
+        done = tr.run()
+        if not done:
+            raise RuntimeError("generation did not finish")
+        if world > 1:
+            t0 = time.perf_counter()
+            n = tr.pack_samples_device(gather_buf["sp"].data_ptr(), gather_buf["oc"].data_ptr(), gather_buf["cap"])
+            gather_buf["cnt"][0] = n
+            dist.all_gather_into_tensor(gather_buf["all_cnt"], gather_buf["cnt"])
+            dist.all_gather_into_tensor(gather_buf["all_sp"], gather_buf["sp"])
+            dist.all_gather_into_tensor(gather_buf["all_oc"], gather_buf["oc"])
+            torch.cuda.synchronize()
+            if timed:
+                totals["gather_ms"] += (time.perf_counter() - t0) * 1e3
+        if timed:
+            st = tr.stats()
+            for k in ("searches", "evals", "plies", "iterations", "mcts_ms", "nn_ms", "pack_ms", "nn_rows"):
+                totals[k] += st[k]
+            totals["samples"] += tr.num_samples()
+            totals["peak_arena_units"] = max(totals["peak_arena_units"], st["peak_arena_units"])
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for w in range(args.warmup):
+        one_step(1000 + w, False)
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        one_step(s, True)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        agg = torch.tensor([totals["searches"], totals["evals"], totals["nn_rows"]], dtype=torch.float64, device="cuda")
+        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+        job_searches, job_evals, job_rows = [float(x) for x in agg.tolist()]
+    else:
+        job_searches, job_evals, job_rows = float(totals["searches"]), float(totals["evals"]), float(totals["nn_rows"])
+
+    if rank == 0:
+        games_total = world * G * args.steps
+        value = games_total / dt
+        nn_s = totals["nn_ms"] * 1e-3
+        mcts_s = totals["mcts_ms"] * 1e-3
+        # dominant kernel = the family with more device time on rank 0
+        if nn_s >= mcts_s:
+            achieved = totals["nn_rows"] * flop_per_row / max(nn_s, 1e-12) / 1e12
+            roofline = {"kernel": "co_k_mlp_forward" if args.net == "mlp12x100" else "co_k_rescnn_forward",
+                        "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                        "algorithmic": "%.1f KFLOP/row x %d rows" % (flop_per_row / 1e3, totals["nn_rows"]),
+                        "avg_launch_ms": totals["nn_ms"] / max(totals["iterations"], 1)}
+        else:
+            achieved = totals["searches"] * BYTES_PER_SIM / max(mcts_s, 1e-12) / 1e9
+            roofline = {"kernel": "co_k_mcts_step", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                        "algorithmic": "%.0f B/simulation x %d simulations" % (BYTES_PER_SIM, totals["searches"]),
+                        "avg_launch_ms": totals["mcts_ms"] / max(totals["iterations"], 1)}
+        out = {
+            "metric": "self-play games/sec at %d sims/move" % args.sims,
+            "value": value,
+            "unit": "games/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt * 1e3 / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "%d parallel self-play games per GPU, %d sims/move, %d searches/eval, %s (random init, seed 0), "
+                            "fused on-device search + inference, %s" % (G, args.sims, args.spe, args.net,
+                                                                        "staggered start" if args.stagger else "no stagger"),
+                "games_per_gpu": G, "sims_per_move": args.sims, "searches_per_eval": args.spe, "net": args.net,
+                "c_puct": args.c_puct, "epsilon": args.epsilon, "parallelism": "games sharded x%d" % world,
+            },
+            "roofline": roofline,
+            "detail": {
+                "sims_per_s": job_searches / dt,
+                "leaf_evals_per_s": job_evals / dt,
+                "plies_per_game": totals["plies"] / max(G * args.steps, 1),
+                "evals_per_game": totals["evals"] / max(G * args.steps, 1),
+                "iterations_per_step": totals["iterations"] / max(args.steps, 1),
+                "rank0_device_ms_per_step": {"mcts": totals["mcts_ms"] / args.steps, "network": totals["nn_ms"] / args.steps,
+                                             "pack": totals["pack_ms"] / args.steps,
+                                             "sample_gather": totals["gather_ms"] / args.steps},
+                "mcts_GBps_algorithmic": totals["searches"] * BYTES_PER_SIM / max(mcts_s, 1e-12) / 1e9,
+                "network_TFLOPs_algorithmic": totals["nn_rows"] * flop_per_row / max(nn_s, 1e-12) / 1e12,
+                "peak_arena_units_per_tree": totals["peak_arena_units"],
+            },
+        }
+        if world == 1 and args.cpu_games > 0 and args.net == "mlp12x100":
+            out["cpu_baseline"] = cpu_baseline(args, weights)
+        elif world == 1 and args.cpu_games > 0:
+            out["cpu_baseline"] = cpu_baseline(args, nets.init_mlp12x100(0))
+            out["cpu_baseline"]["sample"] += " (reference architecture mlp12x100; the CNN has no reference CPU path)"
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

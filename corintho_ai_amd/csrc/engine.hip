@@ -91,6 +91,7 @@ struct ca_trainer {
   DevBuf<uint32_t> pend_leaf, pend_path, rng;
   DevBuf<int32_t> pend_depth, req_offset, trace, all_done;
   DevBuf<float> req, nn_in, nn_eval, nn_probs, samples;
+  DevBuf<unsigned long long> row_counter;
   /* host state */
   int64_t iterations = 0;
   int32_t trainer_iteration = 0; /* Trainer::searches_done_ (train mode only) */
@@ -139,9 +140,19 @@ struct ca_trainer {
     if (!cfg.testing) samples.alloc((size_t)G * CO_MAX_PLIES * CO_SAMPLE_FLOATS);
     if (cfg.trace) trace.alloc((size_t)G * CO_TRACE_CAP);
     all_done.alloc(1);
+    row_counter.alloc(1);
 
-    /* Trainer::initialize (trainer.cpp:238-256): game i is seeded with the i-th
-     * output of mt19937(seed), in global game order */
+    reset_games(cfg.seed);
+    memset(&P, 0, sizeof P);
+    fill_params(cap, cfg.total_games > 0 ? cfg.total_games : G);
+  }
+
+  /* Trainer::initialize (trainer.cpp:238-256): game i is seeded with the i-th
+   * output of mt19937(seed), in global game order.  Also used to start a new
+   * generation in the same pool (ca_trainer_reset). */
+  void reset_games(int32_t seed) {
+    cfg.seed = seed;
+    size_t T = (size_t)2 * G;
     int total = cfg.total_games > 0 ? cfg.total_games : G;
     std::mt19937 gen((uint32_t)cfg.seed);
     std::vector<uint32_t> seeds(total);
@@ -166,9 +177,19 @@ struct ca_trainer {
     rt_h2d(rng.p, st.data(), st.size() * 4, stream);
     rt_h2d(games.p, hg.data(), hg.size() * sizeof(GameCtl), stream);
     rt_h2d(trees.p, ht.data(), ht.size() * sizeof(TreeCtl), stream);
+    rt_memset(row_counter.p, 0, 8, stream);
     rt_sync(stream);
+    iterations = 0;
+    trainer_iteration = 0;
+    scan_valid_for = -99;
+    last_total = 0;
+    finished = false;
+    host_games_valid = false;
+    mcts_ms = nn_ms = pack_ms = 0;
+    mcts_launches = nn_launches = nn_rows = 0;
+  }
 
-    memset(&P, 0, sizeof P);
+  void fill_params(uint32_t cap, int total) {
     P.num_games = G;
     P.max_searches = cfg.max_searches;
     P.searches_per_eval = spe;
@@ -198,6 +219,7 @@ struct ca_trainer {
     P.samples = samples.p;
     P.trace = trace.p;
     P.all_done = all_done.p;
+    P.row_counter = nullptr; /* counted in fused mode only */
   }
 
   /* offsets + compact batch for model `to_play` (K4) */
@@ -355,6 +377,23 @@ struct ca_trainer {
     }
   }
 
+  /* un-augmented samples packed on the device into caller-owned device memory
+   * (the multi-GPU gather hands these straight to RCCL) */
+  int32_t pack_samples_device(float *d_state_policy, float *d_outcome, int32_t cap_rows) {
+    if (cfg.testing) throw EngineError(CA_ERR_STATE, "pack_samples in testing mode");
+    fetch_games();
+    std::vector<int32_t> off(G + 1, 0);
+    for (int g = 0; g < G; ++g) off[g + 1] = off[g] + host_games[g].n_samples;
+    if (off[G] > cap_rows) throw EngineError(CA_ERR_ARG, "pack_samples: destination too small");
+    if (off[G] == 0) return 0;
+    DevBuf<int32_t> d_off;
+    d_off.alloc(G + 1);
+    rt_h2d(d_off.p, off.data(), off.size() * 4, stream);
+    RT_LAUNCH(co_k_pack_samples, G, CO_WAVE, stream, P, (const int32_t *)d_off.p, d_state_policy, d_outcome);
+    rt_sync(stream);
+    return off[G];
+  }
+
   /* Trainer::writeScores (trainer.cpp:115-162) */
   void write_scores(const char *file) {
     fetch_games();
@@ -395,44 +434,48 @@ struct ca_trainer {
   bool run(int64_t max_iterations) {
     if (!nets[0]) throw EngineError(CA_ERR_STATE, "ca_trainer_run: no network set (ca_trainer_set_net)");
     if (cfg.testing && !nets[1]) throw EngineError(CA_ERR_STATE, "arena mode needs both networks");
-    rt_event_t e0, e1, e2, e3;
-    rt_event_create(&e0);
-    rt_event_create(&e1);
-    rt_event_create(&e2);
-    rt_event_create(&e3);
+    const int poll = cfg.testing ? 1 : 8; /* iterations between host polls of the done flag */
+    std::vector<rt_event_t> ev((size_t)poll * 4);
+    for (auto &e : ev) rt_event_create(&e);
     int to_play = cfg.testing ? 0 : -1;
     if (iterations == 0) rt_memset(req_offset.p, 0, ((size_t)G + 1) * 4, stream);
+    P.row_counter = row_counter.p;
     int64_t it = 0;
-    const int poll = 4;
     int idle_flips = 0;
+    int in_window = 0;
     while (!finished && (max_iterations <= 0 || it < max_iterations)) {
-      /* main.pyx:142-168: doIteration -> requests -> predict */
+      /* main.pyx:142-168: doIteration -> requests -> predict, all on the device */
       P.to_play = to_play;
       P.iteration = trainer_iteration;
-      rt_event_record(e0, stream);
+      rt_event_t *e = &ev[(size_t)in_window * 4];
+      rt_event_record(e[0], stream);
       RT_LAUNCH(co_k_mcts_step, G, CO_WAVE, stream, P);
-      rt_event_record(e1, stream);
+      rt_event_record(e[1], stream);
       RT_LAUNCH(co_k_scan, 1, CO_WAVE, stream, P);
       RT_LAUNCH(co_k_compact, G, CO_WAVE, stream, P);
-      rt_event_record(e2, stream);
+      rt_event_record(e[2], stream);
       int slot = (cfg.testing && to_play == 0) ? 1 : 0; /* get_predictions, main.pyx:74-81 */
-      net_forward_rows(slot, nn_in.p, G * spe, req_offset.p + G, nn_eval.p, nn_probs.p);
-      rt_event_record(e3, stream);
+      nets[slot]->forward(nn_in.p, G * spe, req_offset.p + G, nn_eval.p, nn_probs.p, stream);
+      rt_event_record(e[3], stream);
       if (to_play == -1) ++trainer_iteration;
       ++iterations;
       ++it;
       ++mcts_launches;
       ++nn_launches;
-      bool poll_now = cfg.testing || (it % poll) == 0;
-      if (poll_now) {
+      ++in_window;
+      if (in_window == poll || (max_iterations > 0 && it == max_iterations)) {
         int32_t tot_done[2];
         rt_d2h(&tot_done[0], req_offset.p + G, 4, stream);
         rt_d2h(&tot_done[1], all_done.p, 4, stream);
         rt_sync(stream);
         finished = tot_done[1] != 0;
-        mcts_ms += rt_event_elapsed_ms(e0, e1);
-        pack_ms += rt_event_elapsed_ms(e1, e2);
-        nn_ms += rt_event_elapsed_ms(e2, e3);
+        for (int k = 0; k < in_window; ++k) {
+          rt_event_t *q = &ev[(size_t)k * 4];
+          mcts_ms += rt_event_elapsed_ms(q[0], q[1]);
+          pack_ms += rt_event_elapsed_ms(q[1], q[2]);
+          nn_ms += rt_event_elapsed_ms(q[2], q[3]);
+        }
+        in_window = 0;
         if (cfg.testing && !finished) {
           /* main.pyx:150-154: flip the model when it has no request */
           if (tot_done[0] == 0) {
@@ -447,18 +490,15 @@ struct ca_trainer {
       }
     }
     rt_sync(stream);
-    rt_event_destroy(e0);
-    rt_event_destroy(e1);
-    rt_event_destroy(e2);
-    rt_event_destroy(e3);
-    scan_valid_for = -99;
+    for (auto &e : ev) rt_event_destroy(e);
+    P.row_counter = nullptr;
+    unsigned long long rows = 0;
+    rt_d2h(&rows, row_counter.p, 8, stream);
+    rt_sync(stream);
+    nn_rows = (int64_t)rows;
     host_games_valid = false;
-    /* refresh the done flag */
-    {
-      P.to_play = to_play;
-      scan_valid_for = -99;
-      pack(to_play);
-    }
+    scan_valid_for = -99;
+    pack(to_play); /* refresh the done flag and the batch description */
     check_errors();
     return finished;
   }
@@ -523,6 +563,10 @@ extern "C" int ca_trainer_run(ca_trainer *t, int64_t max_iterations, int32_t *al
   CA_GUARD(*all_done = t->run(max_iterations) ? 1 : 0)
 }
 extern "C" int ca_trainer_export_samples(ca_trainer *t, float *sp, float *oc) { CA_GUARD(t->export_samples(sp, oc)) }
+extern "C" int ca_trainer_pack_samples_device(ca_trainer *t, void *d_sp, void *d_oc, int32_t cap_rows, int32_t *n_rows) {
+  CA_GUARD(*n_rows = t->pack_samples_device((float *)d_sp, (float *)d_oc, cap_rows))
+}
+extern "C" int ca_trainer_reset(ca_trainer *t, int32_t seed) { CA_GUARD(t->reset_games(seed)) }
 
 extern "C" int ca_trainer_net_forward(ca_trainer *t, int slot, const float *states, int32_t n, float *evals, float *probs) {
   CA_GUARD({

@@ -116,4 +116,5 @@ struct EngineParams {
   float *samples;       /* [G][CO_MAX_PLIES][166] */
   int32_t *trace;       /* [G][CO_TRACE_CAP] or null */
   int32_t *all_done;    /* [1] */
+  unsigned long long *row_counter; /* [1] rows handed to the network so far */
 };

@@ -71,6 +71,7 @@ CO_KERNEL co_k_scan(EngineParams P) {
     if (lane == 0) {
       P.req_offset[G] = run;
       P.all_done[0] = not_done == 0;
+      if (P.row_counter) P.row_counter[0] += (unsigned long long)run;
     }
   }
 }
@@ -114,6 +115,26 @@ CO_KERNEL co_k_write_samples(EngineParams P, const int32_t *sample_offset, float
         if (lane < CO_NUM_MOVES - 64) ps[64 + lane] = pol[CO_MOVE_SYM[k][64 + lane]];
         if (lane == 0) eval_samples[(off + i) * CO_NUM_SYMMETRIES + k] = evaluation;
       }
+    }
+  }
+}
+
+/* un-augmented (state[70], policy[96]) rows + outcome, game-major, for the
+ * multi-GPU gather (the x8 expansion happens after it) */
+CO_KERNEL co_k_pack_samples(EngineParams P, const int32_t *sample_offset, float *state_policy, float *outcome) {
+  int g = CO_BLOCK_IDX;
+  if (g >= P.num_games) return;
+  GameCtl gc = P.games[g];
+  int n = gc.n_samples;
+  size_t off = (size_t)sample_offset[g];
+  const float *smp = P.samples + (size_t)g * CO_MAX_PLIES * CO_SAMPLE_FLOATS;
+  int total = n * CO_SAMPLE_FLOATS;
+  FOR_LANES {
+    for (int i = lane; i < total; i += CO_WAVE) state_policy[off * CO_SAMPLE_FLOATS + i] = smp[i];
+    for (int i = lane; i < n; i += CO_WAVE) {
+      float e = gc.result == CO_RESULT_DRAW ? 0.0f : 1.0f;
+      if ((n - 1 - i) & 1) e = (float)((double)e * -1.0);
+      outcome[off + i] = e;
     }
   }
 }

@@ -130,6 +130,17 @@ class Trainer:
             _lib.check(self._L, self._L.ca_trainer_export_samples(self._t, _f32(sp, "sp"), _f32(oc, "oc")))
         return sp, oc
 
+    def reset(self, seed):
+        """new generation in the same device pool (no reallocation)"""
+        _lib.check(self._L, self._L.ca_trainer_reset(self._t, int(seed)))
+
+    def pack_samples_device(self, d_state_policy_ptr, d_outcome_ptr, cap_rows):
+        """pack un-augmented samples into caller-owned device memory; returns rows"""
+        n = C.c_int32()
+        _lib.check(self._L, self._L.ca_trainer_pack_samples_device(self._t, C.c_void_p(d_state_policy_ptr),
+                                                                   C.c_void_p(d_outcome_ptr), cap_rows, C.byref(n)))
+        return n.value
+
     # ---- introspection ----
     def stats(self):
         s = _lib.CaStats()

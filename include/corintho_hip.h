@@ -113,6 +113,13 @@ int ca_trainer_net_forward(ca_trainer *t, int slot, const float *states, int32_t
  * (state[70], policy[96]) + outcome[n] in game order; the x8 symmetry expansion
  * is applied after the gather by ca_expand_samples. */
 int ca_trainer_export_samples(ca_trainer *t, float *state_policy /* [n][166] */, float *outcome /* [n] */);
+/* The same rows packed on the device into caller-owned DEVICE buffers
+ * ([cap_rows][166] and [cap_rows] float32), ready for an RCCL all-gather. */
+int ca_trainer_pack_samples_device(ca_trainer *t, void *d_state_policy, void *d_outcome, int32_t cap_rows,
+                                   int32_t *n_rows);
+/* Start a new generation in the same pool: Trainer::initialize (trainer.cpp:238-256)
+ * with a new seed, without reallocating the device buffers. */
+int ca_trainer_reset(ca_trainer *t, int32_t seed);
 int ca_expand_samples(int device, const float *state_policy, const float *outcome, int32_t n, float *game_states,
                       float *eval_samples, float *prob_samples);
 
