@@ -141,18 +141,11 @@ def main():
                  stagger=args.stagger, arena_units=args.arena_units, game_base=rank * G, total_games=world * G)
     tr.set_net(kind, weights)
 
-    gather_buf = None
+    gatherer = None
     if world > 1:
-        cap = G * 44
-        gather_buf = {
-            "sp": torch.empty((cap, 166), dtype=torch.float32, device="cuda"),
-            "oc": torch.empty((cap,), dtype=torch.float32, device="cuda"),
-            "all_sp": torch.empty((world * cap, 166), dtype=torch.float32, device="cuda"),
-            "all_oc": torch.empty((world * cap,), dtype=torch.float32, device="cuda"),
-            "cnt": torch.zeros((1,), dtype=torch.int32, device="cuda"),
-            "all_cnt": torch.zeros((world,), dtype=torch.int32, device="cuda"),
-            "cap": cap,
-        }
+        from corintho_ai_amd.dist import SampleGather
+
+        gatherer = SampleGather(tr, G, on_device=True)
 
     totals = {"searches": 0, "evals": 0, "plies": 0, "iterations": 0, "mcts_ms": 0.0, "nn_ms": 0.0, "pack_ms": 0.0,
               "nn_rows": 0, "gather_ms": 0.0, "samples": 0, "peak_arena_units": 0}
@@ -164,12 +157,7 @@ def main():
             raise RuntimeError("generation did not finish")
         if world > 1:
             t0 = time.perf_counter()
-            n = tr.pack_samples_device(gather_buf["sp"].data_ptr(), gather_buf["oc"].data_ptr(), gather_buf["cap"])
-            gather_buf["cnt"][0] = n
-            dist.all_gather_into_tensor(gather_buf["all_cnt"], gather_buf["cnt"])
-            dist.all_gather_into_tensor(gather_buf["all_sp"], gather_buf["sp"])
-            dist.all_gather_into_tensor(gather_buf["all_oc"], gather_buf["oc"])
-            torch.cuda.synchronize()
+            gatherer.gather()  # one RCCL all-gather of the un-augmented samples per generation
             if timed:
                 totals["gather_ms"] += (time.perf_counter() - t0) * 1e3
         if timed:

@@ -1,0 +1,62 @@
+"""World-size-2 test of the sharded path on CPU: two processes (gloo, 127.0.0.1), each
+running its shard of one generation on the emulation build of the engine, then the
+per-generation sample all-gather; the gathered, x8-expanded samples must equal what ONE
+trainer over all games writes (Trainer::writeSamples order, trainer.cpp:103-113)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+import torch, torch.distributed as dist
+from corintho_ai_amd import Trainer, expand_samples, nets
+from corintho_ai_amd.dist import SampleGather, shard
+from tests.emu import emulib
+from tests import harness as H
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+L = emulib.load()
+G, S, spe = 6, 24, 8
+base, total = shard(rank, world, G)
+t = Trainer(G, "", 4242, S, spe, 1.0, 0.25, 0, 1, False, stagger=False, game_base=base, total_games=total, _cdll=L)
+t.set_net(1, nets.init_mlp12x100(0, bn_noise=True))
+assert t.run()
+g = SampleGather(t, G, on_device=False)
+sp, oc = g.rows()
+score = torch.tensor([t.score() * G], dtype=torch.float64)
+dist.all_reduce(score)
+if rank == 0:
+    gs, ev, pr = expand_samples(sp, oc, _cdll=L)
+    np.savez(%(out)r, gs=gs, ev=ev, pr=pr, score=score.item() / (G * world))
+dist.destroy_process_group()
+"""
+
+
+def test_two_rank_sharded_generation_matches_single_trainer(tmp_path):
+    out = str(tmp_path / "gathered.npz")
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT, "out": out})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2", OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r))) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    got = np.load(out)
+    # the same generation on one trainer
+    from corintho_ai_amd import Trainer, nets
+    from tests import harness as H
+    from tests.emu import emulib
+
+    t = Trainer(12, "", 4242, 24, 8, 1.0, 0.25, 0, 1, False, stagger=False, _cdll=emulib.load())
+    t.set_net(1, nets.init_mlp12x100(0, bn_noise=True))
+    assert t.run()
+    gs, ev, pr = H.get_samples(t)
+    assert got["gs"].tobytes() == gs.tobytes()
+    assert got["ev"].tobytes() == ev.tobytes()
+    assert got["pr"].tobytes() == pr.tobytes()
+    assert abs(float(got["score"]) - t.score()) < 1e-6
