@@ -91,7 +91,7 @@ struct ca_trainer {
   DevBuf<uint32_t> pend_leaf, pend_path, rng;
   DevBuf<int32_t> pend_depth, req_offset, trace, all_done;
   DevBuf<float> req, nn_in, nn_eval, nn_probs, samples;
-  DevBuf<unsigned long long> row_counter;
+  DevBuf<unsigned long long> row_counter, pack_counter;
   /* host state */
   int64_t iterations = 0;
   int32_t trainer_iteration = 0; /* Trainer::searches_done_ (train mode only) */
@@ -141,6 +141,7 @@ struct ca_trainer {
     if (cfg.trace) trace.alloc((size_t)G * CO_TRACE_CAP);
     all_done.alloc(1);
     row_counter.alloc(1);
+    pack_counter.alloc(2);
 
     reset_games(cfg.seed);
     memset(&P, 0, sizeof P);
@@ -178,6 +179,7 @@ struct ca_trainer {
     rt_h2d(games.p, hg.data(), hg.size() * sizeof(GameCtl), stream);
     rt_h2d(trees.p, ht.data(), ht.size() * sizeof(TreeCtl), stream);
     rt_memset(row_counter.p, 0, 8, stream);
+    rt_memset(pack_counter.p, 0, 16, stream);
     rt_sync(stream);
     iterations = 0;
     trainer_iteration = 0;
@@ -220,6 +222,8 @@ struct ca_trainer {
     P.trace = trace.p;
     P.all_done = all_done.p;
     P.row_counter = nullptr; /* counted in fused mode only */
+    P.fused_pack = 0;
+    P.pack_counter = pack_counter.p;
   }
 
   /* offsets + compact batch for model `to_play` (K4) */
@@ -434,12 +438,14 @@ struct ca_trainer {
   bool run(int64_t max_iterations) {
     if (!nets[0]) throw EngineError(CA_ERR_STATE, "ca_trainer_run: no network set (ca_trainer_set_net)");
     if (cfg.testing && !nets[1]) throw EngineError(CA_ERR_STATE, "arena mode needs both networks");
+    const bool self_pack = !cfg.testing; /* training: K3 packs its own requests, no K4 */
     const int poll = cfg.testing ? 1 : 8; /* iterations between host polls of the done flag */
     std::vector<rt_event_t> ev((size_t)poll * 4);
     for (auto &e : ev) rt_event_create(&e);
     int to_play = cfg.testing ? 0 : -1;
     if (iterations == 0) rt_memset(req_offset.p, 0, ((size_t)G + 1) * 4, stream);
-    P.row_counter = row_counter.p;
+    P.row_counter = self_pack ? nullptr : row_counter.p;
+    P.fused_pack = self_pack ? 1 : 0;
     int64_t it = 0;
     int idle_flips = 0;
     int in_window = 0;
@@ -448,15 +454,23 @@ struct ca_trainer {
       P.to_play = to_play;
       P.iteration = trainer_iteration;
       rt_event_t *e = &ev[(size_t)in_window * 4];
+      if (!self_pack && iterations > 0) RT_LAUNCH(co_k_scan, 1, CO_WAVE, stream, P); /* offsets at entry (trainer.cpp:208-215) */
       rt_event_record(e[0], stream);
       RT_LAUNCH(co_k_mcts_step, G, CO_WAVE, stream, P);
       rt_event_record(e[1], stream);
-      RT_LAUNCH(co_k_scan, 1, CO_WAVE, stream, P);
-      RT_LAUNCH(co_k_compact, G, CO_WAVE, stream, P);
+      const int32_t *d_rows;
+      if (self_pack) {
+        d_rows = (const int32_t *)(pack_counter.p + (trainer_iteration & 1)); /* low word = rows */
+      } else {
+        RT_LAUNCH(co_k_scan, 1, CO_WAVE, stream, P);
+        RT_LAUNCH(co_k_compact, G, CO_WAVE, stream, P);
+        d_rows = req_offset.p + G;
+      }
       rt_event_record(e[2], stream);
       int slot = (cfg.testing && to_play == 0) ? 1 : 0; /* get_predictions, main.pyx:74-81 */
-      nets[slot]->forward(nn_in.p, G * spe, req_offset.p + G, nn_eval.p, nn_probs.p, stream);
+      nets[slot]->forward(nn_in.p, G * spe, d_rows, nn_eval.p, nn_probs.p, stream);
       rt_event_record(e[3], stream);
+      const int counter_slot = trainer_iteration & 1;
       if (to_play == -1) ++trainer_iteration;
       ++iterations;
       ++it;
@@ -465,9 +479,17 @@ struct ca_trainer {
       ++in_window;
       if (in_window == poll || (max_iterations > 0 && it == max_iterations)) {
         int32_t tot_done[2];
-        rt_d2h(&tot_done[0], req_offset.p + G, 4, stream);
-        rt_d2h(&tot_done[1], all_done.p, 4, stream);
-        rt_sync(stream);
+        if (self_pack) {
+          unsigned long long c = 0;
+          rt_d2h(&c, pack_counter.p + counter_slot, 8, stream);
+          rt_sync(stream);
+          tot_done[0] = (int32_t)(c & 0xFFFFFFFFull);
+          tot_done[1] = (c >> 32) == 0; /* no game still running */
+        } else {
+          rt_d2h(&tot_done[0], req_offset.p + G, 4, stream);
+          rt_d2h(&tot_done[1], all_done.p, 4, stream);
+          rt_sync(stream);
+        }
         finished = tot_done[1] != 0;
         for (int k = 0; k < in_window; ++k) {
           rt_event_t *q = &ev[(size_t)k * 4];
@@ -492,14 +514,20 @@ struct ca_trainer {
     rt_sync(stream);
     for (auto &e : ev) rt_event_destroy(e);
     P.row_counter = nullptr;
-    unsigned long long rows = 0;
-    rt_d2h(&rows, row_counter.p, 8, stream);
-    rt_sync(stream);
-    nn_rows = (int64_t)rows;
+    P.fused_pack = 0;
     host_games_valid = false;
     scan_valid_for = -99;
     pack(to_play); /* refresh the done flag and the batch description */
     check_errors();
+    if (self_pack) {
+      nn_rows = 0;
+      for (int g = 0; g < G; ++g) nn_rows += host_games[g].evals; /* every consumed row was evaluated once */
+    } else {
+      unsigned long long rows = 0;
+      rt_d2h(&rows, row_counter.p, 8, stream);
+      rt_sync(stream);
+      nn_rows = (int64_t)rows;
+    }
     return finished;
   }
 };

@@ -76,7 +76,8 @@ struct GameCtl {
   uint32_t evals;     /* ... leaf evaluations consumed ... */
   uint32_t nodes;     /* ... nodes created */
   int32_t trace_len;
-  int32_t pad[2];
+  int32_t row_off;    /* fused mode: first row of this game's requests in the compact batch */
+  int32_t pad[1];
 };
 
 struct TreeCtl {
@@ -117,4 +118,9 @@ struct EngineParams {
   int32_t *trace;       /* [G][CO_TRACE_CAP] or null */
   int32_t *all_done;    /* [1] */
   unsigned long long *row_counter; /* [1] rows handed to the network so far */
+  /* fused training mode: K3 packs its own requests.  pack_counter[iteration & 1] =
+   * (games still running << 32) | rows of this iteration's batch; the other one is
+   * cleared for the next iteration.  The network kernels read the low word. */
+  int32_t fused_pack;
+  unsigned long long *pack_counter; /* [2] */
 };

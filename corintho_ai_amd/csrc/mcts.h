@@ -807,12 +807,20 @@ CO_DEV int co_sp_do_iteration(CoWave &w, const float *eval, const float *probs) 
 /* Trainer::doIteration for game g (trainer.cpp:164-236): the body of the
  * `omp parallel for`, one wavefront per game. */
 CO_DEV void co_mcts_step_wave(const EngineParams &P, int g) {
+  if (P.fused_pack && g == 0) {
+    FOR_LANES {
+      if (lane == 0) P.pack_counter[(P.iteration + 1) & 1] = 0ull;
+    }
+  }
   GameCtl gc = P.games[g];
   if (gc.done || gc.error) return;
   if (P.to_play == 0 || P.to_play == 1) {
     if (gc.to_play != (P.to_play + gc.parity) % 2) return;
   } else if (P.stagger_div > 0) {
-    if ((P.game_base + g) / P.stagger_div > P.iteration) return;
+    if ((P.game_base + g) / P.stagger_div > P.iteration) {
+      if (P.fused_pack) co_atomic_add_u64(P.pack_counter + (P.iteration & 1), 1ull << 32); /* still running */
+      return;
+    }
   }
   CoWave w;
   w.g = g;
@@ -835,9 +843,23 @@ CO_DEV void co_mcts_step_wave(const EngineParams &P, int g) {
   w.trace_on = P.trace_on && P.trace;
   w.c_puct = P.c_puct;
   w.epsilon = P.epsilon;
-  int off = P.req_offset[g];
+  int off = P.fused_pack ? gc.row_off : P.req_offset[g];
   int done = co_sp_do_iteration(w, P.nn_eval + off, P.nn_probs + (size_t)off * CO_NUM_MOVES);
   if (done) w.gc.done = 1;
+  if (P.fused_pack && !w.gc.done && !w.gc.error) {
+    /* Trainer::writeRequests fused into the step: reserve rows of the compact batch
+     * (any order: a row's evaluation does not depend on its position) and copy */
+    int n = w.gc.n_pending;
+    unsigned long long old = co_atomic_add_u64(P.pack_counter + (P.iteration & 1), (1ull << 32) | (unsigned long long)n);
+    int base = (int)(unsigned)(old & 0xFFFFFFFFull);
+    w.gc.row_off = base;
+    const float *src = w.req;
+    float *dst = P.nn_in + (size_t)base * CO_STATE_STRIDE;
+    int total = n * CO_STATE_STRIDE;
+    FOR_LANES {
+      for (int i = lane; i < total; i += CO_WAVE) dst[i] = src[i];
+    }
+  }
   FOR_LANES {
     if (lane == 0) {
       P.games[g] = w.gc;

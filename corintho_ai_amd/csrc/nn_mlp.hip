@@ -19,8 +19,10 @@
 // Work: 2*(70*100 + 11*100*100 + 100*97) = 253.4 KFLOP per row (algorithmic);
 // the padded tiles (112x112) issue 28% more MFMA work than that.
 // Geometry: 256 threads = 4 waves per workgroup, 32 rows per wave (two 16-row
-// tiles share every weight fragment), 128 rows per workgroup, 2 workgroups per
-// CU so that one stages weights while the other computes.
+// tiles share every weight fragment), 128 rows per workgroup.  The weights of
+// layer l+1 stream into the second LDS buffer with global_load_lds (LDS-DMA, no
+// registers) while layer l computes: 2 x 50 176 B of LDS, one workgroup per CU,
+// one barrier per layer.
 #include <hip/hip_runtime.h>
 #include <math.h>
 
@@ -40,18 +42,29 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256, 2) void co_k_mlp_forward(const float *__restrict__ in, const int32_t *__restrict__ d_rows,
+/* one wave copies 1 KiB per instruction: lane i supplies bytes [16 i, 16 i + 16) */
+__device__ __forceinline__ void mlp_stage_weights(const float *__restrict__ src, float *lds_dst, int nsteps, int wave,
+                                                  int lane) {
+  const int chunks = nsteps * MLP_FRAG / 256; /* 1 KiB chunks: 49 for 28 steps, 35 for 20 */
+  for (int ch = wave; ch < chunks; ch += 4) {
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + ch * 256 + lane * 4),
+                                     (void __attribute__((address_space(3))) *)(lds_dst + ch * 256), 16, 0, 0);
+  }
+}
+
+__global__ __launch_bounds__(256, 1) void co_k_mlp_forward(const float *__restrict__ in, const int32_t *__restrict__ d_rows,
                                                            const float *__restrict__ wfrag,
                                                            const float *__restrict__ bias,
                                                            const float *__restrict__ bn_a,
                                                            const float *__restrict__ bn_b, float *__restrict__ eval,
                                                            float *__restrict__ probs) {
-  __shared__ float lds_w[MLP_LAYER_FLOATS];
+  extern __shared__ __attribute__((aligned(16))) float lds_all[]; /* 2 x MLP_LAYER_FLOATS */
   const int rows = *d_rows;
   const int row0 = blockIdx.x * MLP_ROWS_PER_WG;
   if (row0 >= rows) return;
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, q = lane >> 4, c = lane & 15;
+  mlp_stage_weights(wfrag, lds_all, MLP_STEPS_L0, wave, lane);
 
   float x[2][MLP_TILES][4];
 #pragma unroll
@@ -71,14 +84,14 @@ __global__ __launch_bounds__(256, 2) void co_k_mlp_forward(const float *__restri
 
   for (int l = 0; l < MLP_NLAYERS; ++l) {
     const int nsteps = l == 0 ? MLP_STEPS_L0 : MLP_STEPS;
+    const float *lds_w = lds_all + (l & 1) * MLP_LAYER_FLOATS;
+    /* this wave's DMA pieces of layer l have landed; the barrier makes every wave's
+     * pieces visible and proves nobody still reads the other buffer (layer l-1) */
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    {
-      const float4 *src = reinterpret_cast<const float4 *>(wfrag + (size_t)l * MLP_LAYER_FLOATS);
-      float4 *dst = reinterpret_cast<float4 *>(lds_w);
-      const int n4 = nsteps * MLP_FRAG / 4;
-      for (int i = tid; i < n4; i += 256) dst[i] = src[i];
-    }
-    __syncthreads();
+    if (l + 1 < MLP_NLAYERS)
+      mlp_stage_weights(wfrag + (size_t)(l + 1) * MLP_LAYER_FLOATS, lds_all + ((l + 1) & 1) * MLP_LAYER_FLOATS, MLP_STEPS,
+                        wave, lane);
     f32x4 acc[2][MLP_TILES];
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
@@ -212,6 +225,8 @@ struct MlpNet : CoNet {
     rt_h2d(d_a, ba.data(), ba.size() * 4, s);
     rt_h2d(d_b, bb.data(), bb.size() * 4, s);
     rt_sync(s);
+    RT_CHECK(hipFuncSetAttribute((const void *)co_k_mlp_forward, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 2 * MLP_LAYER_FLOATS * (int)sizeof(float)));
   }
   ~MlpNet() override {
     rt_free(d_wfrag);
@@ -226,7 +241,7 @@ struct MlpNet : CoNet {
                rt_stream_t s) override {
     int grid = (rows_cap + MLP_ROWS_PER_WG - 1) / MLP_ROWS_PER_WG;
     if (grid < 1) return;
-    hipLaunchKernelGGL(co_k_mlp_forward, dim3(grid), dim3(256), 0, s, d_in, d_rows, (const float *)d_wfrag,
+    hipLaunchKernelGGL(co_k_mlp_forward, dim3(grid), dim3(256), 2 * MLP_LAYER_FLOATS * sizeof(float), s, d_in, d_rows, (const float *)d_wfrag,
                        (const float *)d_bias, (const float *)d_a, (const float *)d_b, d_eval, d_probs);
     RT_CHECK(hipGetLastError());
   }

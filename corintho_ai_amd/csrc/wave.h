@@ -75,6 +75,9 @@ static inline int co_popc64(uint64_t v) { return __builtin_popcountll(v); }
 static inline int co_popc32(uint32_t v) { return __builtin_popcount(v); }
 static inline int co_ffs64(uint64_t v) { return __builtin_ffsll((long long)v); } /* 1-based, 0 if none */
 static inline double co_sqrt_f64(double x) { return sqrt(x); }
+static inline unsigned long long co_atomic_add_u64(unsigned long long *p, unsigned long long v) {
+  return __atomic_fetch_add(p, v, __ATOMIC_RELAXED);
+}
 extern thread_local int co_emu_block_idx;
 #define CO_BLOCK_IDX co_emu_block_idx
 
@@ -138,6 +141,14 @@ __device__ __forceinline__ int co_popc64(uint64_t v) { return __popcll(v); }
 __device__ __forceinline__ int co_popc32(uint32_t v) { return __popc(v); }
 __device__ __forceinline__ int co_ffs64(uint64_t v) { return __ffsll((unsigned long long)v); }
 __device__ __forceinline__ double co_sqrt_f64(double x) { return __builtin_sqrt(x); }
+/* one device-scope atomic per wave (lane 0), old value broadcast to the wave */
+__device__ __forceinline__ unsigned long long co_atomic_add_u64(unsigned long long *p, unsigned long long v) {
+  unsigned long long old = 0;
+  if ((threadIdx.x & 63) == 0) old = atomicAdd(p, v);
+  unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)old);
+  unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(old >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
 #define CO_BLOCK_IDX ((int)blockIdx.x)
 #endif
 
