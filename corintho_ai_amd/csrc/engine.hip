@@ -91,7 +91,7 @@ struct ca_trainer {
   DevBuf<uint32_t> pend_leaf, pend_path, rng;
   DevBuf<int32_t> pend_depth, req_offset, trace, all_done;
   DevBuf<float> req, nn_in, nn_eval, nn_probs, samples;
-  DevBuf<unsigned long long> row_counter, pack_counter;
+  DevBuf<unsigned long long> row_counter, pack_counter, prof;
   /* host state */
   int64_t iterations = 0;
   int32_t trainer_iteration = 0; /* Trainer::searches_done_ (train mode only) */
@@ -224,6 +224,12 @@ struct ca_trainer {
     P.row_counter = nullptr; /* counted in fused mode only */
     P.fused_pack = 0;
     P.pack_counter = pack_counter.p;
+#ifdef CO_PROF
+    prof.alloc((size_t)G * 8);
+    P.prof = prof.p;
+#else
+    P.prof = nullptr;
+#endif
   }
 
   /* offsets + compact batch for model `to_play` (K4) */
@@ -595,6 +601,18 @@ extern "C" int ca_trainer_pack_samples_device(ca_trainer *t, void *d_sp, void *d
   CA_GUARD(*n_rows = t->pack_samples_device((float *)d_sp, (float *)d_oc, cap_rows))
 }
 extern "C" int ca_trainer_reset(ca_trainer *t, int32_t seed) { CA_GUARD(t->reset_games(seed)) }
+/* diagnostic builds (-DCO_PROF): summed in-kernel cycle stamps, see mcts.h; not in the public header */
+extern "C" int ca_trainer_prof(ca_trainer *t, unsigned long long out[8]) {
+  CA_GUARD({
+    for (int i = 0; i < 8; ++i) out[i] = 0;
+    if (!t->prof.p) throw EngineError(CA_ERR_STATE, "not a -DCO_PROF build");
+    std::vector<unsigned long long> h((size_t)t->G * 8);
+    rt_d2h(h.data(), t->prof.p, h.size() * 8, t->stream);
+    rt_sync(t->stream);
+    for (int g = 0; g < t->G; ++g)
+      for (int i = 0; i < 8; ++i) out[i] += h[(size_t)g * 8 + i];
+  })
+}
 
 extern "C" int ca_trainer_net_forward(ca_trainer *t, int slot, const float *states, int32_t n, float *evals, float *probs) {
   CA_GUARD({

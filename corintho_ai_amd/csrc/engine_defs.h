@@ -123,4 +123,5 @@ struct EngineParams {
    * cleared for the next iteration.  The network kernels read the low word. */
   int32_t fused_pack;
   unsigned long long *pack_counter; /* [2] */
+  unsigned long long *prof;         /* [G][8] cycle stamps, profiling builds (-DCO_PROF) only */
 };

@@ -21,6 +21,19 @@ CO_CONST uint32_t CO_GAMMA_BITS[CO_NUM_GAMMA] = CO_GAMMA_BITS_INIT;
 
 #define CO_NEG_INF (-__builtin_huge_valf())
 
+/* in-kernel phase stamps (diagnostic build only: hipcc -DCO_PROF); slots:
+ * 0 receive, 1 search, 2 choose/hand-over, 3 expand (inside 1), 4 steps, 5 searches, 6 receives */
+#if defined(CO_PROF) && !defined(CO_EMU)
+#define CO_CLK() __builtin_amdgcn_s_memtime()
+#define CO_PROF_ADD(w, slot, v)                                   \
+  do {                                                            \
+    if ((w).prof && (threadIdx.x & 63) == 0) (w).prof[slot] += (v); \
+  } while (0)
+#else
+#define CO_CLK() 0ull
+#define CO_PROF_ADD(w, slot, v) ((void)0)
+#endif
+
 struct CoTree {
   uint4 *A;      /* arena of this tree */
   TreeCtl tc;    /* register copy, written back at the end of the step */
@@ -30,7 +43,9 @@ struct CoTree {
 struct CoWave {
   int g;
   GameCtl gc;
-  CoTree tr[2];
+  /* the tree of the player to move and the opponent's; swapped on hand-over so that
+   * no register-resident state is indexed dynamically (that would spill to scratch) */
+  CoTree me, opp;
   uint32_t *mt;
   /* per-game views */
   uint32_t *pend_leaf;
@@ -39,6 +54,7 @@ struct CoWave {
   float *req;
   float *samples;
   int32_t *trace;
+  unsigned long long *prof;
   /* config */
   int max_searches, spe, testing, trace_on;
   float c_puct, epsilon;
@@ -257,10 +273,171 @@ CO_DEV void co_receive_one(CoWave &w, CoTree &t, int k, float leaf_eval, const f
   w.gc.evals++;
 }
 
+/* receiveEval for a batch of up to CO_RB pending leaves at once (trainmc.cpp:269-296).
+ * Same arithmetic as co_receive_one, reorganised so that the wave's lanes are busy:
+ *   A  lane k: leaf k's header                      (all leaves' loads in flight together)
+ *   B  per leaf, lanes = edges: move ids and priors -> LDS tables
+ *   C  lanes = consecutive mt19937 draws: noise in stream order (leaf 0's edges first)
+ *   D  lane k: the two SEQUENTIAL float sums of leaf k, weights, max, 9-bit quantisation
+ *   F  per leaf, lanes = edges: write the priors back
+ *   G  per leaf in request order, lanes = path levels: the backup
+ * Falls back to co_receive_one when a leaf has more than CO_RE legal moves. */
+#define CO_RB 16
+#define CO_RE 48
+#define CO_RS (CO_RE + 1) /* LDS row stride: odd, so lane k's column walk is conflict-free */
+CO_DEV void co_receive_batch(CoWave &w, CoTree &t, int k0, int nb, const float *eval, const float *probs) {
+  uint4 *A = t.A;
+  WAVE_SHARED(float, tp, CO_RB * CO_RS);      /* priors -> weights */
+  WAVE_SHARED(float, tn, CO_RB * CO_RS);      /* noise */
+  WAVE_SHARED(uint8_t, tm, CO_RB * CO_RS + 3); /* move id, then quantised prior low byte */
+  WAVE_SHARED(uint8_t, tq, CO_RB * CO_RS + 3); /* quantised prior high bit */
+  WAVE_SHARED(int, offs, CO_RB + 1);          /* prefix of legal-move counts = first draw of leaf k */
+  /* ---- A */
+  LV(uint32_t, leafv);
+  LV(int, nv);
+  LV(int, dv);
+  FOR_LANES {
+    L(leafv) = 0;
+    L(nv) = 0;
+    L(dv) = 0;
+    if (lane < nb) {
+      L(leafv) = w.pend_leaf[k0 + lane];
+      L(dv) = w.pend_depth[k0 + lane];
+      L(nv) = (int)CO_META_NEDGES(A[L(leafv)].z);
+    }
+  }
+  int total = 0, too_wide = 0;
+  FOR_LANES {
+    if (lane == 0) offs[0] = 0;
+  }
+  for (int k = 0; k < nb; ++k) {
+    int n = WAVE_BCAST(nv, k);
+    if (n > CO_RE) too_wide = 1;
+    total += n;
+    FOR_LANES {
+      if (lane == 0) offs[k + 1] = total;
+    }
+  }
+  if (too_wide) {
+    for (int k = 0; k < nb; ++k) co_receive_one(w, t, k0 + k, eval[k0 + k], probs + (size_t)(k0 + k) * CO_NUM_MOVES);
+    return;
+  }
+  WAVE_SYNC();
+  /* ---- B */
+  for (int k = 0; k < nb; ++k) {
+    uint32_t leaf = WAVE_BCAST(leafv, k);
+    int n = WAVE_BCAST(nv, k);
+    const float *pr = probs + (size_t)(k0 + k) * CO_NUM_MOVES;
+    FOR_LANES {
+      if (lane < n) {
+        uint32_t mv = A[leaf + 2 + lane].z & 127u;
+        tm[k * CO_RS + lane] = (uint8_t)mv;
+        tp[k * CO_RS + lane] = pr[mv];
+      }
+    }
+  }
+  /* ---- C: draw i belongs to the leaf k with offs[k] <= i < offs[k+1] */
+  for (int base = 0; base < total; base += CO_WAVE) {
+    int cnt = total - base < CO_WAVE ? total - base : CO_WAVE;
+    LV(uint32_t, r);
+    CO_MT_DRAW(w.mt, w.gc.rng_idx, cnt, r);
+    FOR_LANES {
+      if (lane < cnt) {
+        int i = base + lane;
+        int k = 0;
+        for (int j = 1; j < CO_RB; ++j) k += (j < nb && offs[j] <= i) ? 1 : 0;
+        tn[k * CO_RS + (i - offs[k])] = co_u2f(CO_GAMMA_BITS[L(r) % CO_NUM_GAMMA]);
+      }
+    }
+  }
+  WAVE_SYNC();
+  /* ---- D: lane k owns leaf k */
+  LV(float, denomv);
+  FOR_LANES {
+    L(denomv) = 0.0f;
+    if (lane < nb) {
+      const int n = L(nv);
+      float *fp = tp + lane * CO_RS;
+      float *dn = tn + lane * CO_RS;
+      float sum = 0.0f, dsum = 0.0f;
+      for (int e = 0; e < n; ++e) {
+        sum += fp[e];
+        dsum += dn[e];
+      }
+      float one_minus = (float)1 - w.epsilon;
+      float scalar = (float)(1.0 / (double)sum * (double)one_minus);
+      float dscalar = (float)(1.0 / (double)dsum * (double)w.epsilon);
+      float max_prob = 0.0f;
+      for (int e = 0; e < n; ++e) {
+        float a = fp[e] * scalar;
+        float d = dn[e] * dscalar;
+        float wt = a + d;
+        fp[e] = wt;
+        max_prob = wt > max_prob ? wt : max_prob;
+      }
+      float denom = 511.0f / max_prob;
+      int final_sum = 0;
+      for (int e = 0; e < n; ++e) {
+        float x = fp[e] * denom;
+        float fl = __builtin_truncf(x);
+        int q = (int)fl;
+        if (x - fl >= 0.5f) q += 1;
+        if (!(q >= 1)) q = 1;
+        final_sum += q;
+        tq[lane * CO_RS + e] = (uint8_t)((q >> 8) & 1);
+        dn[e] = co_u2f((uint32_t)(q & 255)); /* low byte parked in the noise table */
+      }
+      L(denomv) = (float)(1.0 / (double)(float)final_sum);
+    }
+  }
+  WAVE_SYNC();
+  /* ---- F */
+  for (int k = 0; k < nb; ++k) {
+    uint32_t leaf = WAVE_BCAST(leafv, k);
+    int n = WAVE_BCAST(nv, k);
+    float den = WAVE_BCAST(denomv, k);
+    FOR_LANES {
+      if (lane < n) {
+        uint32_t q = co_f2u(tn[k * CO_RS + lane]) | ((uint32_t)tq[k * CO_RS + lane] << 8);
+        uint32_t z = A[leaf + 2 + lane].z;
+        A[leaf + 2 + lane].z = (z & 0xFFFF007Fu) | ((q & 511u) << 7);
+      }
+      if (lane == 63) A[leaf + 1].y = co_f2u(den);
+    }
+  }
+  WAVE_SYNC();
+  /* ---- G: backups strictly in request order (shared ancestors accumulate in that order) */
+  for (int k = 0; k < nb; ++k) {
+    int D = WAVE_BCAST(dv, k);
+    float leaf_eval = eval[k0 + k];
+    const uint32_t *pp = w.pend_path + (size_t)(k0 + k) * CO_PATH_MAX;
+    FOR_LANES {
+      if (lane <= D) {
+        int kk = D - lane;
+        float ce = (kk & 1) ? (float)((double)leaf_eval * -1.0) : leaf_eval;
+        float add = (float)((double)ce - 1.0);
+        uint32_t at = pp[lane];
+        uint4 sl = A[at];
+        sl.y = co_f2u(co_u2f(sl.y) + add);
+        sl = co_slot_set_all_visited(sl, 0);
+        A[at] = sl;
+      }
+    }
+    WAVE_SYNC();
+  }
+  w.gc.evals += (uint32_t)nb;
+}
+
 /* trainmc.cpp:269-296 */
 CO_DEV void co_receive_eval(CoWave &w, CoTree &t, const float *eval, const float *probs) {
   int n = w.gc.n_pending;
-  for (int k = 0; k < n; ++k) co_receive_one(w, t, k, eval[k], probs + (size_t)k * CO_NUM_MOVES);
+  unsigned long long t0 = CO_CLK();
+  for (int k0 = 0; k0 < n; k0 += CO_RB) {
+    int nb = n - k0 < CO_RB ? n - k0 : CO_RB;
+    co_receive_batch(w, t, k0, nb, eval, probs);
+  }
+  CO_PROF_ADD(w, 0, CO_CLK() - t0);
+  CO_PROF_ADD(w, 6, (unsigned long long)n);
   w.gc.n_pending = 0;
 }
 
@@ -300,19 +477,36 @@ CO_DEV void co_propagate_terminal(CoTree &t, const uint32_t *path_block, const u
   }
 }
 
+/* Register copy of the root's header and stat slot, kept across the simulations
+ * of one step so that a simulation starts without any dependent load. */
+struct CoRoot {
+  uint4 h0, h1, cs;
+  int valid;
+};
+
+CO_DEV void co_root_load(CoTree &t, CoRoot &rc) {
+  rc.h0 = co_load_unit(t.A, t.tc.root);
+  rc.h1 = co_load_unit(t.A, t.tc.root + 1);
+  rc.cs = co_load_unit(t.A, rc.h1.x);
+  rc.valid = 1;
+}
+
 /* One simulation: TrainMC::search (trainmc.cpp:602-696) with chooseNext
- * (:540-600) inlined as the lane-parallel edge scan. */
-CO_DEV void co_search(CoWave &w, CoTree &t) {
+ * (:540-600) inlined as the lane-parallel edge scan.  A node's header and its
+ * first 64 edge slots are requested together (one memory round trip per level). */
+CO_DEV void co_search(CoWave &w, CoTree &t, CoRoot &rc) {
   uint4 *A = t.A;
   WAVE_SHARED(uint32_t, path_block, CO_PATH_MAX);
   WAVE_SHARED(uint32_t, path_slot, CO_PATH_MAX);
   uint32_t cur = t.tc.root;
   ++t.tc.searches_done;
   w.gc.searches++;
-  uint4 h0 = co_load_unit(A, cur);
-  uint4 h1 = co_load_unit(A, cur + 1);
+  uint4 h0 = rc.h0;
+  uint4 h1 = rc.h1;
   uint32_t cur_slot = h1.x;
-  uint4 cs = co_load_unit(A, cur_slot);
+  uint4 cs = rc.cs;
+  LV(uint4, ev);
+  FOR_LANES { L(ev) = A[cur + 2 + lane]; } /* arena is padded: lanes >= n read unused units */
   int D = 0;
   FOR_LANES {
     if (lane == 0) {
@@ -321,7 +515,6 @@ CO_DEV void co_search(CoWave &w, CoTree &t) {
     }
   }
   WAVE_SYNC();
-  int leaf_is_new = 0;
   while (!co_res_terminal(co_slot_result(cs))) {
     int n = (int)CO_META_NEDGES(h0.z);
     float denom = co_u2f(h1.y);
@@ -332,14 +525,13 @@ CO_DEV void co_search(CoWave &w, CoTree &t) {
     int best_e = -1;
     uint4 best_slot = make_uint4(0, 0, 0, 0);
     for (int base = 0; base < n; base += CO_WAVE) {
-      LV(uint4, ev);
       LV(float, u);
       FOR_LANES {
         int e = base + lane;
         float uu = CO_NEG_INF;
+        if (base > 0 && e < n) L(ev) = A[cur + 2 + e];
         if (e < n) {
-          uint4 s = A[cur + 2 + e];
-          L(ev) = s;
+          uint4 s = L(ev);
           float prob = (float)((s.z >> 7) & 511u) * denom;
           if (s.x != CO_NONE) {
             int r = co_slot_result(s);
@@ -388,9 +580,11 @@ CO_DEV void co_search(CoWave &w, CoTree &t) {
       WAVE_SYNC();
       --t.tc.searches_done;
       w.gc.searches--;
+      rc.valid = 0;
       return;
     }
     co_store_unit(A, cur_slot, cs);
+    if (D == 0) rc.cs = cs;
     if (D + 1 >= CO_PATH_MAX) {
       w.gc.error |= CO_ERR_PATH_TOO_DEEP;
       return;
@@ -404,10 +598,11 @@ CO_DEV void co_search(CoWave &w, CoTree &t) {
       co_do_move(&board, &meta, move);
       int res;
       int depth = (int)CO_META_DEPTH(h0.z) + 1;
+      unsigned long long te = CO_CLK();
       uint32_t nb = co_create_node(w, t, board, meta, depth, cur, child_slot, &res);
+      CO_PROF_ADD(w, 3, CO_CLK() - te);
       if (nb == CO_NONE) return;
       cs = make_uint4(nb, 0u, (best_slot.z & 0xFFFFu) | (1u << 16), (uint32_t)res | 0x100u);
-      co_store_unit(A, child_slot, cs);
       cur = nb;
       cur_slot = child_slot;
       h0 = make_uint4((uint32_t)board, (uint32_t)(board >> 32), co_meta_make(meta, depth, 0), 0u);
@@ -419,7 +614,6 @@ CO_DEV void co_search(CoWave &w, CoTree &t) {
         }
       }
       WAVE_SYNC();
-      leaf_is_new = 1;
       break;
     }
     /* kVisited: descend */
@@ -428,6 +622,7 @@ CO_DEV void co_search(CoWave &w, CoTree &t) {
     cs = best_slot;
     h0 = co_load_unit(A, cur);
     h1 = co_load_unit(A, cur + 1);
+    FOR_LANES { L(ev) = A[cur + 2 + lane]; }
     ++D;
     FOR_LANES {
       if (lane == 0) {
@@ -437,15 +632,13 @@ CO_DEV void co_search(CoWave &w, CoTree &t) {
     }
     WAVE_SYNC();
   }
-  (void)leaf_is_new;
   int r = co_slot_result(cs);
   if (co_res_terminal(r)) {
-    /* trainmc.cpp:663-682 */
-    co_propagate_terminal(t, path_block, path_slot, D);
+    /* trainmc.cpp:663-682.  (For a fresh child the slot is first written here.) */
     float cur_eval = co_res_drawn(r) ? 0.0f : -1.0f;
-    cs = co_load_unit(A, cur_slot); /* propagate may not touch the leaf, but stay literal */
     cs.y = co_f2u(cur_eval);
     co_store_unit(A, cur_slot, cs);
+    co_propagate_terminal(t, path_block, path_slot, D);
     FOR_LANES {
       if (lane < D) {
         int kk = D - lane; /* kk-th ancestor receives eval*(-1)^(kk-1) - 1 */
@@ -457,6 +650,7 @@ CO_DEV void co_search(CoWave &w, CoTree &t) {
       }
     }
     WAVE_SYNC();
+    rc.valid = 0;
   } else {
     /* trainmc.cpp:684-692: default +1 evaluation, queue the leaf */
     cs.y = co_f2u(1.0f);
@@ -500,12 +694,17 @@ CO_DEV int co_mc_do_iteration(CoWave &w, CoTree &t, const float *eval, const flo
     return 0;
   }
   if (w.gc.n_pending > 0) co_receive_eval(w, t, eval, probs);
+  CoRoot rc;
+  rc.valid = 0;
   for (;;) {
     if (!(w.gc.n_pending < w.spe && t.tc.searches_done < w.max_searches)) break;
-    rs = co_load_unit(t.A, co_load_unit(t.A, t.tc.root + 1).x);
-    if (co_res_known(co_slot_result(rs)) || co_slot_all_visited(rs)) break;
+    if (!rc.valid) co_root_load(t, rc);
+    if (co_res_known(co_slot_result(rc.cs)) || co_slot_all_visited(rc.cs)) break;
     if (w.gc.error) break;
-    co_search(w, t);
+    unsigned long long t0 = CO_CLK();
+    co_search(w, t, rc);
+    CO_PROF_ADD(w, 1, CO_CLK() - t0);
+    CO_PROF_ADD(w, 5, 1ull);
   }
   rs = co_load_unit(t.A, co_load_unit(t.A, t.tc.root + 1).x);
   return (t.tc.searches_done == w.max_searches || co_res_known(co_slot_result(rs))) && w.gc.n_pending == 0;
@@ -752,7 +951,7 @@ CO_DEV int co_choose_move_and_continue(CoWave &w) {
   while (!need_eval) {
     if (w.gc.error) return 0;
     int p = w.gc.to_play;
-    CoTree &me = w.tr[p];
+    CoTree &me = w.me;
     uint4 rs = co_load_unit(me.A, co_load_unit(me.A, me.tc.root + 1).x);
     if (co_res_known(co_slot_result(rs)) && w.gc.mate_turn == 0) w.gc.mate_turn = w.gc.n_samples + 1;
     float *sample = (float *)0;
@@ -778,8 +977,14 @@ CO_DEV int co_choose_move_and_continue(CoWave &w) {
       else w.gc.result = CO_RESULT_WIN;
       return 1;
     }
+    /* hand over: the opponent becomes the player to move */
     w.gc.to_play = 1 - p;
-    CoTree &opp = w.tr[1 - p];
+    {
+      CoTree tmp = w.me;
+      w.me = w.opp;
+      w.opp = tmp;
+    }
+    CoTree &opp = w.me; /* the new player to move */
     uint64_t board = (uint64_t)h0.x | ((uint64_t)h0.y << 32);
     int depth = (int)CO_META_DEPTH(h0.z);
     if (opp.tc.root == CO_NONE) {
@@ -798,9 +1003,14 @@ CO_DEV int co_choose_move_and_continue(CoWave &w) {
 
 /* SelfPlayer::doIteration, selfplayer.cpp:115-122 */
 CO_DEV int co_sp_do_iteration(CoWave &w, const float *eval, const float *probs) {
-  int done = co_mc_do_iteration(w, w.tr[w.gc.to_play], eval, probs);
+  int done = co_mc_do_iteration(w, w.me, eval, probs);
   if (w.gc.error) return 0;
-  if (done) return co_choose_move_and_continue(w);
+  if (done) {
+    unsigned long long t0 = CO_CLK();
+    int r = co_choose_move_and_continue(w);
+    CO_PROF_ADD(w, 2, CO_CLK() - t0);
+    return r;
+  }
   return 0;
 }
 
@@ -825,10 +1035,15 @@ CO_DEV void co_mcts_step_wave(const EngineParams &P, int g) {
   CoWave w;
   w.g = g;
   w.gc = gc;
-  for (int p = 0; p < 2; ++p) {
-    w.tr[p].A = P.arena + (size_t)(2 * g + p) * ((size_t)P.cap_units + CO_ARENA_PAD);
-    w.tr[p].tc = P.trees[2 * g + p];
-    w.tr[p].cap = P.cap_units;
+  {
+    const size_t stride = (size_t)P.cap_units + CO_ARENA_PAD;
+    const int tm = 2 * g + gc.to_play, to = 2 * g + 1 - gc.to_play;
+    w.me.A = P.arena + (size_t)tm * stride;
+    w.me.tc = P.trees[tm];
+    w.me.cap = P.cap_units;
+    w.opp.A = P.arena + (size_t)to * stride;
+    w.opp.tc = P.trees[to];
+    w.opp.cap = P.cap_units;
   }
   w.mt = P.rng + (size_t)g * CO_MT_N;
   w.pend_leaf = P.pend_leaf + (size_t)g * P.searches_per_eval;
@@ -837,12 +1052,14 @@ CO_DEV void co_mcts_step_wave(const EngineParams &P, int g) {
   w.req = P.req + (size_t)g * P.searches_per_eval * CO_STATE_STRIDE;
   w.samples = P.samples ? P.samples + (size_t)g * CO_MAX_PLIES * CO_SAMPLE_FLOATS : (float *)0;
   w.trace = P.trace ? P.trace + (size_t)g * CO_TRACE_CAP : (int32_t *)0;
+  w.prof = P.prof ? P.prof + (size_t)g * 8 : (unsigned long long *)0;
   w.max_searches = P.max_searches;
   w.spe = P.searches_per_eval;
   w.testing = P.testing;
   w.trace_on = P.trace_on && P.trace;
   w.c_puct = P.c_puct;
   w.epsilon = P.epsilon;
+  CO_PROF_ADD(w, 4, 1ull);
   int off = P.fused_pack ? gc.row_off : P.req_offset[g];
   int done = co_sp_do_iteration(w, P.nn_eval + off, P.nn_probs + (size_t)off * CO_NUM_MOVES);
   if (done) w.gc.done = 1;
@@ -863,8 +1080,8 @@ CO_DEV void co_mcts_step_wave(const EngineParams &P, int g) {
   FOR_LANES {
     if (lane == 0) {
       P.games[g] = w.gc;
-      P.trees[2 * g] = w.tr[0].tc;
-      P.trees[2 * g + 1] = w.tr[1].tc;
+      P.trees[2 * g + w.gc.to_play] = w.me.tc;
+      P.trees[2 * g + 1 - w.gc.to_play] = w.opp.tc;
     }
   }
 }

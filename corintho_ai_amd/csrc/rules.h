@@ -117,9 +117,10 @@ CO_DEV int co_legal_moves(uint64_t board, uint32_t meta, uint32_t out[3]) {
   uint32_t m0 = 0xFFFFFFFFu, m1 = 0xFFFFFFFFu, m2 = 0xFFFFFFFFu;
   int is_lines = 0;
   /* one line per category, first match in scan order (game.cpp:265,310,330-356,368-388) */
-  const uint64_t cat_mask[4] = {0xFFFull, 0xFFFull << 12, 0x3Full << 24, 0xFull << 30};
+#pragma unroll
   for (int cat = 0; cat < 4; ++cat) {
-    uint64_t c = cand & cat_mask[cat];
+    const uint64_t cmask = cat == 0 ? 0xFFFull : cat == 1 ? (0xFFFull << 12) : cat == 2 ? (0x3Full << 24) : (0xFull << 30);
+    uint64_t c = cand & cmask;
     if (!c) continue;
     is_lines = 1;
     int j = co_ffs64(c) - 1;

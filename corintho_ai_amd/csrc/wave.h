@@ -98,39 +98,61 @@ extern thread_local int co_emu_block_idx;
 #define UNI_U(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
 #define UNI_F(x) __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x)))
 
+/* Cross-lane reductions stay in the VALU: four DPP steps reduce each row of 16
+ * lanes (quad_perm xor-1, xor-2, row_half_mirror, row_mirror -- valid for
+ * commutative ops because every lane of a group already holds the group's
+ * value), then four v_readlane + scalar-operand ops join the rows.  No LDS
+ * round trips (ds_bpermute), which dominated the search loop's latency. */
+#define CO_DPP_XOR1 0xB1        /* quad_perm [1,0,3,2] */
+#define CO_DPP_XOR2 0x4E        /* quad_perm [2,3,0,1] */
+#define CO_DPP_HALF_MIRROR 0x141
+#define CO_DPP_MIRROR 0x140
+#define CO_DPP_I(v, ctrl) __builtin_amdgcn_update_dpp(0, (v), (ctrl), 0xF, 0xF, false)
+#define CO_DPP_F(v, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (ctrl), 0xF, 0xF, false))
+__device__ __forceinline__ float co_fmaxsel(float a, float b) { return b > a ? b : a; }
 __device__ __forceinline__ float co_wave_max_f32(float v) {
-  // butterfly over 64 lanes; max is exact and order independent
-  for (int o = 32; o >= 1; o >>= 1) {
-    float t = __shfl_xor(v, o, 64);
-    v = t > v ? t : v;
-  }
-  return v;
+  v = co_fmaxsel(v, CO_DPP_F(v, CO_DPP_XOR1));
+  v = co_fmaxsel(v, CO_DPP_F(v, CO_DPP_XOR2));
+  v = co_fmaxsel(v, CO_DPP_F(v, CO_DPP_HALF_MIRROR));
+  v = co_fmaxsel(v, CO_DPP_F(v, CO_DPP_MIRROR));
+  float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+  float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+  float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+  float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+  return co_fmaxsel(co_fmaxsel(r0, r1), co_fmaxsel(r2, r3));
 }
 __device__ __forceinline__ int co_wave_sum_i32(int v) {
-  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += CO_DPP_I(v, CO_DPP_XOR1);
+  v += CO_DPP_I(v, CO_DPP_XOR2);
+  v += CO_DPP_I(v, CO_DPP_HALF_MIRROR);
+  v += CO_DPP_I(v, CO_DPP_MIRROR);
+  return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+         __builtin_amdgcn_readlane(v, 48);
 }
+/* broadcast from a wave-uniform lane index: v_readlane, not ds_bpermute */
+__device__ __forceinline__ int co_rl(int v, int i) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(i)); }
 template <typename T>
 __device__ __forceinline__ T co_bcast(T v, int i);
 template <>
 __device__ __forceinline__ int co_bcast<int>(int v, int i) {
-  return __shfl(v, i, 64);
+  return co_rl(v, i);
 }
 template <>
 __device__ __forceinline__ uint32_t co_bcast<uint32_t>(uint32_t v, int i) {
-  return (uint32_t)__shfl((int)v, i, 64);
+  return (uint32_t)co_rl((int)v, i);
 }
 template <>
 __device__ __forceinline__ float co_bcast<float>(float v, int i) {
-  return __shfl(v, i, 64);
+  return __int_as_float(co_rl(__float_as_int(v), i));
 }
 template <>
 __device__ __forceinline__ uint4 co_bcast<uint4>(uint4 v, int i) {
   uint4 r;
-  r.x = (uint32_t)__shfl((int)v.x, i, 64);
-  r.y = (uint32_t)__shfl((int)v.y, i, 64);
-  r.z = (uint32_t)__shfl((int)v.z, i, 64);
-  r.w = (uint32_t)__shfl((int)v.w, i, 64);
+  int u = __builtin_amdgcn_readfirstlane(i);
+  r.x = (uint32_t)__builtin_amdgcn_readlane((int)v.x, u);
+  r.y = (uint32_t)__builtin_amdgcn_readlane((int)v.y, u);
+  r.z = (uint32_t)__builtin_amdgcn_readlane((int)v.z, u);
+  r.w = (uint32_t)__builtin_amdgcn_readlane((int)v.w, u);
   return r;
 }
 #define WAVE_BALLOT(p) ((uint64_t)__ballot(p))
