@@ -223,9 +223,10 @@ struct ca_trainer {
     P.all_done = all_done.p;
     P.row_counter = nullptr; /* counted in fused mode only */
     P.fused_pack = 0;
+    P.defer_handover = 0;
     P.pack_counter = pack_counter.p;
 #ifdef CO_PROF
-    prof.alloc((size_t)G * 8);
+    prof.alloc((size_t)G * 16 + 24);
     P.prof = prof.p;
 #else
     P.prof = nullptr;
@@ -452,6 +453,7 @@ struct ca_trainer {
     if (iterations == 0) rt_memset(req_offset.p, 0, ((size_t)G + 1) * 4, stream);
     P.row_counter = self_pack ? nullptr : row_counter.p;
     P.fused_pack = self_pack ? 1 : 0;
+    P.defer_handover = self_pack ? 1 : 0;
     int64_t it = 0;
     int idle_flips = 0;
     int in_window = 0;
@@ -513,14 +515,23 @@ struct ca_trainer {
             idle_flips = 0;
           }
         }
-        if (!cfg.testing && !finished && tot_done[0] == 0)
-          throw EngineError(CA_ERR_ENGINE, "No requests during training"); /* main.pyx:161-163 */
+        /* main.pyx:161-163 raises when a training iteration yields no request.  With deferred
+         * hand-overs a single empty batch is legal (every running game may be between turns),
+         * so only a run of empty polls means that no game can make progress any more. */
+        if (!cfg.testing && !finished) {
+          if (tot_done[0] == 0) {
+            if (++idle_flips > 16) throw EngineError(CA_ERR_ENGINE, "No requests during training");
+          } else {
+            idle_flips = 0;
+          }
+        }
       }
     }
     rt_sync(stream);
     for (auto &e : ev) rt_event_destroy(e);
     P.row_counter = nullptr;
     P.fused_pack = 0;
+    P.defer_handover = 0;
     host_games_valid = false;
     scan_valid_for = -99;
     pack(to_play); /* refresh the done flag and the batch description */
@@ -602,15 +613,19 @@ extern "C" int ca_trainer_pack_samples_device(ca_trainer *t, void *d_sp, void *d
 }
 extern "C" int ca_trainer_reset(ca_trainer *t, int32_t seed) { CA_GUARD(t->reset_games(seed)) }
 /* diagnostic builds (-DCO_PROF): summed in-kernel cycle stamps, see mcts.h; not in the public header */
-extern "C" int ca_trainer_prof(ca_trainer *t, unsigned long long out[8]) {
+extern "C" int ca_trainer_prof(ca_trainer *t, unsigned long long out[36]) {
   CA_GUARD({
-    for (int i = 0; i < 8; ++i) out[i] = 0;
+    for (int i = 0; i < 36; ++i) out[i] = 0;
     if (!t->prof.p) throw EngineError(CA_ERR_STATE, "not a -DCO_PROF build");
-    std::vector<unsigned long long> h((size_t)t->G * 8);
+    std::vector<unsigned long long> h((size_t)t->G * 16);
     rt_d2h(h.data(), t->prof.p, h.size() * 8, t->stream);
     rt_sync(t->stream);
     for (int g = 0; g < t->G; ++g)
-      for (int i = 0; i < 8; ++i) out[i] += h[(size_t)g * 8 + i];
+      for (int i = 0; i < 16; ++i) out[i] += h[(size_t)g * 16 + i];
+    unsigned long long clk[20];
+    rt_d2h(clk, t->prof.p + (size_t)t->G * 16, sizeof clk, t->stream);
+    rt_sync(t->stream);
+    for (int i = 0; i < 20; ++i) out[16 + i] = clk[i];
   })
 }
 

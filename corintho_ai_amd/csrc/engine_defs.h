@@ -77,7 +77,7 @@ struct GameCtl {
   uint32_t nodes;     /* ... nodes created */
   int32_t trace_len;
   int32_t row_off;    /* fused mode: first row of this game's requests in the compact batch */
-  int32_t pad[1];
+  int32_t resume;     /* fused mode: the new mover's first searches of a turn were deferred to the next step */
 };
 
 struct TreeCtl {
@@ -122,6 +122,7 @@ struct EngineParams {
    * (games still running << 32) | rows of this iteration's batch; the other one is
    * cleared for the next iteration.  The network kernels read the low word. */
   int32_t fused_pack;
+  int32_t defer_handover; /* fused mode: end a game's step at the hand-over (see mcts.h co_choose_move_and_continue) */
   unsigned long long *pack_counter; /* [2] */
   unsigned long long *prof;         /* [G][8] cycle stamps, profiling builds (-DCO_PROF) only */
 };

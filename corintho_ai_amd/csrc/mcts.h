@@ -56,7 +56,7 @@ struct CoWave {
   int32_t *trace;
   unsigned long long *prof;
   /* config */
-  int max_searches, spe, testing, trace_on;
+  int max_searches, spe, testing, trace_on, defer_handover;
   float c_puct, epsilon;
 };
 
@@ -282,16 +282,17 @@ CO_DEV void co_receive_one(CoWave &w, CoTree &t, int k, float leaf_eval, const f
  *   F  per leaf, lanes = edges: write the priors back
  *   G  per leaf in request order, lanes = path levels: the backup
  * Falls back to co_receive_one when a leaf has more than CO_RE legal moves. */
-#define CO_RB 16
+#define CO_RB 8
 #define CO_RE 48
 #define CO_RS (CO_RE + 1) /* LDS row stride: odd, so lane k's column walk is conflict-free */
 CO_DEV void co_receive_batch(CoWave &w, CoTree &t, int k0, int nb, const float *eval, const float *probs) {
   uint4 *A = t.A;
-  WAVE_SHARED(float, tp, CO_RB * CO_RS);      /* priors -> weights */
-  WAVE_SHARED(float, tn, CO_RB * CO_RS);      /* noise */
+  WAVE_SHARED(float, tp, CO_RB * CO_RS + 4);  /* priors -> weights (+4: phase D reads four ahead) */
+  WAVE_SHARED(float, tn, CO_RB * CO_RS + 4);  /* noise */
   WAVE_SHARED(uint8_t, tm, CO_RB * CO_RS + 3); /* move id, then quantised prior low byte */
   WAVE_SHARED(uint8_t, tq, CO_RB * CO_RS + 3); /* quantised prior high bit */
   WAVE_SHARED(int, offs, CO_RB + 1);          /* prefix of legal-move counts = first draw of leaf k */
+  unsigned long long tA = CO_CLK();
   /* ---- A */
   LV(uint32_t, leafv);
   LV(int, nv);
@@ -323,19 +324,46 @@ CO_DEV void co_receive_batch(CoWave &w, CoTree &t, int k0, int nb, const float *
     return;
   }
   WAVE_SYNC();
-  /* ---- B */
-  for (int k = 0; k < nb; ++k) {
-    uint32_t leaf = WAVE_BCAST(leafv, k);
-    int n = WAVE_BCAST(nv, k);
-    const float *pr = probs + (size_t)(k0 + k) * CO_NUM_MOVES;
-    FOR_LANES {
-      if (lane < n) {
-        uint32_t mv = A[leaf + 2 + lane].z & 127u;
-        tm[k * CO_RS + lane] = (uint8_t)mv;
-        tp[k * CO_RS + lane] = pr[mv];
+  CO_PROF_ADD(w, 8, CO_CLK() - tA);
+  tA = CO_CLK();
+  /* ---- B: every leaf's loads are issued before the first is used (two memory round
+   * trips for the whole batch instead of two per leaf) */
+  {
+    /* loads are unconditional (inactive lanes read unit 0 / prior 0) so that none of them
+     * sits in a predicated block with its first use: the compiler then keeps all eight in
+     * flight instead of waiting for each */
+    LV(uint32_t, mvv[CO_RB]);
+    LV(float, prv[CO_RB]);
+#pragma unroll
+    for (int k = 0; k < CO_RB; ++k) {
+      uint32_t leaf = WAVE_BCAST(leafv, k);
+      int n = WAVE_BCAST(nv, k);
+      FOR_LANES {
+        uint32_t at = (k < nb && lane < n) ? leaf + 2u + (uint32_t)lane : 0u;
+        L(mvv[k]) = A[at].z;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < CO_RB; ++k) {
+      const float *pr = probs + (size_t)(k < nb ? k0 + k : k0) * CO_NUM_MOVES;
+      FOR_LANES {
+        L(mvv[k]) &= 127u;
+        L(prv[k]) = pr[L(mvv[k]) < (uint32_t)CO_NUM_MOVES ? L(mvv[k]) : 0u];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < CO_RB; ++k) {
+      int n = WAVE_BCAST(nv, k);
+      FOR_LANES {
+        if (k < nb && lane < n) {
+          tm[k * CO_RS + lane] = (uint8_t)L(mvv[k]);
+          tp[k * CO_RS + lane] = L(prv[k]);
+        }
       }
     }
   }
+  CO_PROF_ADD(w, 9, CO_CLK() - tA);
+  tA = CO_CLK();
   /* ---- C: draw i belongs to the leaf k with offs[k] <= i < offs[k+1] */
   for (int base = 0; base < total; base += CO_WAVE) {
     int cnt = total - base < CO_WAVE ? total - base : CO_WAVE;
@@ -351,6 +379,8 @@ CO_DEV void co_receive_batch(CoWave &w, CoTree &t, int k0, int nb, const float *
     }
   }
   WAVE_SYNC();
+  CO_PROF_ADD(w, 10, CO_CLK() - tA);
+  tA = CO_CLK();
   /* ---- D: lane k owns leaf k */
   LV(float, denomv);
   FOR_LANES {
@@ -359,39 +389,62 @@ CO_DEV void co_receive_batch(CoWave &w, CoTree &t, int k0, int nb, const float *
       const int n = L(nv);
       float *fp = tp + lane * CO_RS;
       float *dn = tn + lane * CO_RS;
+      /* the sums are sequential float additions in edge order; reading four entries
+       * ahead keeps the LDS latency off the dependent add chain (x + 0.0f == x) */
       float sum = 0.0f, dsum = 0.0f;
-      for (int e = 0; e < n; ++e) {
-        sum += fp[e];
-        dsum += dn[e];
+      for (int e = 0; e < n; e += 4) {
+        float a0 = fp[e], a1 = fp[e + 1], a2 = fp[e + 2], a3 = fp[e + 3];
+        float d0 = dn[e], d1 = dn[e + 1], d2 = dn[e + 2], d3 = dn[e + 3];
+        sum += a0;
+        dsum += d0;
+        sum += e + 1 < n ? a1 : 0.0f;
+        dsum += e + 1 < n ? d1 : 0.0f;
+        sum += e + 2 < n ? a2 : 0.0f;
+        dsum += e + 2 < n ? d2 : 0.0f;
+        sum += e + 3 < n ? a3 : 0.0f;
+        dsum += e + 3 < n ? d3 : 0.0f;
       }
       float one_minus = (float)1 - w.epsilon;
       float scalar = (float)(1.0 / (double)sum * (double)one_minus);
       float dscalar = (float)(1.0 / (double)dsum * (double)w.epsilon);
       float max_prob = 0.0f;
-      for (int e = 0; e < n; ++e) {
-        float a = fp[e] * scalar;
-        float d = dn[e] * dscalar;
-        float wt = a + d;
-        fp[e] = wt;
-        max_prob = wt > max_prob ? wt : max_prob;
+      for (int e = 0; e < n; e += 4) {
+        float a0 = fp[e], a1 = fp[e + 1], a2 = fp[e + 2], a3 = fp[e + 3];
+        float d0 = dn[e], d1 = dn[e + 1], d2 = dn[e + 2], d3 = dn[e + 3];
+        float w0 = a0 * scalar + d0 * dscalar, w1 = a1 * scalar + d1 * dscalar;
+        float w2 = a2 * scalar + d2 * dscalar, w3 = a3 * scalar + d3 * dscalar;
+        fp[e] = w0;
+        max_prob = w0 > max_prob ? w0 : max_prob;
+        if (e + 1 < n) { fp[e + 1] = w1; max_prob = w1 > max_prob ? w1 : max_prob; }
+        if (e + 2 < n) { fp[e + 2] = w2; max_prob = w2 > max_prob ? w2 : max_prob; }
+        if (e + 3 < n) { fp[e + 3] = w3; max_prob = w3 > max_prob ? w3 : max_prob; }
       }
       float denom = 511.0f / max_prob;
       int final_sum = 0;
-      for (int e = 0; e < n; ++e) {
-        float x = fp[e] * denom;
-        float fl = __builtin_truncf(x);
-        int q = (int)fl;
-        if (x - fl >= 0.5f) q += 1;
-        if (!(q >= 1)) q = 1;
-        final_sum += q;
-        tq[lane * CO_RS + e] = (uint8_t)((q >> 8) & 1);
-        dn[e] = co_u2f((uint32_t)(q & 255)); /* low byte parked in the noise table */
+      for (int e = 0; e < n; e += 4) {
+        float x4[4] = {fp[e], fp[e + 1], fp[e + 2], fp[e + 3]};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (e + i < n) {
+            float x = x4[i] * denom;
+            float fl = __builtin_truncf(x);
+            int q = (int)fl;
+            if (x - fl >= 0.5f) q += 1;
+            if (!(q >= 1)) q = 1;
+            final_sum += q;
+            tq[lane * CO_RS + e + i] = (uint8_t)((q >> 8) & 1);
+            dn[e + i] = co_u2f((uint32_t)(q & 255)); /* low byte parked in the noise table */
+          }
+        }
       }
       L(denomv) = (float)(1.0 / (double)(float)final_sum);
     }
   }
   WAVE_SYNC();
-  /* ---- F */
+  CO_PROF_ADD(w, 11, CO_CLK() - tA);
+  tA = CO_CLK();
+  /* ---- F: a leaf that waits for its evaluation has no children (all_visited is born
+   * true, node.h:186), so its edge words are just the move id: plain stores, no reload */
   for (int k = 0; k < nb; ++k) {
     uint32_t leaf = WAVE_BCAST(leafv, k);
     int n = WAVE_BCAST(nv, k);
@@ -399,32 +452,71 @@ CO_DEV void co_receive_batch(CoWave &w, CoTree &t, int k0, int nb, const float *
     FOR_LANES {
       if (lane < n) {
         uint32_t q = co_f2u(tn[k * CO_RS + lane]) | ((uint32_t)tq[k * CO_RS + lane] << 8);
-        uint32_t z = A[leaf + 2 + lane].z;
-        A[leaf + 2 + lane].z = (z & 0xFFFF007Fu) | ((q & 511u) << 7);
+        A[leaf + 2 + lane].z = (uint32_t)tm[k * CO_RS + lane] | ((q & 511u) << 7);
       }
       if (lane == 63) A[leaf + 1].y = co_f2u(den);
     }
   }
   WAVE_SYNC();
-  /* ---- G: backups strictly in request order (shared ancestors accumulate in that order) */
-  for (int k = 0; k < nb; ++k) {
-    int D = WAVE_BCAST(dv, k);
-    float leaf_eval = eval[k0 + k];
-    const uint32_t *pp = w.pend_path + (size_t)(k0 + k) * CO_PATH_MAX;
-    FOR_LANES {
-      if (lane <= D) {
-        int kk = D - lane;
-        float ce = (kk & 1) ? (float)((double)leaf_eval * -1.0) : leaf_eval;
-        float add = (float)((double)ce - 1.0);
-        uint32_t at = pp[lane];
-        uint4 sl = A[at];
-        sl.y = co_f2u(co_u2f(sl.y) + add);
-        sl = co_slot_set_all_visited(sl, 0);
-        A[at] = sl;
+  CO_PROF_ADD(w, 12, CO_CLK() - tA);
+  tA = CO_CLK();
+  /* ---- G: backups, lane = path level.  The slot of a shared ancestor must receive the
+   * leaves' contributions in request order (float addition is not associative).  All
+   * slots are fetched up front; leaf k then starts from the value left by the latest
+   * earlier leaf that touched the same slot (register forwarding) instead of re-reading
+   * memory, so the 16 read-modify-writes cost one memory round trip, not sixteen. */
+  {
+    LV(uint32_t, at[CO_RB]);
+    LV(uint32_t, ny[CO_RB]);
+    LV(uint32_t, nw[CO_RB]);
+    LV(int, on[CO_RB]);
+#pragma unroll
+    for (int k = 0; k < CO_RB; ++k) {
+      int D = WAVE_BCAST(dv, k);
+      const uint32_t *pp = w.pend_path + (size_t)(k < nb ? k0 + k : k0) * CO_PATH_MAX;
+      FOR_LANES {
+        L(on[k]) = (k < nb && lane <= D);
+        L(at[k]) = pp[L(on[k]) ? lane : 0];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < CO_RB; ++k) {
+      FOR_LANES {
+        if (!L(on[k])) L(at[k]) = 0u;
+        uint4 sl = A[L(at[k])]; /* unconditional: inactive lanes read unit 0 */
+        L(ny[k]) = sl.y;
+        L(nw[k]) = sl.w & ~0x100u; /* all_visited := false */
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < CO_RB; ++k) {
+      int D = WAVE_BCAST(dv, k);
+      float leaf_eval = k < nb ? eval[k0 + k] : 0.0f;
+      FOR_LANES {
+        if (L(on[k])) {
+          uint32_t cur = L(ny[k]);
+#pragma unroll
+          for (int j = 0; j < k; ++j)
+            if (L(on[j]) && L(at[j]) == L(at[k])) cur = L(ny[j]);
+          int kk = D - lane;
+          float ce = (kk & 1) ? (float)((double)leaf_eval * -1.0) : leaf_eval;
+          float add = (float)((double)ce - 1.0);
+          L(ny[k]) = co_f2u(co_u2f(cur) + add);
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < CO_RB; ++k) {
+      FOR_LANES {
+        if (L(on[k])) {
+          A[L(at[k])].y = L(ny[k]);
+          A[L(at[k])].w = L(nw[k]);
+        }
       }
     }
     WAVE_SYNC();
   }
+  CO_PROF_ADD(w, 13, CO_CLK() - tA);
   w.gc.evals += (uint32_t)nb;
 }
 
@@ -996,14 +1088,31 @@ CO_DEV int co_choose_move_and_continue(CoWave &w) {
       return co_mc_do_iteration(w, opp, (const float *)0, (const float *)0);
     }
     need_eval = co_receive_opponent_move(w, opp, choice, board, h0.z, depth);
-    if (!need_eval) need_eval = !co_mc_do_iteration(w, opp, (const float *)0, (const float *)0);
+    if (!need_eval) {
+      if (w.defer_handover) {
+        /* Lock-step scheduling only: games are independent, so the new mover's first
+         * searches may as well run in the next step.  Without this, the few games that
+         * change turns in a step run up to twice the simulations of the others and every
+         * launch waits for them.  The game's own sequence of operations is unchanged. */
+        w.gc.resume = 1;
+        return 0;
+      }
+      need_eval = !co_mc_do_iteration(w, opp, (const float *)0, (const float *)0);
+    }
   }
   return 0;
 }
 
 /* SelfPlayer::doIteration, selfplayer.cpp:115-122 */
 CO_DEV int co_sp_do_iteration(CoWave &w, const float *eval, const float *probs) {
-  int done = co_mc_do_iteration(w, w.me, eval, probs);
+  int done;
+  if (w.gc.resume) {
+    /* continuation of a deferred hand-over: selfplayer.cpp:287-288 */
+    w.gc.resume = 0;
+    done = co_mc_do_iteration(w, w.me, (const float *)0, (const float *)0);
+  } else {
+    done = co_mc_do_iteration(w, w.me, eval, probs);
+  }
   if (w.gc.error) return 0;
   if (done) {
     unsigned long long t0 = CO_CLK();
@@ -1052,14 +1161,19 @@ CO_DEV void co_mcts_step_wave(const EngineParams &P, int g) {
   w.req = P.req + (size_t)g * P.searches_per_eval * CO_STATE_STRIDE;
   w.samples = P.samples ? P.samples + (size_t)g * CO_MAX_PLIES * CO_SAMPLE_FLOATS : (float *)0;
   w.trace = P.trace ? P.trace + (size_t)g * CO_TRACE_CAP : (int32_t *)0;
-  w.prof = P.prof ? P.prof + (size_t)g * 8 : (unsigned long long *)0;
+  w.prof = P.prof ? P.prof + (size_t)g * 16 : (unsigned long long *)0;
   w.max_searches = P.max_searches;
   w.spe = P.searches_per_eval;
   w.testing = P.testing;
   w.trace_on = P.trace_on && P.trace;
+  w.defer_handover = P.defer_handover;
   w.c_puct = P.c_puct;
   w.epsilon = P.epsilon;
   CO_PROF_ADD(w, 4, 1ull);
+  unsigned long long t_wave0 = CO_CLK();
+#if defined(CO_PROF) && !defined(CO_EMU)
+  unsigned long long t_real0 = __builtin_amdgcn_s_memrealtime();
+#endif
   int off = P.fused_pack ? gc.row_off : P.req_offset[g];
   int done = co_sp_do_iteration(w, P.nn_eval + off, P.nn_probs + (size_t)off * CO_NUM_MOVES);
   if (done) w.gc.done = 1;
@@ -1077,6 +1191,21 @@ CO_DEV void co_mcts_step_wave(const EngineParams &P, int g) {
       for (int i = lane; i < total; i += CO_WAVE) dst[i] = src[i];
     }
   }
+  CO_PROF_ADD(w, 7, CO_CLK() - t_wave0);
+#if defined(CO_PROF) && !defined(CO_EMU)
+  if (w.prof && g == 1 && (threadIdx.x & 63) == 0) {
+    unsigned long long dr = __builtin_amdgcn_s_memrealtime() - t_real0;
+    P.prof[(size_t)P.num_games * 16 + 0] += CO_CLK() - t_wave0;
+    P.prof[(size_t)P.num_games * 16 + 1] += dr;
+  }
+  if (w.prof && (threadIdx.x & 63) == 0) {
+    unsigned long long dt = CO_CLK() - t_wave0;
+    atomicMax(P.prof + (size_t)P.num_games * 16 + 2, dt);
+    int bucket = (int)(dt / 50000ull);
+    if (bucket > 15) bucket = 15;
+    atomicAdd(P.prof + (size_t)P.num_games * 16 + 4 + bucket, 1ull);
+  }
+#endif
   FOR_LANES {
     if (lane == 0) {
       P.games[g] = w.gc;
