@@ -1,5 +1,424 @@
-// nn_rescnn.hip -- K6: the north-star 4-block residual CNN (placeholder until
-// the convolution kernels land; co_rescnn_create reports "not available").
+// nn_rescnn.hip -- K6: the north-star policy/value network, a 4-block residual
+// CNN over the 4x4 board (specification: corintho_ai_amd/nets.py "rescnn4"), as
+// ONE fused gfx950 kernel on fp32 MFMA.
+//
+// Mapping.  A 4x4 board has exactly 16 pixels -- one N-tile of
+// v_mfma_f32_16x16x4_f32.  A 3x3 convolution is evaluated transposed, as for the
+// MLP (nn_mlp.hip): out^T[co][pixel] += W[tap][ci][co] * in[ci][pixel + tap], so
+//   A operand = a 16(co) x 4(ci) weight fragment,
+//   B operand = the activation tile of ONE position shifted by the tap.
+// The activation tile of a position lives in registers in accumulator layout
+// (pixel on the lane, lane & 15; channel 16t + 4q + r in register r of tile t,
+// q = lane >> 4), which IS the B layout when the K steps run in the order
+// (tap, t, r) with k-slot q.  The spatial shift of a tap is a DPP row shift inside
+// each 16-lane row (source pixel p + 4dy + dx, zero outside the row) plus a lane
+// mask for the x wrap-around: "im2col" costs two VALU ops per B operand and no
+// memory traffic at all.  Activations, the residual skip and the accumulators
+// never leave registers through stem + 8 convolutions; bias + BatchNorm + ReLU +
+// residual add run on the accumulators; the heads (1x1 convs, dense layers, tanh,
+// 96-way softmax) are fused behind them.  Only weights move: one tap of one
+// convolution (16 KB) at a time through a double-buffered LDS window filled by
+// LDS-DMA (global_load_lds) while the previous tap computes.
+//
+// fp32 end to end, fixed k order, one position per MFMA column: a row's result
+// does not depend on its batch (SURVEY 8e invariant).
+// Work: 9.65 MFLOP per position, no padding waste in the 64->64 convolutions.
+// Geometry: 256 threads = 4 waves, 4 positions per wave (every weight fragment
+// feeds 16 MFMAs), 16 positions per workgroup.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <string.h>
+
+#include <vector>
+
+#include "engine_defs.h"
 #include "nn.h"
 
-CoNet *co_rescnn_create(const float *, size_t, size_t, rt_stream_t) { return nullptr; }
+#define RC_NB 4
+#define RC_POS_PER_WG 16
+#define RC_STEM_CHUNK 1024   /* floats: 4 steps x 4 out tiles x 64 lanes */
+#define RC_CONV_CHUNK 4096   /* floats: 16 steps x 4 out tiles x 64 lanes */
+#define RC_NUM_CONVS 9       /* stem + 8 */
+#define RC_NUM_CHUNKS 81
+#define RC_TRUNK_FLOATS (9 * RC_STEM_CHUNK + 72 * RC_CONV_CHUNK)
+#define RC_NUM_WEIGHTS 312383
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct RcParams {
+  const float *in;        /* [rows][80] */
+  const int32_t *d_rows;
+  const float *wtrunk;    /* RC_TRUNK_FLOATS, fragment order */
+  const float *epi;       /* [9][3][64]: bias, bn scale, bn shift */
+  const float *whead;     /* [16][64]   1x1 convs: rows 0..3 policy, 4..5 value */
+  const float *head_epi;  /* [3][16] */
+  const float *wpol;      /* [16][6][64] */
+  const float *bpol;      /* [96] */
+  const float *wv1;       /* [8][4][64] */
+  const float *bv1;       /* [64] */
+  const float *wv2;       /* [16][64] */
+  const float *bv2;       /* [1] */
+  float *eval;
+  float *probs;
+};
+
+__device__ __forceinline__ const float *rc_chunk_ptr(const float *wtrunk, int ch) {
+  return ch < 9 ? wtrunk + ch * RC_STEM_CHUNK : wtrunk + 9 * RC_STEM_CHUNK + (ch - 9) * RC_CONV_CHUNK;
+}
+
+/* LDS-DMA: each wave-instruction moves 1 KiB (lane i: bytes [16 i, 16 i + 16)) */
+__device__ __forceinline__ void rc_stage(const float *wtrunk, float *lds_buf, int ch, int wave, int lane) {
+  const float *src = rc_chunk_ptr(wtrunk, ch);
+  const int pieces = ch < 9 ? RC_STEM_CHUNK / 256 : RC_CONV_CHUNK / 256;
+  for (int p = wave; p < pieces; p += 4) {
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + p * 256 + lane * 4),
+                                     (void __attribute__((address_space(3))) *)(lds_buf + p * 256), 16, 0, 0);
+  }
+}
+
+/* the tap's view of an activation register: pixel p reads pixel p + S (S = 4 dy + dx),
+ * zero outside the board */
+template <int S>
+__device__ __forceinline__ float rc_row_shift(float v) {
+  if (S == 0) return v;
+  constexpr int ctrl = S > 0 ? (0x100 + S) : (0x110 - S); /* row_shl:S reads lane+S, row_shr:S reads lane-S */
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xF, 0xF, true));
+}
+
+template <int TAP>
+__device__ __forceinline__ float rc_tap(float v, bool okL, bool okR) {
+  constexpr int dy = TAP / 3 - 1, dx = TAP % 3 - 1;
+  float s = rc_row_shift<4 * dy + dx>(v);
+  if (dx == -1) s = okL ? s : 0.0f;
+  if (dx == 1) s = okR ? s : 0.0f;
+  return s;
+}
+
+template <int CT, int TAP>
+__device__ __forceinline__ void rc_conv_tap(f32x4 (&acc)[RC_NB][4], const float (&in)[RC_NB][4][4], const float *w, int lane,
+                                            bool okL, bool okR) {
+#pragma unroll
+  for (int t = 0; t < CT; ++t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float *wp = w + ((t * 4 + r) * 4) * 64 + lane;
+      float a[4];
+#pragma unroll
+      for (int to = 0; to < 4; ++to) a[to] = wp[to * 64];
+#pragma unroll
+      for (int nb = 0; nb < RC_NB; ++nb) {
+        const float b = rc_tap<TAP>(in[nb][t][r], okL, okR);
+#pragma unroll
+        for (int to = 0; to < 4; ++to) acc[nb][to] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[to], b, acc[nb][to], 0, 0, 0);
+      }
+    }
+  }
+}
+
+/* one 3x3 convolution = 9 weight chunks; chunk `ch` is consumed from LDS buffer ch & 1
+ * while chunk ch + 1 streams into the other */
+template <int CT>
+__device__ __forceinline__ void rc_conv3x3(f32x4 (&acc)[RC_NB][4], const float (&in)[RC_NB][4][4], int &ch,
+                                           const float *wtrunk, float *lds_w, int wave, int lane, bool okL, bool okR) {
+#pragma unroll
+  for (int nb = 0; nb < RC_NB; ++nb)
+#pragma unroll
+    for (int to = 0; to < 4; ++to) acc[nb][to] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#define RC_TAP(T)                                                                         \
+  {                                                                                       \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                      \
+    __syncthreads();                                                                      \
+    if (ch + 1 < RC_NUM_CHUNKS) rc_stage(wtrunk, lds_w + ((ch + 1) & 1) * RC_CONV_CHUNK, ch + 1, wave, lane); \
+    rc_conv_tap<CT, T>(acc, in, lds_w + (ch & 1) * RC_CONV_CHUNK, lane, okL, okR);        \
+    ++ch;                                                                                 \
+  }
+  RC_TAP(0) RC_TAP(1) RC_TAP(2) RC_TAP(3) RC_TAP(4) RC_TAP(5) RC_TAP(6) RC_TAP(7) RC_TAP(8)
+#undef RC_TAP
+}
+
+/* conv bias -> BatchNorm affine (-> + skip) -> ReLU, channel 16 to + 4 q + r */
+template <bool ADD_SKIP, bool RELU>
+__device__ __forceinline__ void rc_epilogue(float (&out)[RC_NB][4][4], const f32x4 (&acc)[RC_NB][4],
+                                            const float (&skip)[RC_NB][4][4], const float *epi, int q) {
+#pragma unroll
+  for (int to = 0; to < 4; ++to) {
+    const float4 b4 = *reinterpret_cast<const float4 *>(epi + 16 * to + 4 * q);
+    const float4 a4 = *reinterpret_cast<const float4 *>(epi + 64 + 16 * to + 4 * q);
+    const float4 c4 = *reinterpret_cast<const float4 *>(epi + 128 + 16 * to + 4 * q);
+    const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+    const float aa[4] = {a4.x, a4.y, a4.z, a4.w};
+    const float cc[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+    for (int nb = 0; nb < RC_NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[nb][to][r] + bb[r];
+        v = aa[r] * v + cc[r];
+        if (ADD_SKIP) v = skip[nb][to][r] + v;
+        if (RELU) v = v > 0.0f ? v : 0.0f;
+        out[nb][to][r] = v;
+      }
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void co_k_rescnn_forward(RcParams P) {
+  __shared__ __attribute__((aligned(16))) float lds_w[2 * RC_CONV_CHUNK];
+  __shared__ float lds_feat[4][RC_NB][96];
+  const int rows = *P.d_rows;
+  const int row0 = blockIdx.x * RC_POS_PER_WG;
+  if (row0 >= rows) return;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, q = lane >> 4, c = lane & 15;
+  const bool okL = (c & 3) != 0, okR = (c & 3) != 3;
+  rc_stage(P.wtrunk, lds_w, 0, wave, lane);
+
+  /* input planes: lane (q, pixel c) holds channels 4q..4q+3 -- q 0: the cell's four
+   * board bits, q 1: reserves 0..3, q 2: reserves 4..5 (+ zero padding), q 3: zeros */
+  float x[RC_NB][4][4];
+#pragma unroll
+  for (int nb = 0; nb < RC_NB; ++nb) {
+    const int pos = row0 + wave * RC_NB + nb;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pos < rows) v = *reinterpret_cast<const float4 *>(P.in + (size_t)pos * CO_STATE_STRIDE + (q == 0 ? 4 * c : 60 + 4 * q));
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) x[nb][t][r] = 0.0f;
+    x[nb][0][0] = v.x;
+    x[nb][0][1] = v.y;
+    x[nb][0][2] = v.z;
+    x[nb][0][3] = v.w;
+  }
+
+  f32x4 acc[RC_NB][4];
+  float y[RC_NB][4][4];
+  int ch = 0;
+  /* stem */
+  rc_conv3x3<1>(acc, x, ch, P.wtrunk, lds_w, wave, lane, okL, okR);
+  rc_epilogue<false, true>(x, acc, x, P.epi, q);
+  /* residual tower */
+  for (int b = 0; b < 4; ++b) {
+    rc_conv3x3<4>(acc, x, ch, P.wtrunk, lds_w, wave, lane, okL, okR);
+    rc_epilogue<false, true>(y, acc, x, P.epi + (size_t)(1 + 2 * b) * 192, q);
+    rc_conv3x3<4>(acc, y, ch, P.wtrunk, lds_w, wave, lane, okL, okR);
+    rc_epilogue<true, true>(x, acc, x, P.epi + (size_t)(2 + 2 * b) * 192, q);
+  }
+
+  /* ---- heads.  1x1 convolutions: out rows 0..3 policy planes, 4..5 value planes */
+  f32x4 h1[RC_NB];
+#pragma unroll
+  for (int nb = 0; nb < RC_NB; ++nb) h1[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float a = P.whead[(t * 4 + r) * 64 + lane];
+#pragma unroll
+      for (int nb = 0; nb < RC_NB; ++nb) h1[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, x[nb][t][r], h1[nb], 0, 0, 0);
+    }
+  {
+    const float4 b4 = *reinterpret_cast<const float4 *>(P.head_epi + 4 * q);
+    const float4 a4 = *reinterpret_cast<const float4 *>(P.head_epi + 16 + 4 * q);
+    const float4 c4 = *reinterpret_cast<const float4 *>(P.head_epi + 32 + 4 * q);
+    const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+    const float aa[4] = {a4.x, a4.y, a4.z, a4.w};
+    const float cc[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+    for (int nb = 0; nb < RC_NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = h1[nb][r] + bb[r];
+        v = aa[r] * v + cc[r];
+        v = v > 0.0f ? v : 0.0f;
+        /* flatten: policy index pixel*4 + ch, value index 64 + pixel*2 + ch */
+        if (q == 0) lds_feat[wave][nb][c * 4 + r] = v;
+        if (q == 1 && r < 2) lds_feat[wave][nb][64 + c * 2 + r] = v;
+      }
+  }
+  __syncthreads();
+  /* dense layers with the wave's positions as MFMA columns (column c < RC_NB) */
+  const bool col_ok = c < RC_NB;
+  const float *feat = &lds_feat[wave][col_ok ? c : 0][0];
+  f32x4 pl[6];
+#pragma unroll
+  for (int to = 0; to < 6; ++to) pl[to] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    const float b = col_ok ? feat[4 * s + q] : 0.0f;
+#pragma unroll
+    for (int to = 0; to < 6; ++to)
+      pl[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(P.wpol[(s * 6 + to) * 64 + lane], b, pl[to], 0, 0, 0);
+  }
+  f32x4 v1[4];
+#pragma unroll
+  for (int to = 0; to < 4; ++to) v1[to] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const float b = col_ok ? feat[64 + 4 * s + q] : 0.0f;
+#pragma unroll
+    for (int to = 0; to < 4; ++to)
+      v1[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(P.wv1[(s * 4 + to) * 64 + lane], b, v1[to], 0, 0, 0);
+  }
+  f32x4 v2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const float4 b4 = *reinterpret_cast<const float4 *>(P.bv1 + 16 * t + 4 * q);
+    const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float hv = v1[t][r] + bb[r];
+      hv = hv > 0.0f ? hv : 0.0f;
+      v2 = __builtin_amdgcn_mfma_f32_16x16x4f32(P.wv2[(t * 4 + r) * 64 + lane], hv, v2, 0, 0, 0);
+    }
+  }
+  /* softmax over the 96 logits of column c: registers (to, r) in the lane, q across lanes */
+  float lg[6][4];
+  float m = -INFINITY;
+#pragma unroll
+  for (int to = 0; to < 6; ++to) {
+    const float4 b4 = *reinterpret_cast<const float4 *>(P.bpol + 16 * to + 4 * q);
+    const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      lg[to][r] = pl[to][r] + bb[r];
+      m = lg[to][r] > m ? lg[to][r] : m;
+    }
+  }
+  float o = __shfl_xor(m, 16, 64);
+  m = o > m ? o : m;
+  o = __shfl_xor(m, 32, 64);
+  m = o > m ? o : m;
+  float sum = 0.0f;
+#pragma unroll
+  for (int to = 0; to < 6; ++to)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      lg[to][r] = expf(lg[to][r] - m);
+      sum += lg[to][r];
+    }
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  const int pos = row0 + wave * RC_NB + c;
+  if (col_ok && pos < rows) {
+#pragma unroll
+    for (int to = 0; to < 6; ++to) {
+      float4 p = make_float4(lg[to][0] / sum, lg[to][1] / sum, lg[to][2] / sum, lg[to][3] / sum);
+      *reinterpret_cast<float4 *>(P.probs + (size_t)pos * CO_NUM_MOVES + 16 * to + 4 * q) = p;
+    }
+    if (q == 0) P.eval[pos] = tanhf(v2[0] + P.bv2[0]);
+  }
+}
+
+/* ------------------------------------------------------------------ host */
+struct ResCnnNet : CoNet {
+  std::vector<float *> bufs;
+  RcParams P;
+  size_t cap;
+
+  float *upload(const std::vector<float> &h, rt_stream_t s) {
+    float *d = nullptr;
+    rt_malloc((void **)&d, h.size() * 4);
+    rt_h2d(d, h.data(), h.size() * 4, s);
+    bufs.push_back(d);
+    return d;
+  }
+
+  ResCnnNet(const float *w, size_t max_rows, rt_stream_t s) : cap(max_rows) {
+    const float *p = w;
+    std::vector<float> trunk(RC_TRUNK_FLOATS, 0.0f), epi((size_t)RC_NUM_CONVS * 192, 0.0f);
+    auto bn_fold = [](const float *ga, const float *be, const float *mu, const float *va, int n, float *a, float *c) {
+      for (int i = 0; i < n; ++i) {
+        a[i] = (float)((double)ga[i] / sqrt((double)va[i] + CO_BN_EPS));
+        c[i] = (float)((double)be[i] - (double)mu[i] * (double)a[i]);
+      }
+    };
+    size_t off = 0;
+    for (int cv = 0; cv < RC_NUM_CONVS; ++cv) {
+      const int cin = cv == 0 ? 10 : 64;
+      const int ct = cv == 0 ? 1 : 4;
+      const size_t chunk = cv == 0 ? RC_STEM_CHUNK : RC_CONV_CHUNK;
+      const float *K = p; /* [3][3][cin][64] */
+      for (int tap = 0; tap < 9; ++tap)
+        for (int t = 0; t < ct; ++t)
+          for (int r = 0; r < 4; ++r)
+            for (int to = 0; to < 4; ++to)
+              for (int q = 0; q < 4; ++q)
+                for (int i = 0; i < 16; ++i) {
+                  int ci = 16 * t + 4 * q + r, co = 16 * to + i;
+                  float v = ci < cin ? K[((size_t)tap * cin + ci) * 64 + co] : 0.0f;
+                  trunk[off + (size_t)tap * chunk + ((size_t)(t * 4 + r) * 4 + to) * 64 + 16 * q + i] = v;
+                }
+      off += 9 * chunk;
+      p += (size_t)9 * cin * 64;
+      const float *b = p, *ga = b + 64, *be = ga + 64, *mu = be + 64, *va = mu + 64;
+      for (int i = 0; i < 64; ++i) epi[(size_t)cv * 192 + i] = b[i];
+      bn_fold(ga, be, mu, va, 64, &epi[(size_t)cv * 192 + 64], &epi[(size_t)cv * 192 + 128]);
+      p = va + 64;
+    }
+    /* policy head */
+    const float *pk = p, *pb = pk + 64 * 4, *pga = pb + 4, *pbe = pga + 4, *pmu = pbe + 4, *pva = pmu + 4;
+    const float *pdk = pva + 4, *pdb = pdk + 64 * 96;
+    const float *vk = pdb + 96, *vb = vk + 64 * 2, *vga = vb + 2, *vbe = vga + 2, *vmu = vbe + 2, *vva = vmu + 2;
+    const float *vd1k = vva + 2, *vd1b = vd1k + 32 * 64, *vd2k = vd1b + 64, *vd2b = vd2k + 64;
+    std::vector<float> whead(16 * 64, 0.0f), hepi(48, 0.0f), wpol(16 * 6 * 64, 0.0f), bpol(pdb, pdb + 96);
+    std::vector<float> wv1(8 * 4 * 64, 0.0f), bv1(vd1b, vd1b + 64), wv2(16 * 64, 0.0f), bv2(vd2b, vd2b + 1);
+    for (int t = 0; t < 4; ++t)
+      for (int r = 0; r < 4; ++r)
+        for (int q = 0; q < 4; ++q)
+          for (int i = 0; i < 16; ++i) {
+            int k = 16 * t + 4 * q + r;
+            float v = i < 4 ? pk[k * 4 + i] : i < 6 ? vk[k * 2 + (i - 4)] : 0.0f;
+            whead[(size_t)(t * 4 + r) * 64 + 16 * q + i] = v;
+            wv2[(size_t)(t * 4 + r) * 64 + 16 * q + i] = i == 0 ? vd2k[k] : 0.0f;
+          }
+    for (int i = 0; i < 4; ++i) hepi[i] = pb[i];
+    for (int i = 0; i < 2; ++i) hepi[4 + i] = vb[i];
+    bn_fold(pga, pbe, pmu, pva, 4, &hepi[16], &hepi[32]);
+    bn_fold(vga, vbe, vmu, vva, 2, &hepi[16 + 4], &hepi[32 + 4]);
+    for (int s2 = 0; s2 < 16; ++s2)
+      for (int to = 0; to < 6; ++to)
+        for (int q = 0; q < 4; ++q)
+          for (int i = 0; i < 16; ++i) wpol[((size_t)s2 * 6 + to) * 64 + 16 * q + i] = pdk[(size_t)(4 * s2 + q) * 96 + 16 * to + i];
+    for (int s2 = 0; s2 < 8; ++s2)
+      for (int to = 0; to < 4; ++to)
+        for (int q = 0; q < 4; ++q)
+          for (int i = 0; i < 16; ++i) wv1[((size_t)s2 * 4 + to) * 64 + 16 * q + i] = vd1k[(size_t)(4 * s2 + q) * 64 + 16 * to + i];
+    memset(&P, 0, sizeof P);
+    P.wtrunk = upload(trunk, s);
+    P.epi = upload(epi, s);
+    P.whead = upload(whead, s);
+    P.head_epi = upload(hepi, s);
+    P.wpol = upload(wpol, s);
+    P.bpol = upload(bpol, s);
+    P.wv1 = upload(wv1, s);
+    P.bv1 = upload(bv1, s);
+    P.wv2 = upload(wv2, s);
+    P.bv2 = upload(bv2, s);
+    rt_sync(s);
+  }
+  ~ResCnnNet() override {
+    for (float *d : bufs) rt_free(d);
+  }
+  size_t max_rows() const override { return cap; }
+  int kind() const override { return CO_NET_RESCNN4; }
+  double flop_per_row() const override {
+    return 2.0 * 16 * 9 * (10 * 64 + 8 * 64 * 64) + 2.0 * 16 * 64 * 6 + 2.0 * 64 * 96 + 2.0 * 32 * 64 + 2.0 * 64;
+  }
+  void forward(const float *d_in, int32_t rows_cap, const int32_t *d_rows, float *d_eval, float *d_probs,
+               rt_stream_t s) override {
+    int grid = (rows_cap + RC_POS_PER_WG - 1) / RC_POS_PER_WG;
+    if (grid < 1) return;
+    RcParams p = P;
+    p.in = d_in;
+    p.d_rows = d_rows;
+    p.eval = d_eval;
+    p.probs = d_probs;
+    hipLaunchKernelGGL(co_k_rescnn_forward, dim3(grid), dim3(256), 0, s, p);
+    RT_CHECK(hipGetLastError());
+  }
+};
+
+CoNet *co_rescnn_create(const float *weights, size_t n_floats, size_t max_rows, rt_stream_t s) {
+  if (n_floats != (size_t)RC_NUM_WEIGHTS) return nullptr;
+  return new ResCnnNet(weights, max_rows, s);
+}

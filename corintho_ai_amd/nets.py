@@ -82,3 +82,132 @@ def mlp12x100_forward_np(weights, states):
     lg = lg - lg.max(axis=1, keepdims=True)
     e = np.exp(lg).astype(np.float32)
     return v, (e / e.sum(axis=1, keepdims=True)).astype(np.float32)
+
+
+# --------------------------------------------------------------------------- rescnn4
+# The north-star network (BASELINE.json north_star; it has no counterpart in the
+# reference, whose network is the MLP above -- SURVEY "two facts").  Specification:
+#   input   the 70-float state as a 4x4 image with 10 channels, NHWC, pixel p = row*4+col:
+#           channels 0..3 = the four board bits of the cell (state[p*4 + k]),
+#           channels 4..9 = the six reserve counters state[64..69], broadcast over the board
+#   stem    Conv3x3(10 -> 64, pad 1) + bias -> BatchNorm -> ReLU
+#   4 x     residual block: Conv3x3(64->64)+bias -> BN -> ReLU -> Conv3x3(64->64)+bias -> BN
+#           -> add block input -> ReLU
+#   policy  Conv1x1(64 -> 4)+bias -> BN -> ReLU -> flatten (pixel*4 + ch) -> Dense(64 -> 96) -> softmax
+#   value   Conv1x1(64 -> 2)+bias -> BN -> ReLU -> flatten (pixel*2 + ch) -> Dense(32 -> 64) -> ReLU
+#           -> Dense(64 -> 1) -> tanh
+# BatchNorm is the inference affine with epsilon 1e-3.  Flat float32 layout, in order:
+#   stem: kernel[3,3,10,64] (HWIO), bias[64], gamma, beta, mean, var [64 each]
+#   blocks b = 0..3: conv1 (kernel[3,3,64,64], bias, gamma, beta, mean, var), conv2 (same)
+#   policy: kernel[64,4], bias[4], gamma, beta, mean, var [4 each], dense kernel[64,96], bias[96]
+#   value:  kernel[64,2], bias[2], gamma, beta, mean, var [2 each], dense1 kernel[32,64], bias[64],
+#           dense2 kernel[64,1], bias[1]
+RES_C = 64
+RES_BLOCKS = 4
+RES_CIN = 10
+
+
+def _rescnn4_shapes():
+    sh = [("stem_k", (3, 3, RES_CIN, RES_C)), ("stem_b", (RES_C,))] + [("stem_bn%d" % i, (RES_C,)) for i in range(4)]
+    for b in range(RES_BLOCKS):
+        for c in (1, 2):
+            sh += [("b%d_c%d_k" % (b, c), (3, 3, RES_C, RES_C)), ("b%d_c%d_b" % (b, c), (RES_C,))]
+            sh += [("b%d_c%d_bn%d" % (b, c, i), (RES_C,)) for i in range(4)]
+    sh += [("p_k", (RES_C, 4)), ("p_b", (4,))] + [("p_bn%d" % i, (4,)) for i in range(4)]
+    sh += [("p_dk", (64, NUM_MOVES)), ("p_db", (NUM_MOVES,))]
+    sh += [("v_k", (RES_C, 2)), ("v_b", (2,))] + [("v_bn%d" % i, (2,)) for i in range(4)]
+    sh += [("v_d1k", (32, 64)), ("v_d1b", (64,)), ("v_d2k", (64, 1)), ("v_d2b", (1,))]
+    return sh
+
+
+RESCNN4_NUM_WEIGHTS = sum(int(np.prod(s)) for _, s in _rescnn4_shapes())
+
+
+def rescnn4_flop_per_row():
+    conv = 2 * 16 * 9 * (RES_CIN * RES_C + 2 * RES_BLOCKS * RES_C * RES_C)
+    heads = 2 * 16 * RES_C * 6 + 2 * 64 * NUM_MOVES + 2 * 32 * 64 + 2 * 64
+    return float(conv + heads)
+
+
+def init_rescnn4(seed=0, bn_noise=False):
+    rng = np.random.default_rng(seed)
+    parts = []
+    for name, shape in _rescnn4_shapes():
+        if name.endswith("_k") or name.endswith("k") and not name.endswith("_b"):
+            if len(shape) == 4:
+                fan_in, fan_out = shape[0] * shape[1] * shape[2], shape[0] * shape[1] * shape[3]
+            else:
+                fan_in, fan_out = shape
+            parts.append(_glorot(rng, fan_in, fan_out, shape).ravel())
+        elif "_bn" in name:
+            i = int(name[-1])
+            if bn_noise:
+                v = [rng.uniform(0.5, 1.5, shape), rng.normal(0, 0.1, shape), rng.normal(0, 0.2, shape),
+                     rng.uniform(0.5, 2.0, shape)][i]
+            else:
+                v = [np.ones(shape), np.zeros(shape), np.zeros(shape), np.ones(shape)][i]
+            parts.append(np.asarray(v, np.float32).ravel())
+        else:  # biases
+            parts.append((rng.normal(0, 0.1, shape) if bn_noise else np.zeros(shape)).astype(np.float32).ravel())
+    w = np.concatenate(parts).astype(np.float32)
+    assert w.size == RESCNN4_NUM_WEIGHTS
+    return w
+
+
+def rescnn4_unpack(weights):
+    w = np.asarray(weights, np.float32)
+    out, p = {}, 0
+    for name, shape in _rescnn4_shapes():
+        n = int(np.prod(shape))
+        out[name] = w[p:p + n].reshape(shape)
+        p += n
+    assert p == w.size
+    return out
+
+
+def rescnn4_input_planes(states):
+    """[n,70] -> NHWC [n,4,4,10]"""
+    s = np.asarray(states, np.float32)[:, :GAME_STATE_SIZE]
+    n = s.shape[0]
+    x = np.zeros((n, 16, RES_CIN), np.float32)
+    x[:, :, :4] = s[:, :64].reshape(n, 16, 4)
+    x[:, :, 4:] = s[:, None, 64:70]
+    return x.reshape(n, 4, 4, RES_CIN)
+
+
+def rescnn4_forward_ref(weights, states):
+    """float32 restatement with torch CPU convolutions (test infrastructure)."""
+    import torch
+    import torch.nn.functional as F
+
+    W = rescnn4_unpack(weights)
+    x = torch.from_numpy(rescnn4_input_planes(states)).permute(0, 3, 1, 2).contiguous()  # NCHW
+
+    def bn(t, prefix):
+        ga, be, mu, va = (torch.from_numpy(W[prefix + "_bn%d" % i].astype(np.float64)) for i in range(4))
+        a = (ga / torch.sqrt(va + BN_EPS)).float()
+        c = (be - mu * a.double()).float()
+        return t * a.view(1, -1, 1, 1) + c.view(1, -1, 1, 1)
+
+    def conv(t, prefix, pad):
+        k = torch.from_numpy(W[prefix + "_k"])
+        if k.dim() == 2:
+            k = k.view(1, 1, *k.shape)
+        k = k.permute(3, 2, 0, 1).contiguous()  # HWIO -> OIHW
+        return F.conv2d(t, k, torch.from_numpy(W[prefix + "_b"]), padding=pad)
+
+    with torch.no_grad():
+        x = torch.relu(bn(conv(x, "stem", 1), "stem"))
+        for b in range(RES_BLOCKS):
+            y = torch.relu(bn(conv(x, "b%d_c1" % b, 1), "b%d_c1" % b))
+            y = bn(conv(y, "b%d_c2" % b, 1), "b%d_c2" % b)
+            x = torch.relu(x + y)
+        p = torch.relu(bn(conv(x, "p", 0), "p"))            # [n,4,4,4] NCHW
+        p = p.permute(0, 2, 3, 1).reshape(p.shape[0], 64)    # pixel*4 + ch
+        logits = p @ torch.from_numpy(W["p_dk"]) + torch.from_numpy(W["p_db"])
+        probs = torch.softmax(logits, dim=1)
+        v = torch.relu(bn(conv(x, "v", 0), "v"))
+        v = v.permute(0, 2, 3, 1).reshape(v.shape[0], 32)    # pixel*2 + ch
+        v = torch.relu(v @ torch.from_numpy(W["v_d1k"]) + torch.from_numpy(W["v_d1b"]))
+        v = torch.tanh(v @ torch.from_numpy(W["v_d2k"]) + torch.from_numpy(W["v_d2b"]))[:, 0]
+    return v.numpy().astype(np.float32), probs.numpy().astype(np.float32)

@@ -330,3 +330,44 @@ def test_mlp_matches_float32_restatement(engine):
         # a row's result must not depend on its batch (SURVEY 8e invariant)
         ev1, pr1 = t.net_forward(states[5:6])
         assert ev1[0] == ev[5] and np.array_equal(pr1[0], pr[5])
+
+
+@pytest.mark.gpu
+def test_rescnn4_matches_float32_restatement():
+    """north-star network: policy/value within 1e-4 (fp32) of the torch-CPU restatement
+    of the specification in corintho_ai_amd/nets.py; rows independent of their batch"""
+    from corintho_ai_amd import NET_RESCNN4
+
+    t = make_trainer("hip", 64, "", 1, 50, 16, 1.0, 0.25, 0, 1, False)
+    rng = np.random.default_rng(11)
+    n = 203
+    states = np.zeros((n, 70), np.float32)
+    states[:, :64] = rng.integers(0, 2, (n, 64))
+    states[:, 64:] = rng.integers(0, 5, (n, 6)) * 0.25
+    for seed, noise in ((0, False), (3, True)):
+        w = nets.init_rescnn4(seed=seed, bn_noise=noise)
+        t.set_net(NET_RESCNN4, w)
+        ev, pr = t.net_forward(states)
+        ev0, pr0 = nets.rescnn4_forward_ref(w, states)
+        assert np.max(np.abs(ev - ev0)) < 1e-4, np.max(np.abs(ev - ev0))
+        assert np.max(np.abs(pr - pr0)) < 1e-4, np.max(np.abs(pr - pr0))
+        assert np.all(np.abs(pr.sum(axis=1) - 1) < 1e-5)
+        ev1, pr1 = t.net_forward(states[7:8])
+        assert ev1[0] == ev[7] and np.array_equal(pr1[0], pr[7])
+
+
+@pytest.mark.gpu
+def test_fused_rescnn4_generation_replays_on_the_oracle():
+    from corintho_ai_amd import NET_RESCNN4
+
+    G, S_, spe = 24, 40, 8
+    w = nets.init_rescnn4(seed=0, bn_noise=True)
+    f = make_trainer("hip", G, "", 31, S_, spe, 1.0, 0.25, 0, 1, False, stagger=False)
+    f.set_net(NET_RESCNN4, w)
+    assert f.run()
+    o = O.Trainer(G, seed=31, max_searches=S_, searches_per_eval=spe)
+    o.set_stagger(False)
+    H.play_generation(o, G, spe, lambda s: f.net_forward(s))
+    for x, y in zip(H.get_samples(f), H.get_samples(o)):
+        assert x.tobytes() == y.tobytes()
+    assert f.score() == o.score()
