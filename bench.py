@@ -43,10 +43,12 @@ def parse():
     ap.add_argument("--spe", type=int, default=16)
     ap.add_argument("--c-puct", type=float, default=1.0)
     ap.add_argument("--epsilon", type=float, default=0.25)
-    ap.add_argument("--net", default="mlp12x100", choices=["mlp12x100", "rescnn4"])
+    ap.add_argument("--net", default="rescnn4", choices=["mlp12x100", "rescnn4"],
+                    help="rescnn4 = the 4-block residual CNN BASELINE.json configs[1] names; mlp12x100 = the reference's own net")
+    ap.add_argument("--no-mlp-extra", action="store_true", help="skip the extra mlp12x100 generation reported under detail")
     ap.add_argument("--stagger", action="store_true", help="keep the reference's staggered start")
     ap.add_argument("--arena-units", type=int, default=0)
-    ap.add_argument("--cpu-games", type=int, default=96, help="games of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-games", type=int, default=64, help="games of the bounded CPU-baseline sample (0 = skip)")
     return ap.parse_args()
 
 
@@ -68,7 +70,7 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("CORINTHO_CPU_THREADS", "16"))))
 
 
-def cpu_baseline(args, weights):
+def cpu_baseline(args, weights, net_name="mlp12x100"):
     """The oracle (CPU restatement of the reference's OpenMP path) on this box's host
     cores, with the same network evaluated on the CPU between iterations as the
     reference's Keras loop does (main.pyx:70-83).  Bounded sample; rank 0, N = 1 only."""
@@ -88,9 +90,17 @@ def cpu_baseline(args, weights):
                   epsilon=args.epsilon, num_threads=cores)
     nn_time = [0.0]
 
+    if net_name == "rescnn4":
+        import torch
+
+        torch.set_num_threads(cores)
+        fwd = nets.rescnn4_forward_ref
+    else:
+        fwd = nets.mlp12x100_forward_np
+
     def net(states):
         t0 = time.perf_counter()
-        out = nets.mlp12x100_forward_np(weights, states)
+        out = fwd(weights, states)
         nn_time[0] += time.perf_counter() - t0
         return out
 
@@ -102,8 +112,9 @@ def cpu_baseline(args, weights):
         "unit": "games/s",
         "cores": cores,
         "kind": "port",
-        "sample": "%d games x %d sims/move, spe %d, oracle/ (OpenMP, %d threads) + numpy fp32 mlp12x100 on the host; "
-                  "%.1f s total, %.1f s of it network" % (G, args.sims, args.spe, cores, dt, nn_time[0]),
+        "sample": "%d games x %d sims/move, spe %d, oracle/ (OpenMP, %d threads) + fp32 %s on the host (%s); "
+                  "%.1f s total, %.1f s of it network" % (G, args.sims, args.spe, cores, net_name,
+                                                          "torch CPU" if net_name == "rescnn4" else "numpy", dt, nn_time[0]),
         "mcts_only_games_per_s": G / max(dt - nn_time[0], 1e-9),
     }
 
@@ -244,11 +255,24 @@ def main():
                 "peak_arena_units_per_tree": totals["peak_arena_units"],
             },
         }
-        if world == 1 and args.cpu_games > 0 and args.net == "mlp12x100":
-            out["cpu_baseline"] = cpu_baseline(args, weights)
-        elif world == 1 and args.cpu_games > 0:
-            out["cpu_baseline"] = cpu_baseline(args, nets.init_mlp12x100(0))
-            out["cpu_baseline"]["sample"] += " (reference architecture mlp12x100; the CNN has no reference CPU path)"
+        if world == 1 and args.net == "rescnn4" and not args.no_mlp_extra:
+            # the reference's own architecture on the same pool, one generation, for comparison
+            tr.set_net(NET_MLP12X100, nets.init_mlp12x100(0))
+            tr.reset(777)
+            tr.run()  # warm
+            tr.reset(778)
+            t1 = time.perf_counter()
+            tr.run()
+            d1 = time.perf_counter() - t1
+            st = tr.stats()
+            mf = 2.0 * (70 * 100 + 11 * 100 * 100 + 100 + 100 * 96)
+            out["detail"]["mlp12x100"] = {
+                "games_per_s": G / d1, "ms_per_step": d1 * 1e3,
+                "network_TFLOPs_algorithmic": st["nn_rows"] * mf / max(st["nn_ms"] * 1e-3, 1e-12) / 1e12,
+                "device_ms": {"mcts": st["mcts_ms"], "network": st["nn_ms"], "pack": st["pack_ms"]},
+            }
+        if world == 1 and args.cpu_games > 0:
+            out["cpu_baseline"] = cpu_baseline(args, weights, args.net)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
