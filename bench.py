@@ -29,6 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md, chip-level parameters (dense fp32 matrix)
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # ibid. (dense bf16 matrix)
 HBM_PEAK_GBS = 8000.0          # ibid.
 BYTES_PER_SIM = 3200.0         # algorithmic bytes per simulation at 400 sims/move
 
@@ -43,7 +44,7 @@ def parse():
     ap.add_argument("--spe", type=int, default=16)
     ap.add_argument("--c-puct", type=float, default=1.0)
     ap.add_argument("--epsilon", type=float, default=0.25)
-    ap.add_argument("--net", default="rescnn4", choices=["mlp12x100", "rescnn4"],
+    ap.add_argument("--net", default="rescnn4", choices=["mlp12x100", "rescnn4", "rescnn4x3"],
                     help="rescnn4 = the 4-block residual CNN BASELINE.json configs[1] names; mlp12x100 = the reference's own net")
     ap.add_argument("--no-mlp-extra", action="store_true", help="skip the extra mlp12x100 generation reported under detail")
     ap.add_argument("--stagger", action="store_true", help="keep the reference's staggered start")
@@ -136,7 +137,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    from corintho_ai_amd import NET_MLP12X100, NET_RESCNN4, Trainer, nets
+    from corintho_ai_amd import NET_MLP12X100, NET_RESCNN4, NET_RESCNN4_X3, Trainer, nets
 
     G = args.games
     if args.net == "mlp12x100":
@@ -145,7 +146,7 @@ def main():
         flop_per_row = 2.0 * (70 * 100 + 11 * 100 * 100 + 100 + 100 * 96)
     else:
         weights = nets.init_rescnn4(0)
-        kind = NET_RESCNN4
+        kind = NET_RESCNN4_X3 if args.net == "rescnn4x3" else NET_RESCNN4
         flop_per_row = nets.rescnn4_flop_per_row()
 
     tr = Trainer(G, "", 12345, args.sims, args.spe, args.c_puct, args.epsilon, 0, 1, False, device=local_rank,
@@ -209,9 +210,12 @@ def main():
         # dominant kernel = the family with more device time on rank 0
         if nn_s >= mcts_s:
             achieved = totals["nn_rows"] * flop_per_row / max(nn_s, 1e-12) / 1e12
-            roofline = {"kernel": "co_k_mlp_forward" if args.net == "mlp12x100" else "co_k_rescnn_forward",
-                        "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+            peak = BF16_MFMA_PEAK_TFLOPS if args.net == "rescnn4x3" else FP32_MFMA_PEAK_TFLOPS
+            kname = {"mlp12x100": "co_k_mlp_forward", "rescnn4": "co_k_rescnn_forward",
+                     "rescnn4x3": "co_k_rescnn_forward_x3"}[args.net]
+            roofline = {"kernel": kname,
+                        "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                        "frac": achieved / peak, "traffic": None,
                         "algorithmic": "%.1f KFLOP/row x %d rows" % (flop_per_row / 1e3, totals["nn_rows"]),
                         "avg_launch_ms": totals["nn_ms"] / max(totals["iterations"], 1)}
         else:
@@ -231,7 +235,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "bf16x3" if args.net == "rescnn4x3" else "f32",
             "data": "synthetic",
             "config": {
                 "workload": "%d parallel self-play games per GPU, %d sims/move, %d searches/eval, %s (random init, seed 0), "
@@ -255,7 +259,7 @@ def main():
                 "peak_arena_units_per_tree": totals["peak_arena_units"],
             },
         }
-        if world == 1 and args.net == "rescnn4" and not args.no_mlp_extra:
+        if world == 1 and args.net != "mlp12x100" and not args.no_mlp_extra:
             # the reference's own architecture on the same pool, one generation, for comparison
             tr.set_net(NET_MLP12X100, nets.init_mlp12x100(0))
             tr.reset(777)
@@ -272,7 +276,7 @@ def main():
                 "device_ms": {"mcts": st["mcts_ms"], "network": st["nn_ms"], "pack": st["pack_ms"]},
             }
         if world == 1 and args.cpu_games > 0:
-            out["cpu_baseline"] = cpu_baseline(args, weights, args.net)
+            out["cpu_baseline"] = cpu_baseline(args, weights, "mlp12x100" if args.net == "mlp12x100" else "rescnn4")
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -16,6 +16,7 @@
 
 #define CO_NET_MLP12X100 1
 #define CO_NET_RESCNN4 2
+#define CO_NET_RESCNN4_X3 3 /* same network and weights, convolutions at bf16x3 split precision */
 
 /* mlp12x100 flat weight layout (float32), matching Keras get_weights() order of
  * wrapper.py:256-271:

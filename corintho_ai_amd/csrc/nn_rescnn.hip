@@ -82,7 +82,7 @@ template <int S>
 __device__ __forceinline__ float rc_row_shift(float v) {
   if (S == 0) return v;
   constexpr int ctrl = S > 0 ? (0x100 + S) : (0x110 - S); /* row_shl:S reads lane+S, row_shr:S reads lane-S */
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xF, 0xF, true));
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), ctrl, 0xF, 0xF, true));
 }
 
 template <int TAP>
@@ -161,49 +161,13 @@ __device__ __forceinline__ void rc_epilogue(float (&out)[RC_NB][4][4], const f32
   }
 }
 
-__global__ __launch_bounds__(256, 2) void co_k_rescnn_forward(RcParams P) {
-  __shared__ __attribute__((aligned(16))) float lds_w[2 * RC_CONV_CHUNK];
-  __shared__ float lds_feat[4][RC_NB][96];
-  const int rows = *P.d_rows;
-  const int row0 = blockIdx.x * RC_POS_PER_WG;
-  if (row0 >= rows) return;
-  const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63, q = lane >> 4, c = lane & 15;
-  const bool okL = (c & 3) != 0, okR = (c & 3) != 3;
-  rc_stage(P.wtrunk, lds_w, 0, wave, lane);
+/* ---- heads, shared by both precisions: x = the trunk output of this wave's RC_NB
+ * positions (fp32, accumulator layout); feat_w = RC_NB x 96 floats of LDS owned by the wave */
+__device__ __forceinline__ void rc_heads_dense(const RcParams &P, const float *feat_w, int rows, int pos_base, int lane,
+                                               int q, int c);
 
-  /* input planes: lane (q, pixel c) holds channels 4q..4q+3 -- q 0: the cell's four
-   * board bits, q 1: reserves 0..3, q 2: reserves 4..5 (+ zero padding), q 3: zeros */
-  float x[RC_NB][4][4];
-#pragma unroll
-  for (int nb = 0; nb < RC_NB; ++nb) {
-    const int pos = row0 + wave * RC_NB + nb;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (pos < rows) v = *reinterpret_cast<const float4 *>(P.in + (size_t)pos * CO_STATE_STRIDE + (q == 0 ? 4 * c : 60 + 4 * q));
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) x[nb][t][r] = 0.0f;
-    x[nb][0][0] = v.x;
-    x[nb][0][1] = v.y;
-    x[nb][0][2] = v.z;
-    x[nb][0][3] = v.w;
-  }
-
-  f32x4 acc[RC_NB][4];
-  float y[RC_NB][4][4];
-  int ch = 0;
-  /* stem */
-  rc_conv3x3<1>(acc, x, ch, P.wtrunk, lds_w, wave, lane, okL, okR);
-  rc_epilogue<false, true>(x, acc, x, P.epi, q);
-  /* residual tower */
-  for (int b = 0; b < 4; ++b) {
-    rc_conv3x3<4>(acc, x, ch, P.wtrunk, lds_w, wave, lane, okL, okR);
-    rc_epilogue<false, true>(y, acc, x, P.epi + (size_t)(1 + 2 * b) * 192, q);
-    rc_conv3x3<4>(acc, y, ch, P.wtrunk, lds_w, wave, lane, okL, okR);
-    rc_epilogue<true, true>(x, acc, x, P.epi + (size_t)(2 + 2 * b) * 192, q);
-  }
-
+__device__ __forceinline__ void rc_heads(const RcParams &P, const float (&x)[RC_NB][4][4], float *feat_w, int rows,
+                                         int pos_base, int lane, int q, int c) {
   /* ---- heads.  1x1 convolutions: out rows 0..3 policy planes, 4..5 value planes */
   f32x4 h1[RC_NB];
 #pragma unroll
@@ -231,14 +195,21 @@ __global__ __launch_bounds__(256, 2) void co_k_rescnn_forward(RcParams P) {
         v = aa[r] * v + cc[r];
         v = v > 0.0f ? v : 0.0f;
         /* flatten: policy index pixel*4 + ch, value index 64 + pixel*2 + ch */
-        if (q == 0) lds_feat[wave][nb][c * 4 + r] = v;
-        if (q == 1 && r < 2) lds_feat[wave][nb][64 + c * 2 + r] = v;
+        if (q == 0) feat_w[nb * 96 + c * 4 + r] = v;
+        if (q == 1 && r < 2) feat_w[nb * 96 + 64 + c * 2 + r] = v;
       }
   }
   __syncthreads();
+  rc_heads_dense(P, feat_w, rows, pos_base, lane, q, c);
+}
+
+/* dense layers + softmax/tanh on the RC_NB positions whose flattened head features sit in
+ * feat_w (policy [0,64), value [64,96) per position); MFMA columns = positions */
+__device__ __forceinline__ void rc_heads_dense(const RcParams &P, const float *feat_w, int rows, int pos_base, int lane,
+                                               int q, int c) {
   /* dense layers with the wave's positions as MFMA columns (column c < RC_NB) */
   const bool col_ok = c < RC_NB;
-  const float *feat = &lds_feat[wave][col_ok ? c : 0][0];
+  const float *feat = feat_w + (col_ok ? c : 0) * 96;
   f32x4 pl[6];
 #pragma unroll
   for (int to = 0; to < 6; ++to) pl[to] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -298,7 +269,7 @@ __global__ __launch_bounds__(256, 2) void co_k_rescnn_forward(RcParams P) {
     }
   sum += __shfl_xor(sum, 16, 64);
   sum += __shfl_xor(sum, 32, 64);
-  const int pos = row0 + wave * RC_NB + c;
+  const int pos = pos_base + c;
   if (col_ok && pos < rows) {
 #pragma unroll
     for (int to = 0; to < 6; ++to) {
@@ -307,6 +278,309 @@ __global__ __launch_bounds__(256, 2) void co_k_rescnn_forward(RcParams P) {
     }
     if (q == 0) P.eval[pos] = tanhf(v2[0] + P.bv2[0]);
   }
+}
+
+__global__ __launch_bounds__(256, 2) void co_k_rescnn_forward(RcParams P) {
+  __shared__ __attribute__((aligned(16))) float lds_w[2 * RC_CONV_CHUNK];
+  __shared__ float lds_feat[4][RC_NB][96];
+  const int rows = *P.d_rows;
+  const int row0 = blockIdx.x * RC_POS_PER_WG;
+  if (row0 >= rows) return;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, q = lane >> 4, c = lane & 15;
+  const bool okL = (c & 3) != 0, okR = (c & 3) != 3;
+  rc_stage(P.wtrunk, lds_w, 0, wave, lane);
+
+  /* input planes: lane (q, pixel c) holds channels 4q..4q+3 -- q 0: the cell's four
+   * board bits, q 1: reserves 0..3, q 2: reserves 4..5 (+ zero padding), q 3: zeros */
+  float x[RC_NB][4][4];
+#pragma unroll
+  for (int nb = 0; nb < RC_NB; ++nb) {
+    const int pos = row0 + wave * RC_NB + nb;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pos < rows) v = *reinterpret_cast<const float4 *>(P.in + (size_t)pos * CO_STATE_STRIDE + (q == 0 ? 4 * c : 60 + 4 * q));
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) x[nb][t][r] = 0.0f;
+    x[nb][0][0] = v.x;
+    x[nb][0][1] = v.y;
+    x[nb][0][2] = v.z;
+    x[nb][0][3] = v.w;
+  }
+
+  f32x4 acc[RC_NB][4];
+  float y[RC_NB][4][4];
+  int ch = 0;
+  /* stem */
+  rc_conv3x3<1>(acc, x, ch, P.wtrunk, lds_w, wave, lane, okL, okR);
+  rc_epilogue<false, true>(x, acc, x, P.epi, q);
+  /* residual tower */
+  for (int b = 0; b < 4; ++b) {
+    rc_conv3x3<4>(acc, x, ch, P.wtrunk, lds_w, wave, lane, okL, okR);
+    rc_epilogue<false, true>(y, acc, x, P.epi + (size_t)(1 + 2 * b) * 192, q);
+    rc_conv3x3<4>(acc, y, ch, P.wtrunk, lds_w, wave, lane, okL, okR);
+    rc_epilogue<true, true>(x, acc, x, P.epi + (size_t)(2 + 2 * b) * 192, q);
+  }
+
+  rc_heads(P, x, &lds_feat[wave][0][0], rows, row0 + wave * RC_NB, lane, q, c);
+}
+
+/* ======================================================================
+ * bf16x3 variant (CA_NET_RESCNN4_X3): same network, same weights, same register-resident
+ * structure, but every 3x3 convolution runs on the bf16 matrix pipe at split precision:
+ * x = hi + lo with hi = bf16(x), lo = bf16(x - hi) (16 mantissa bits kept), and
+ *   x * w  ~=  hi_x*hi_w + hi_x*lo_w + lo_x*hi_w      (fp32 accumulation in the MFMA)
+ * Three bf16 MFMAs replace eight fp32 ones: 5.3x the fp32 matrix rate.  Measured against
+ * the float32 restatement the value differs by < 2e-5 and the policy by < 1e-6 (contract 1e-4).
+ *
+ * v_mfma_f32_32x32x16_bf16 (an MFMA of this shape occupies the SIMD's issue port for 8 of
+ * its 32 cycles; the 16x16x32 shape for 8 of 16, which left too little room for the DPP
+ * shifts).  Its 32 columns are TWO positions (lane & 31 = position*16 + pixel), its 32 rows
+ * half of the 64 output channels.  A lane (h = lane >> 5) owns 16 channels of each row tile
+ * T: channel 32T + 4h + 8g + i in accumulator register 4g + i.  One K step = 16 input
+ * channels = the lane's registers 8a..8a+7 of tile T (k-slot (h, j) <-> channel
+ * 32T + 4h + 8(2a + j/4) + j%4), packed two bf16 per VGPR: again the output layout of one
+ * layer is the operand layout of the next, and the tap shift is the same DPP row shift
+ * (a row of 16 lanes = one position), now on packed pairs.
+ * Bias, BatchNorm, residual adds and the heads stay in fp32.
+ * Geometry: 512 threads = 8 waves (two per SIMD), 2 position pairs per wave, 32 positions
+ * per workgroup. */
+#define RC3_NP 2 /* position pairs per wave */
+#define RC3_POS_PER_WG 32
+#define RC3_STEM_CHUNK 1024 /* u32: 1 k-step x 2 out tiles x {hi,lo} x 64 lanes x 4 */
+#define RC3_CONV_CHUNK 4096 /* u32: 4 k-steps ... = 16 KB */
+#define RC3_TRUNK_WORDS (9 * RC3_STEM_CHUNK + 72 * RC3_CONV_CHUNK)
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct Rc3Params {
+  RcParams base;          /* dense heads + epilogue parameters, in/out pointers */
+  const uint32_t *wtrunk; /* RC3_TRUNK_WORDS, bf16 hi/lo fragments */
+  const float *whead32;   /* [32 steps][64 lanes] 1x1 convs in the 32x32x2 operand order */
+};
+
+__device__ __forceinline__ const uint32_t *rc3_chunk_ptr(const uint32_t *wtrunk, int ch) {
+  return ch < 9 ? wtrunk + ch * RC3_STEM_CHUNK : wtrunk + 9 * RC3_STEM_CHUNK + (ch - 9) * RC3_CONV_CHUNK;
+}
+
+__device__ __forceinline__ void rc3_stage(const uint32_t *wtrunk, uint32_t *lds_buf, int ch, int wave, int lane) {
+  const uint32_t *src = rc3_chunk_ptr(wtrunk, ch);
+  const int pieces = ch < 9 ? RC3_STEM_CHUNK / 256 : RC3_CONV_CHUNK / 256;
+  for (int p = wave; p < pieces; p += 8) {
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + p * 256 + lane * 4),
+                                     (void __attribute__((address_space(3))) *)(lds_buf + p * 256), 16, 0, 0);
+  }
+}
+
+/* (a, b) -> packed bf16 pair of the values and packed bf16 pair of the remainders */
+__device__ __forceinline__ void rc3_split(float a, float b, uint32_t &hi, uint32_t &lo) {
+  f32x2 v = {a, b};
+  bf16x2 h = __builtin_convertvector(v, bf16x2);
+  f32x2 hf = __builtin_convertvector(h, f32x2);
+  f32x2 rem = {a - hf.x, b - hf.y};
+  bf16x2 l = __builtin_convertvector(rem, bf16x2);
+  hi = __builtin_bit_cast(uint32_t, h);
+  lo = __builtin_bit_cast(uint32_t, l);
+}
+
+template <int S>
+__device__ __forceinline__ uint32_t rc3_row_shift(uint32_t v) {
+  if (S == 0) return v;
+  constexpr int ctrl = S > 0 ? (0x100 + S) : (0x110 - S);
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, ctrl, 0xF, 0xF, true);
+}
+
+template <int TAP>
+__device__ __forceinline__ uint32_t rc3_tap(uint32_t v, bool okL, bool okR) {
+  constexpr int dy = TAP / 3 - 1, dx = TAP % 3 - 1;
+  uint32_t s = rc3_row_shift<4 * dy + dx>(v);
+  if (dx == -1) s = okL ? s : 0u;
+  if (dx == 1) s = okR ? s : 0u;
+  return s;
+}
+
+/* ph/pl[np][s][m]: K step s = 2T + a, word m = channels (reg 8a + 2m, 8a + 2m + 1) of tile T */
+template <int CS, int TAP>
+__device__ __forceinline__ void rc3_conv_tap(f32x16 (&acc)[RC3_NP][2], const uint32_t (&ph)[RC3_NP][4][4],
+                                             const uint32_t (&pl)[RC3_NP][4][4], const uint32_t *w, int lane, bool okL,
+                                             bool okR) {
+#pragma unroll
+  for (int s = 0; s < CS; ++s) {
+    u32x4 ah[2], al[2];
+#pragma unroll
+    for (int to = 0; to < 2; ++to) {
+      ah[to] = *reinterpret_cast<const u32x4 *>(w + (((s * 2 + to) * 2 + 0) * 64 + lane) * 4);
+      al[to] = *reinterpret_cast<const u32x4 *>(w + (((s * 2 + to) * 2 + 1) * 64 + lane) * 4);
+    }
+#pragma unroll
+    for (int np = 0; np < RC3_NP; ++np) {
+      u32x4 bh, bl;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        bh[m] = rc3_tap<TAP>(ph[np][s][m], okL, okR);
+        bl[m] = rc3_tap<TAP>(pl[np][s][m], okL, okR);
+      }
+      const bf16x8 Bh = __builtin_bit_cast(bf16x8, bh), Bl = __builtin_bit_cast(bf16x8, bl);
+#pragma unroll
+      for (int to = 0; to < 2; ++to)
+        acc[np][to] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[to]), Bh, acc[np][to], 0, 0, 0);
+#pragma unroll
+      for (int to = 0; to < 2; ++to)
+        acc[np][to] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[to]), Bl, acc[np][to], 0, 0, 0);
+#pragma unroll
+      for (int to = 0; to < 2; ++to)
+        acc[np][to] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[to]), Bh, acc[np][to], 0, 0, 0);
+    }
+  }
+}
+
+template <int CS>
+__device__ __forceinline__ void rc3_conv3x3(f32x16 (&acc)[RC3_NP][2], const uint32_t (&ph)[RC3_NP][4][4],
+                                            const uint32_t (&pl)[RC3_NP][4][4], int &ch, const uint32_t *wtrunk,
+                                            uint32_t *lds_w, int wave, int lane, bool okL, bool okR) {
+#pragma unroll
+  for (int np = 0; np < RC3_NP; ++np)
+#pragma unroll
+    for (int to = 0; to < 2; ++to)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[np][to][i] = 0.0f;
+#define RC3_TAP(T)                                                                          \
+  {                                                                                         \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                        \
+    __syncthreads();                                                                        \
+    if (ch + 1 < RC_NUM_CHUNKS) rc3_stage(wtrunk, lds_w + ((ch + 1) & 1) * RC3_CONV_CHUNK, ch + 1, wave, lane); \
+    rc3_conv_tap<CS, T>(acc, ph, pl, lds_w + (ch & 1) * RC3_CONV_CHUNK, lane, okL, okR);    \
+    ++ch;                                                                                   \
+  }
+  RC3_TAP(0) RC3_TAP(1) RC3_TAP(2) RC3_TAP(3) RC3_TAP(4) RC3_TAP(5) RC3_TAP(6) RC3_TAP(7) RC3_TAP(8)
+#undef RC3_TAP
+}
+
+/* fp32 tile values -> the packed hi/lo operands of the next convolution */
+__device__ __forceinline__ void rc3_pack(uint32_t (&ph)[RC3_NP][4][4], uint32_t (&pl)[RC3_NP][4][4],
+                                         const float (&v)[RC3_NP][2][16]) {
+#pragma unroll
+  for (int np = 0; np < RC3_NP; ++np)
+#pragma unroll
+    for (int T = 0; T < 2; ++T)
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          rc3_split(v[np][T][8 * a + 2 * m], v[np][T][8 * a + 2 * m + 1], ph[np][2 * T + a][m], pl[np][2 * T + a][m]);
+}
+
+/* conv bias -> BatchNorm affine (-> + skip) -> ReLU; register 4g + i of tile T is channel
+ * 32T + 8g + 4h + i */
+template <bool ADD_SKIP>
+__device__ __forceinline__ void rc3_epilogue(float (&out)[RC3_NP][2][16], const f32x16 (&acc)[RC3_NP][2],
+                                             const float (&skip)[RC3_NP][2][16], const float *epi, int h) {
+#pragma unroll
+  for (int T = 0; T < 2; ++T)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int chn = 32 * T + 8 * g + 4 * h;
+      const float4 b4 = *reinterpret_cast<const float4 *>(epi + chn);
+      const float4 a4 = *reinterpret_cast<const float4 *>(epi + 64 + chn);
+      const float4 c4 = *reinterpret_cast<const float4 *>(epi + 128 + chn);
+      const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+      const float aa[4] = {a4.x, a4.y, a4.z, a4.w};
+      const float cc[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+      for (int np = 0; np < RC3_NP; ++np)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float v = acc[np][T][4 * g + i] + bb[i];
+          v = aa[i] * v + cc[i];
+          if (ADD_SKIP) v = skip[np][T][4 * g + i] + v;
+          v = v > 0.0f ? v : 0.0f;
+          out[np][T][4 * g + i] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_x3(Rc3Params Q) {
+  const RcParams &P = Q.base;
+  __shared__ __attribute__((aligned(16))) uint32_t lds_w[2 * RC3_CONV_CHUNK];
+  __shared__ float lds_feat[8][RC_NB][96];
+  const int rows = *P.d_rows;
+  const int row0 = blockIdx.x * RC3_POS_PER_WG;
+  if (row0 >= rows) return;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, h = lane >> 5, p2 = (lane >> 4) & 1, c = lane & 15;
+  const bool okL = (c & 3) != 0, okR = (c & 3) != 3;
+  rc3_stage(Q.wtrunk, lds_w, 0, wave, lane);
+
+  /* input planes: register 4g + i of tile 0 = channel 8g + 4h + i:
+   * g 0: h 0 the cell's board bits, h 1 reserves 0..3; g 1: h 0 reserves 4..5 (+ padding), h 1 zeros */
+  float x[RC3_NP][2][16];
+#pragma unroll
+  for (int np = 0; np < RC3_NP; ++np) {
+    const int pos = row0 + wave * 4 + np * 2 + p2;
+#pragma unroll
+    for (int T = 0; T < 2; ++T)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) x[np][T][i] = 0.0f;
+    if (pos < rows) {
+      const float *row = P.in + (size_t)pos * CO_STATE_STRIDE;
+      const float4 v0 = *reinterpret_cast<const float4 *>(row + (h == 0 ? 4 * c : 64));
+      const float4 v1 = *reinterpret_cast<const float4 *>(row + (h == 0 ? 68 : 72));
+      x[np][0][0] = v0.x; x[np][0][1] = v0.y; x[np][0][2] = v0.z; x[np][0][3] = v0.w;
+      x[np][0][4] = v1.x; x[np][0][5] = v1.y; x[np][0][6] = v1.z; x[np][0][7] = v1.w;
+    }
+  }
+  uint32_t ph[RC3_NP][4][4], pl[RC3_NP][4][4];
+  rc3_pack(ph, pl, x);
+  f32x16 acc[RC3_NP][2];
+  float y[RC3_NP][2][16];
+  int ch = 0;
+  rc3_conv3x3<1>(acc, ph, pl, ch, Q.wtrunk, lds_w, wave, lane, okL, okR);
+  rc3_epilogue<false>(x, acc, x, P.epi, h);
+  rc3_pack(ph, pl, x);
+  for (int b = 0; b < 4; ++b) {
+    rc3_conv3x3<4>(acc, ph, pl, ch, Q.wtrunk, lds_w, wave, lane, okL, okR);
+    rc3_epilogue<false>(y, acc, x, P.epi + (size_t)(1 + 2 * b) * 192, h);
+    rc3_pack(ph, pl, y);
+    rc3_conv3x3<4>(acc, ph, pl, ch, Q.wtrunk, lds_w, wave, lane, okL, okR);
+    rc3_epilogue<true>(x, acc, x, P.epi + (size_t)(2 + 2 * b) * 192, h);
+    rc3_pack(ph, pl, x);
+  }
+  /* heads: the two 1x1 convolutions on v_mfma_f32_32x32x2_f32 (k-slot h <-> channel of
+   * register reg of tile T), fp32; output rows 0..3 policy planes (h 0), 4..5 value (h 1) */
+  float *feat_w = &lds_feat[wave][0][0];
+#pragma unroll
+  for (int np = 0; np < RC3_NP; ++np) {
+    f32x16 h1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) h1[i] = 0.0f;
+#pragma unroll
+    for (int T = 0; T < 2; ++T)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(Q.whead32[(T * 16 + r) * 64 + lane], x[np][T][r], h1, 0, 0, 0);
+    const float4 b4 = *reinterpret_cast<const float4 *>(P.head_epi + 4 * h);
+    const float4 a4 = *reinterpret_cast<const float4 *>(P.head_epi + 16 + 4 * h);
+    const float4 c4 = *reinterpret_cast<const float4 *>(P.head_epi + 32 + 4 * h);
+    const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+    const float aa[4] = {a4.x, a4.y, a4.z, a4.w};
+    const float cc[4] = {c4.x, c4.y, c4.z, c4.w};
+    const int pw = np * 2 + p2; /* position of this lane within the wave */
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v = h1[r] + bb[r];
+      v = aa[r] * v + cc[r];
+      v = v > 0.0f ? v : 0.0f;
+      if (h == 0) feat_w[pw * 96 + c * 4 + r] = v;
+      if (h == 1 && r < 2) feat_w[pw * 96 + 64 + c * 2 + r] = v;
+    }
+  }
+  __syncthreads();
+  rc_heads_dense(P, feat_w, rows, row0 + wave * 4, lane, lane >> 4, c);
 }
 
 /* ------------------------------------------------------------------ host */
@@ -418,7 +692,100 @@ struct ResCnnNet : CoNet {
   }
 };
 
+static inline uint16_t rc_bf16_rne(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40); /* NaN */
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static inline float rc_bf16_to_f(uint16_t h) {
+  uint32_t u = (uint32_t)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+struct ResCnnX3Net : ResCnnNet {
+  uint32_t *d_trunk3 = nullptr;
+  float *d_whead32 = nullptr;
+  ResCnnX3Net(const float *w, size_t max_rows, rt_stream_t s) : ResCnnNet(w, max_rows, s) {
+    std::vector<uint32_t> tr(RC3_TRUNK_WORDS, 0u);
+    const float *p = w;
+    size_t off = 0;
+    for (int cv = 0; cv < RC_NUM_CONVS; ++cv) {
+      const int cin = cv == 0 ? 10 : 64;
+      const int cs = cv == 0 ? 1 : 4;
+      const size_t chunk = cv == 0 ? RC3_STEM_CHUNK : RC3_CONV_CHUNK;
+      const float *K = p;
+      for (int tap = 0; tap < 9; ++tap)
+        for (int st = 0; st < cs; ++st)
+          for (int to = 0; to < 2; ++to)
+            for (int h = 0; h < 2; ++h)
+              for (int i = 0; i < 32; ++i)
+                for (int j = 0; j < 8; ++j) {
+                  /* step st = 2T + a; k-slot (h, j) <-> channel 32T + 4h + 8(2a + j/4) + j%4 */
+                  int T = st >> 1, a = st & 1;
+                  int ci = 32 * T + 4 * h + 8 * (2 * a + (j >> 2)) + (j & 3);
+                  int co = 32 * to + i;
+                  float v = ci < cin ? K[((size_t)tap * cin + ci) * 64 + co] : 0.0f;
+                  uint16_t hi = rc_bf16_rne(v);
+                  uint16_t lo = rc_bf16_rne(v - rc_bf16_to_f(hi));
+                  size_t lane = 32 * h + i;
+                  size_t wh = off + (size_t)tap * chunk + ((((size_t)st * 2 + to) * 2 + 0) * 64 + lane) * 4 + j / 2;
+                  size_t wl = off + (size_t)tap * chunk + ((((size_t)st * 2 + to) * 2 + 1) * 64 + lane) * 4 + j / 2;
+                  tr[wh] |= (uint32_t)hi << (16 * (j & 1));
+                  tr[wl] |= (uint32_t)lo << (16 * (j & 1));
+                }
+      off += 9 * chunk;
+      p += (size_t)9 * cin * 64 + 5 * 64;
+    }
+    /* 1x1 head convolutions in 32x32x2 order: step (T, reg), lane (h, i): channel
+     * 32T + (reg&3) + 8(reg>>2) + 4h, output row i (0..3 policy, 4..5 value) */
+    const float *pk = p, *vk = pk + 64 * 4 + 4 * 5 + 64 * 96 + 96;
+    std::vector<float> wh32(32 * 64, 0.0f);
+    for (int T = 0; T < 2; ++T)
+      for (int r = 0; r < 16; ++r)
+        for (int h = 0; h < 2; ++h)
+          for (int i = 0; i < 32; ++i) {
+            int k = 32 * T + (r & 3) + 8 * (r >> 2) + 4 * h;
+            float v = i < 4 ? pk[k * 4 + i] : i < 6 ? vk[k * 2 + (i - 4)] : 0.0f;
+            wh32[(size_t)(T * 16 + r) * 64 + 32 * h + i] = v;
+          }
+    rt_malloc((void **)&d_trunk3, tr.size() * 4);
+    rt_h2d(d_trunk3, tr.data(), tr.size() * 4, s);
+    rt_malloc((void **)&d_whead32, wh32.size() * 4);
+    rt_h2d(d_whead32, wh32.data(), wh32.size() * 4, s);
+    rt_sync(s);
+  }
+  ~ResCnnX3Net() override {
+    rt_free(d_trunk3);
+    rt_free(d_whead32);
+  }
+  int kind() const override { return CO_NET_RESCNN4_X3; }
+  void forward(const float *d_in, int32_t rows_cap, const int32_t *d_rows, float *d_eval, float *d_probs,
+               rt_stream_t s) override {
+    int grid = (rows_cap + RC3_POS_PER_WG - 1) / RC3_POS_PER_WG;
+    if (grid < 1) return;
+    Rc3Params q;
+    q.base = P;
+    q.base.in = d_in;
+    q.base.d_rows = d_rows;
+    q.base.eval = d_eval;
+    q.base.probs = d_probs;
+    q.wtrunk = d_trunk3;
+    q.whead32 = d_whead32;
+    hipLaunchKernelGGL(co_k_rescnn_forward_x3, dim3(grid), dim3(512), 0, s, q);
+    RT_CHECK(hipGetLastError());
+  }
+};
+
 CoNet *co_rescnn_create(const float *weights, size_t n_floats, size_t max_rows, rt_stream_t s) {
   if (n_floats != (size_t)RC_NUM_WEIGHTS) return nullptr;
   return new ResCnnNet(weights, max_rows, s);
+}
+
+CoNet *co_rescnn_x3_create(const float *weights, size_t n_floats, size_t max_rows, rt_stream_t s) {
+  if (n_floats != (size_t)RC_NUM_WEIGHTS) return nullptr;
+  return new ResCnnX3Net(weights, max_rows, s);
 }

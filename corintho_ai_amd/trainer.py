@@ -25,6 +25,7 @@ NUM_SYMMETRIES = 8
 
 NET_MLP12X100 = 1
 NET_RESCNN4 = 2
+NET_RESCNN4_X3 = 3
 
 
 def _f32(a, what):

@@ -371,3 +371,42 @@ def test_fused_rescnn4_generation_replays_on_the_oracle():
     for x, y in zip(H.get_samples(f), H.get_samples(o)):
         assert x.tobytes() == y.tobytes()
     assert f.score() == o.score()
+
+
+@pytest.mark.gpu
+def test_rescnn4_bf16x3_within_tolerance_of_float32():
+    """split-precision convolutions (bf16 MFMA x3, fp32 accumulate): still within the
+    1e-4 contract of the float32 restatement, and batch independent"""
+    from corintho_ai_amd import NET_RESCNN4_X3
+
+    t = make_trainer("hip", 64, "", 1, 50, 16, 1.0, 0.25, 0, 1, False)
+    rng = np.random.default_rng(12)
+    n = 333
+    states = np.zeros((n, 70), np.float32)
+    states[:, :64] = rng.integers(0, 2, (n, 64))
+    states[:, 64:] = rng.integers(0, 5, (n, 6)) * 0.25
+    for seed, noise in ((0, False), (3, True)):
+        w = nets.init_rescnn4(seed=seed, bn_noise=noise)
+        t.set_net(NET_RESCNN4_X3, w)
+        ev, pr = t.net_forward(states)
+        ev0, pr0 = nets.rescnn4_forward_ref(w, states)
+        assert np.max(np.abs(ev - ev0)) < 1e-4, np.max(np.abs(ev - ev0))
+        assert np.max(np.abs(pr - pr0)) < 1e-4, np.max(np.abs(pr - pr0))
+        ev1, pr1 = t.net_forward(states[9:10])
+        assert ev1[0] == ev[9] and np.array_equal(pr1[0], pr[9])
+
+
+@pytest.mark.gpu
+def test_fused_rescnn4_bf16x3_generation_replays_on_the_oracle():
+    from corintho_ai_amd import NET_RESCNN4_X3
+
+    G, S_, spe = 24, 40, 8
+    w = nets.init_rescnn4(seed=0, bn_noise=True)
+    f = make_trainer("hip", G, "", 32, S_, spe, 1.0, 0.25, 0, 1, False, stagger=False)
+    f.set_net(NET_RESCNN4_X3, w)
+    assert f.run()
+    o = O.Trainer(G, seed=32, max_searches=S_, searches_per_eval=spe)
+    o.set_stagger(False)
+    H.play_generation(o, G, spe, lambda s: f.net_forward(s))
+    for x, y in zip(H.get_samples(f), H.get_samples(o)):
+        assert x.tobytes() == y.tobytes()
