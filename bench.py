@@ -44,9 +44,11 @@ def parse():
     ap.add_argument("--spe", type=int, default=16)
     ap.add_argument("--c-puct", type=float, default=1.0)
     ap.add_argument("--epsilon", type=float, default=0.25)
-    ap.add_argument("--net", default="rescnn4", choices=["mlp12x100", "rescnn4", "rescnn4x3"],
-                    help="rescnn4 = the 4-block residual CNN BASELINE.json configs[1] names; mlp12x100 = the reference's own net")
-    ap.add_argument("--no-mlp-extra", action="store_true", help="skip the extra mlp12x100 generation reported under detail")
+    ap.add_argument("--net", default="rescnn4x3", choices=["mlp12x100", "rescnn4", "rescnn4x3"],
+                    help="rescnn4x3 (default) = the 4-block residual CNN BASELINE.json configs[1] names, convolutions at "
+                         "bf16x3 split precision (within 2e-5 of fp32); rescnn4 = the same network on fp32 MFMA; "
+                         "mlp12x100 = the reference's own net")
+    ap.add_argument("--no-mlp-extra", action="store_true", help="skip the extra generations (other networks) reported under detail.variants")
     ap.add_argument("--stagger", action="store_true", help="keep the reference's staggered start")
     ap.add_argument("--arena-units", type=int, default=0)
     ap.add_argument("--cpu-games", type=int, default=64, help="games of the bounded CPU-baseline sample (0 = skip)")
@@ -259,22 +261,30 @@ def main():
                 "peak_arena_units_per_tree": totals["peak_arena_units"],
             },
         }
-        if world == 1 and args.net != "mlp12x100" and not args.no_mlp_extra:
-            # the reference's own architecture on the same pool, one generation, for comparison
-            tr.set_net(NET_MLP12X100, nets.init_mlp12x100(0))
-            tr.reset(777)
-            tr.run()  # warm
-            tr.reset(778)
-            t1 = time.perf_counter()
-            tr.run()
-            d1 = time.perf_counter() - t1
-            st = tr.stats()
-            mf = 2.0 * (70 * 100 + 11 * 100 * 100 + 100 + 100 * 96)
-            out["detail"]["mlp12x100"] = {
-                "games_per_s": G / d1, "ms_per_step": d1 * 1e3,
-                "network_TFLOPs_algorithmic": st["nn_rows"] * mf / max(st["nn_ms"] * 1e-3, 1e-12) / 1e12,
-                "device_ms": {"mcts": st["mcts_ms"], "network": st["nn_ms"], "pack": st["pack_ms"]},
-            }
+        if world == 1 and not args.no_mlp_extra:
+            # the other networks on the same pool, one timed generation each, for comparison
+            variants = {}
+            for name, vkind, vw, vflop, vpeak in (
+                ("rescnn4_fp32", NET_RESCNN4, None, nets.rescnn4_flop_per_row(), FP32_MFMA_PEAK_TFLOPS),
+                ("rescnn4_bf16x3", NET_RESCNN4_X3, None, nets.rescnn4_flop_per_row(), BF16_MFMA_PEAK_TFLOPS),
+                ("mlp12x100_fp32", NET_MLP12X100, "mlp", 2.0 * (70 * 100 + 11 * 100 * 100 + 100 + 100 * 96),
+                 FP32_MFMA_PEAK_TFLOPS),
+            ):
+                if vkind == kind:
+                    continue
+                tr.set_net(vkind, nets.init_mlp12x100(0) if vw == "mlp" else nets.init_rescnn4(0))
+                tr.reset(777)
+                tr.run()  # warm
+                tr.reset(778)
+                t1 = time.perf_counter()
+                tr.run()
+                d1 = time.perf_counter() - t1
+                st = tr.stats()
+                tf = st["nn_rows"] * vflop / max(st["nn_ms"] * 1e-3, 1e-12) / 1e12
+                variants[name] = {"games_per_s": G / d1, "ms_per_step": d1 * 1e3, "network_TFLOPs_algorithmic": tf,
+                                  "network_frac_of_mfma_peak": tf / vpeak,
+                                  "device_ms": {"mcts": st["mcts_ms"], "network": st["nn_ms"], "pack": st["pack_ms"]}}
+            out["detail"]["variants"] = variants
         if world == 1 and args.cpu_games > 0:
             out["cpu_baseline"] = cpu_baseline(args, weights, "mlp12x100" if args.net == "mlp12x100" else "rescnn4")
         print(json.dumps(out))

@@ -351,6 +351,7 @@ __global__ __launch_bounds__(256, 2) void co_k_rescnn_forward(RcParams P) {
 #define RC3_STEM_CHUNK 1024 /* u32: 1 k-step x 2 out tiles x {hi,lo} x 64 lanes x 4 */
 #define RC3_CONV_CHUNK 4096 /* u32: 4 k-steps ... = 16 KB */
 #define RC3_TRUNK_WORDS (9 * RC3_STEM_CHUNK + 72 * RC3_CONV_CHUNK)
+#define RC3_LDS_BYTES (2 * 3 * RC3_CONV_CHUNK * 4 + 8 * RC_NB * 96 * 4)
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -364,13 +365,17 @@ struct Rc3Params {
   const float *whead32;   /* [32 steps][64 lanes] 1x1 convs in the 32x32x2 operand order */
 };
 
-__device__ __forceinline__ const uint32_t *rc3_chunk_ptr(const uint32_t *wtrunk, int ch) {
-  return ch < 9 ? wtrunk + ch * RC3_STEM_CHUNK : wtrunk + 9 * RC3_STEM_CHUNK + (ch - 9) * RC3_CONV_CHUNK;
+/* weights stream through LDS in groups of three taps (one kernel row): 27 groups, group
+ * gi < 3 belongs to the stem */
+#define RC3_NUM_GROUPS 27
+#define RC3_GROUP_WORDS (3 * RC3_CONV_CHUNK) /* 48 KB */
+__device__ __forceinline__ const uint32_t *rc3_chunk_ptr(const uint32_t *wtrunk, int gi) {
+  return gi < 3 ? wtrunk + gi * 3 * RC3_STEM_CHUNK : wtrunk + 9 * RC3_STEM_CHUNK + (gi - 3) * 3 * RC3_CONV_CHUNK;
 }
 
-__device__ __forceinline__ void rc3_stage(const uint32_t *wtrunk, uint32_t *lds_buf, int ch, int wave, int lane) {
-  const uint32_t *src = rc3_chunk_ptr(wtrunk, ch);
-  const int pieces = ch < 9 ? RC3_STEM_CHUNK / 256 : RC3_CONV_CHUNK / 256;
+__device__ __forceinline__ void rc3_stage(const uint32_t *wtrunk, uint32_t *lds_buf, int gi, int wave, int lane) {
+  const uint32_t *src = rc3_chunk_ptr(wtrunk, gi);
+  const int pieces = gi < 3 ? 3 * RC3_STEM_CHUNK / 256 : 3 * RC3_CONV_CHUNK / 256;
   for (int p = wave; p < pieces; p += 8) {
     __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + p * 256 + lane * 4),
                                      (void __attribute__((address_space(3))) *)(lds_buf + p * 256), 16, 0, 0);
@@ -449,15 +454,21 @@ __device__ __forceinline__ void rc3_conv3x3(f32x16 (&acc)[RC3_NP][2], const uint
     for (int to = 0; to < 2; ++to)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[np][to][i] = 0.0f;
-#define RC3_TAP(T)                                                                          \
-  {                                                                                         \
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                        \
-    __syncthreads();                                                                        \
-    if (ch + 1 < RC_NUM_CHUNKS) rc3_stage(wtrunk, lds_w + ((ch + 1) & 1) * RC3_CONV_CHUNK, ch + 1, wave, lane); \
-    rc3_conv_tap<CS, T>(acc, ph, pl, lds_w + (ch & 1) * RC3_CONV_CHUNK, lane, okL, okR);    \
-    ++ch;                                                                                   \
+#define RC3_GROUP(G)                                                                         \
+  {                                                                                          \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                         \
+    __syncthreads();                                                                         \
+    if (ch + 1 < RC3_NUM_GROUPS) rc3_stage(wtrunk, lds_w + ((ch + 1) & 1) * RC3_GROUP_WORDS, ch + 1, wave, lane); \
+    const uint32_t *wg = lds_w + (ch & 1) * RC3_GROUP_WORDS;                                 \
+    constexpr int tw = CS == 1 ? RC3_STEM_CHUNK : RC3_CONV_CHUNK;                            \
+    rc3_conv_tap<CS, 3 * G + 0>(acc, ph, pl, wg, lane, okL, okR);                            \
+    rc3_conv_tap<CS, 3 * G + 1>(acc, ph, pl, wg + tw, lane, okL, okR);                       \
+    rc3_conv_tap<CS, 3 * G + 2>(acc, ph, pl, wg + 2 * tw, lane, okL, okR);                   \
+    ++ch;                                                                                    \
   }
-  RC3_TAP(0) RC3_TAP(1) RC3_TAP(2) RC3_TAP(3) RC3_TAP(4) RC3_TAP(5) RC3_TAP(6) RC3_TAP(7) RC3_TAP(8)
+  RC3_GROUP(0) RC3_GROUP(1) RC3_GROUP(2)
+#undef RC3_GROUP
+#define RC3_TAP(T)
 #undef RC3_TAP
 }
 
@@ -506,8 +517,9 @@ __device__ __forceinline__ void rc3_epilogue(float (&out)[RC3_NP][2][16], const 
 
 __global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_x3(Rc3Params Q) {
   const RcParams &P = Q.base;
-  __shared__ __attribute__((aligned(16))) uint32_t lds_w[2 * RC3_CONV_CHUNK];
-  __shared__ float lds_feat[8][RC_NB][96];
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[]; /* 2 weight groups + head features */
+  uint32_t *lds_w = lds_dyn;
+  float(*lds_feat)[RC_NB][96] = reinterpret_cast<float(*)[RC_NB][96]>(lds_dyn + 2 * RC3_GROUP_WORDS);
   const int rows = *P.d_rows;
   const int row0 = blockIdx.x * RC3_POS_PER_WG;
   if (row0 >= rows) return;
@@ -754,6 +766,8 @@ struct ResCnnX3Net : ResCnnNet {
           }
     rt_malloc((void **)&d_trunk3, tr.size() * 4);
     rt_h2d(d_trunk3, tr.data(), tr.size() * 4, s);
+    RT_CHECK(hipFuncSetAttribute((const void *)co_k_rescnn_forward_x3, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 RC3_LDS_BYTES));
     rt_malloc((void **)&d_whead32, wh32.size() * 4);
     rt_h2d(d_whead32, wh32.data(), wh32.size() * 4, s);
     rt_sync(s);
@@ -775,7 +789,7 @@ struct ResCnnX3Net : ResCnnNet {
     q.base.probs = d_probs;
     q.wtrunk = d_trunk3;
     q.whead32 = d_whead32;
-    hipLaunchKernelGGL(co_k_rescnn_forward_x3, dim3(grid), dim3(512), 0, s, q);
+    hipLaunchKernelGGL(co_k_rescnn_forward_x3, dim3(grid), dim3(512), RC3_LDS_BYTES, s, q);
     RT_CHECK(hipGetLastError());
   }
 };
