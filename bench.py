@@ -55,6 +55,19 @@ def parse():
     return ap.parse_args()
 
 
+def measured_traffic(kernel, args):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    (profiles/r01_pmc.json; PMC counters cannot be collected from inside an un-profiled run).
+    Only valid for the workload those passes were taken on; otherwise null."""
+    if (args.games, args.sims, args.spe, args.net) != (4096, 400, 16, "rescnn4x3"):
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc.json")) as f:
+            return json.load(f)["kernels"][kernel]["traffic_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def host_cores():
     """cores this process may really use: affinity, cgroup quota, and the GPU box's
     per-GPU CPU share (16) -- os.cpu_count() reports the whole host"""
@@ -217,13 +230,15 @@ def main():
                      "rescnn4x3": "co_k_rescnn_forward_x3"}[args.net]
             roofline = {"kernel": kname,
                         "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                        "frac": achieved / peak, "traffic": None,
+                        "frac": achieved / peak, "traffic": measured_traffic(kname, args),
+                        "issued_frac": (3.0 if args.net == "rescnn4x3" else 1.0) * achieved / peak,
                         "algorithmic": "%.1f KFLOP/row x %d rows" % (flop_per_row / 1e3, totals["nn_rows"]),
                         "avg_launch_ms": totals["nn_ms"] / max(totals["iterations"], 1)}
         else:
             achieved = totals["searches"] * BYTES_PER_SIM / max(mcts_s, 1e-12) / 1e9
             roofline = {"kernel": "co_k_mcts_step", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                        "traffic": measured_traffic("co_k_mcts_step", args),
                         "algorithmic": "%.0f B/simulation x %d simulations" % (BYTES_PER_SIM, totals["searches"]),
                         "avg_launch_ms": totals["mcts_ms"] / max(totals["iterations"], 1)}
         out = {
