@@ -410,3 +410,23 @@ def test_fused_rescnn4_bf16x3_generation_replays_on_the_oracle():
     H.play_generation(o, G, spe, lambda s: f.net_forward(s))
     for x, y in zip(H.get_samples(f), H.get_samples(o)):
         assert x.tobytes() == y.tobytes()
+
+
+@pytest.mark.parametrize("engine", ENGINES)
+def test_fused_arena_matches_oracle(engine):
+    """arena (testing=True) kept on the device: two networks, model switching as main.pyx:150-154,
+    offsets recomputed at entry for the model to move (trainer.cpp:208-215) -- same games, same
+    score as the oracle driven by the reference loop with the same two networks"""
+    G, S_, spe = 12, 32, 8
+    wa, wb = nets.init_mlp12x100(seed=4, bn_noise=True), nets.init_mlp12x100(seed=5, bn_noise=True)
+    f = make_trainer(engine, G, "", 9, S_, spe, 1.0, 0.25, 0, 1, True, trace=True)
+    f.set_net(1, wa, slot=0)  # best model
+    f.set_net(1, wb, slot=1)  # new model
+    assert f.run()
+    o = O.Trainer(G, seed=9, max_searches=S_, searches_per_eval=spe, testing=True)
+    o.enable_trace()
+    nets2 = (lambda s: f.net_forward(s, slot=1), lambda s: f.net_forward(s, slot=0))  # to_play 0 -> new model
+    H.play_generation(o, G, spe, None, nets_by_player=nets2)
+    for g in range(G):
+        assert np.array_equal(f.trace(g), o.trace(g)), "game %d" % g
+    assert f.score() == o.score()

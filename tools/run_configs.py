@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Run the other BASELINE.json configurations once each in fused mode and print one JSON
+line per configuration (games/s, device time split, arena high-water mark).
+  cfg1: 64 games, 50 sims (plumbing)        cfg4: 4096 games, 1600 sims + Dirichlet noise
+  cfg5: arena, 1024 two-model games, testing=True, 400 sims"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from corintho_ai_amd import NET_MLP12X100, NET_RESCNN4_X3, Trainer, nets  # noqa: E402
+
+which = sys.argv[1:] or ["cfg1", "cfg4", "cfg5"]
+net_kind = NET_RESCNN4_X3
+w0, w1 = nets.init_rescnn4(0), nets.init_rescnn4(1)
+
+
+def run(name, G, S, testing=False, reps=1):
+    t = Trainer(G, "", 12345, S, 16, 1.0, 0.25, 0, 1, testing, stagger=False)
+    t.set_net(net_kind, w0, slot=0)
+    if testing:
+        t.set_net(net_kind, w1, slot=1)
+    t.run()  # warm
+    best = None
+    for r in range(reps):
+        t.reset(100 + r)
+        t0 = time.perf_counter()
+        assert t.run()
+        dt = time.perf_counter() - t0
+        st = t.stats()
+        rec = {"config": name, "games": G, "sims": S, "testing": testing, "net": "rescnn4x3", "seconds": dt,
+               "games_per_s": G / dt, "iterations": st["iterations"], "searches": st["searches"], "evals": st["evals"],
+               "plies_per_game": st["plies"] / G, "device_ms": {k: st[k] for k in ("mcts_ms", "nn_ms", "pack_ms")},
+               "peak_arena_units_per_tree": st["peak_arena_units"], "score": t.score()}
+        if best is None or rec["games_per_s"] > best["games_per_s"]:
+            best = rec
+    print(json.dumps(best), flush=True)
+    t.close()
+
+
+if "cfg1" in which:
+    run("cfg1: 64 games x 50 sims", 64, 50, reps=2)
+if "cfg4" in which:
+    run("cfg4: 4096 games x 1600 sims + Dirichlet (deep-tree stress)", 4096, 1600)
+if "cfg5" in which:
+    run("cfg5: arena, 1024 two-model games, greedy 400 sims", 1024, 400, testing=True)
