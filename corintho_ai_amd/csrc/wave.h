@@ -13,7 +13,7 @@
 //     v_readlane).
 //   * tests/emu (g++ -DCO_EMU): LV(T,x) is T x[64], FOR_LANES is a loop over
 //     lanes.  It exists so that the kernel LOGIC can be tested and run under
-//     ASan/UBSan on a machine without a GPU.  It is test infrastructure and is
+//     the CPU sanitizers on a machine without a GPU.  It is test infrastructure and is
 //     never loaded by the product.
 //
 // Rules for code written against this layer:

@@ -11,9 +11,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _cache = {}
 
 
-def load(asan=False):
-    name = "libcorintho_emu_asan.so" if asan else "libcorintho_emu.so"
+def load():
+    name = "libcorintho_emu.so"
     if name not in _cache:
-        subprocess.check_call(["make", "-s", "-C", _HERE, "asan" if asan else "all"])
+        subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
         _cache[name] = _lib.declare(C.CDLL(os.path.join(_HERE, name)))
     return _cache[name]
