@@ -502,12 +502,15 @@ __device__ __forceinline__ void rc3_epilogue(float (&out)[RC3_NP][2][16], const 
       const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
       const float aa[4] = {a4.x, a4.y, a4.z, a4.w};
       const float cc[4] = {c4.x, c4.y, c4.z, c4.w};
+      float cb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) cb[i] = __builtin_fmaf(aa[i], bb[i], cc[i]);
 #pragma unroll
       for (int np = 0; np < RC3_NP; ++np)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          float v = acc[np][T][4 * g + i] + bb[i];
-          v = aa[i] * v + cc[i];
+          /* a (acc + bias) + c as one fma on the folded shift cb = a bias + c */
+          float v = __builtin_fmaf(aa[i], acc[np][T][4 * g + i], cb[i]);
           if (ADD_SKIP) v = skip[np][T][4 * g + i] + v;
           v = v > 0.0f ? v : 0.0f;
           out[np][T][4 * g + i] = v;
