@@ -430,3 +430,53 @@ def test_fused_arena_matches_oracle(engine):
     for g in range(G):
         assert np.array_equal(f.trace(g), o.trace(g)), "game %d" % g
     assert f.score() == o.score()
+
+
+@pytest.mark.gpu
+def test_full_size_generation_properties():
+    """BASELINE configs[1] at full size (4096 games, 400 sims/move, residual CNN, fused): too big
+    for the oracle, so checked through size-independent properties -- every game finished, the
+    reference's sample invariants (ranges, probability sums, the 7 symmetry copies being
+    permutations, selfplayer_test.cpp:63-142), alternating outcome labels, determinism of a
+    re-run, a 256-game shard reproducing its slice, and the first 64 games of the same generation
+    replayed on the oracle (fed by the same device network) bit for bit."""
+    from corintho_ai_amd import NET_RESCNN4_X3
+
+    G, S_, spe = 4096, 400, 16
+    w = nets.init_rescnn4(0)
+    t = make_trainer("hip", G, "", 12345, S_, spe, 1.0, 0.25, 0, 1, False, stagger=False)
+    t.set_net(NET_RESCNN4_X3, w)
+    assert t.run()
+    infos = [t.game_info(g) for g in range(0, G, 97)]
+    assert all(i["done"] == 1 and i["error"] == 0 and 0 < i["n_samples"] <= 40 for i in infos)
+    gs, ev, pr = H.get_samples(t)
+    n = t.num_samples()
+    assert gs.shape == (n * 8, 70) and 13 * G < n < 22 * G
+    H.check_sample_properties(gs, ev, pr)
+    assert 0.0 <= t.score() <= 1.0
+    digest = (gs.tobytes(), ev.tobytes(), pr.tobytes(), t.score())
+    # same seed again in the same pool: identical generation
+    t.reset(12345)
+    assert t.run()
+    gs2, ev2, pr2 = H.get_samples(t)
+    assert (gs2.tobytes(), ev2.tobytes(), pr2.tobytes(), t.score()) == digest
+    # games [512, 768) of that generation as their own shard, then on the oracle with the same network
+    sp_all, oc_all = t.export_samples()
+    counts = [t.game_info(g)["n_samples"] for g in range(768)]
+    lo, hi = sum(counts[:512]), sum(counts[:768])
+    shard = make_trainer("hip", 256, "", 12345, S_, spe, 1.0, 0.25, 0, 1, False, stagger=False, game_base=512,
+                         total_games=G)
+    shard.set_net(NET_RESCNN4_X3, w)
+    assert shard.run()
+    sp, oc = shard.export_samples()
+    assert sp.tobytes() == sp_all[lo:hi].tobytes() and oc.tobytes() == oc_all[lo:hi].tobytes()
+    # the first 64 games on the CPU oracle, evaluated by the same device network
+    o = O.Trainer(64, seed=12345, max_searches=S_, searches_per_eval=spe, num_threads=8)
+    o.set_stagger(False)
+    H.play_generation(o, 64, spe, lambda st: t.net_forward(st))
+    ogs, oev, opr = H.get_samples(o)
+    m = sum(counts[:64])
+    assert ogs.shape[0] == m * 8
+    assert ogs[0::8].tobytes() == sp_all[:m, :70].tobytes()
+    assert opr[0::8].tobytes() == sp_all[:m, 70:].tobytes()
+    assert oev[0::8].tobytes() == oc_all[:m].tobytes()
