@@ -274,64 +274,113 @@ CO_DEV void co_receive_one(CoWave &w, CoTree &t, int k, float leaf_eval, const f
 }
 
 /* receiveEval for a batch of up to CO_RB pending leaves at once (trainmc.cpp:269-296).
- * Same arithmetic as co_receive_one, reorganised so that the wave's lanes are busy:
- *   A  lane k: leaf k's header                      (all leaves' loads in flight together)
- *   B  per leaf, lanes = edges: move ids and priors -> LDS tables
+ * Same arithmetic as co_receive_one, reorganised so that loads overlap and lanes are busy:
+ *   A  lane k: leaf k's header; the backup path of every leaf and its stat slots are
+ *      requested here already (consumed in G)
+ *   B  per leaf, lanes = edges: move ids and priors -> LDS tables (all loads in flight together)
  *   C  lanes = consecutive mt19937 draws: noise in stream order (leaf 0's edges first)
- *   D  lane k: the two SEQUENTIAL float sums of leaf k, weights, max, 9-bit quantisation
- *   F  per leaf, lanes = edges: write the priors back
- *   G  per leaf in request order, lanes = path levels: the backup
+ *   D  lane k: the two SEQUENTIAL float sums of leaf k (the only order-sensitive part)
+ *   E  per leaf, lanes = edges: weights, max, 9-bit quantisation, write-back
+ *   G  lanes = path levels: the backups, in request order by register forwarding
  * Falls back to co_receive_one when a leaf has more than CO_RE legal moves. */
 #define CO_RB 8
 #define CO_RE 48
 #define CO_RS (CO_RE + 1) /* LDS row stride: odd, so lane k's column walk is conflict-free */
+
+/* up to 64*CO_RC consecutive generator outputs starting at state position `from` (no wrap):
+ * draw base+lane of chunk c -> noise table entry of its (leaf, edge) */
+#define CO_RC 6
+CO_DEV void co_receive_draws(CoWave &w, float *tn, const int (&offs)[CO_RB + 1], int nb, int from, int first, int count) {
+  LV(uint32_t, raw[CO_RC]);
+#pragma unroll
+  for (int c = 0; c < CO_RC; ++c) {
+    FOR_LANES {
+      int i = c * CO_WAVE + lane;
+      L(raw[c]) = w.mt[from + (i < count ? i : 0)];
+    }
+  }
+  LV(float, gv[CO_RC]);
+#pragma unroll
+  for (int c = 0; c < CO_RC; ++c) {
+    FOR_LANES { L(gv[c]) = co_u2f(CO_GAMMA_BITS[co_mt_temper(L(raw[c])) % CO_NUM_GAMMA]); }
+  }
+#pragma unroll
+  for (int c = 0; c < CO_RC; ++c) {
+    FOR_LANES {
+      int i = c * CO_WAVE + lane;
+      if (i < count) {
+        int d = first + i; /* index of this draw within the batch */
+        int k = 0, ob = 0; /* offs is non-decreasing: the last j with offs[j] <= d owns the draw */
+#pragma unroll
+        for (int j = 1; j < CO_RB; ++j)
+          if (j < nb && offs[j] <= d) {
+            k = j;
+            ob = offs[j];
+          }
+        tn[k * CO_RS + (d - ob)] = L(gv[c]);
+      }
+    }
+  }
+}
+
 CO_DEV void co_receive_batch(CoWave &w, CoTree &t, int k0, int nb, const float *eval, const float *probs) {
   uint4 *A = t.A;
-  WAVE_SHARED(float, tp, CO_RB * CO_RS + 4);  /* priors -> weights (+4: phase D reads four ahead) */
+  WAVE_SHARED(float, tp, CO_RB * CO_RS + 4);  /* priors (+4: phase D reads four ahead) */
   WAVE_SHARED(float, tn, CO_RB * CO_RS + 4);  /* noise */
-  WAVE_SHARED(uint8_t, tm, CO_RB * CO_RS + 3); /* move id, then quantised prior low byte */
-  WAVE_SHARED(uint8_t, tq, CO_RB * CO_RS + 3); /* quantised prior high bit */
-  WAVE_SHARED(int, offs, CO_RB + 1);          /* prefix of legal-move counts = first draw of leaf k */
+  WAVE_SHARED(uint8_t, tm, CO_RB * CO_RS + 3); /* move ids */
   unsigned long long tA = CO_CLK();
   /* ---- A */
   LV(uint32_t, leafv);
   LV(int, nv);
   LV(int, dv);
   FOR_LANES {
-    L(leafv) = 0;
-    L(nv) = 0;
-    L(dv) = 0;
-    if (lane < nb) {
-      L(leafv) = w.pend_leaf[k0 + lane];
-      L(dv) = w.pend_depth[k0 + lane];
-      L(nv) = (int)CO_META_NEDGES(A[L(leafv)].z);
+    int kk = lane < nb ? k0 + lane : k0;
+    L(leafv) = w.pend_leaf[kk];
+    L(dv) = w.pend_depth[kk];
+  }
+  FOR_LANES { L(nv) = lane < nb ? (int)CO_META_NEDGES(A[L(leafv)].z) : 0; }
+  /* backup operands: path slot addresses and their current contents */
+  LV(uint32_t, at[CO_RB]);
+  LV(uint32_t, ny[CO_RB]);
+  LV(uint32_t, nw[CO_RB]);
+  LV(int, on[CO_RB]);
+#pragma unroll
+  for (int k = 0; k < CO_RB; ++k) {
+    int D = WAVE_BCAST(dv, k);
+    const uint32_t *pp = w.pend_path + (size_t)(k < nb ? k0 + k : k0) * CO_PATH_MAX;
+    FOR_LANES {
+      L(on[k]) = (k < nb && lane <= D);
+      L(at[k]) = pp[L(on[k]) ? lane : 0];
     }
   }
-  int total = 0, too_wide = 0;
-  FOR_LANES {
-    if (lane == 0) offs[0] = 0;
+#pragma unroll
+  for (int k = 0; k < CO_RB; ++k) {
+    FOR_LANES {
+      if (!L(on[k])) L(at[k]) = 0u;
+      uint4 sl = A[L(at[k])]; /* unconditional: inactive lanes read unit 0 */
+      L(ny[k]) = sl.y;
+      L(nw[k]) = sl.w & ~0x100u; /* all_visited := false */
+    }
   }
-  for (int k = 0; k < nb; ++k) {
+  int offs[CO_RB + 1];
+  int total = 0, too_wide = 0;
+  offs[0] = 0;
+#pragma unroll
+  for (int k = 0; k < CO_RB; ++k) {
     int n = WAVE_BCAST(nv, k);
     if (n > CO_RE) too_wide = 1;
     total += n;
-    FOR_LANES {
-      if (lane == 0) offs[k + 1] = total;
-    }
+    offs[k + 1] = total;
   }
   if (too_wide) {
     for (int k = 0; k < nb; ++k) co_receive_one(w, t, k0 + k, eval[k0 + k], probs + (size_t)(k0 + k) * CO_NUM_MOVES);
     return;
   }
-  WAVE_SYNC();
   CO_PROF_ADD(w, 8, CO_CLK() - tA);
   tA = CO_CLK();
-  /* ---- B: every leaf's loads are issued before the first is used (two memory round
-   * trips for the whole batch instead of two per leaf) */
+  /* ---- B: loads are unconditional (inactive lanes read unit 0 / prior 0) so that none of
+   * them sits in a predicated block with its first use: all eight stay in flight */
   {
-    /* loads are unconditional (inactive lanes read unit 0 / prior 0) so that none of them
-     * sits in a predicated block with its first use: the compiler then keeps all eight in
-     * flight instead of waiting for each */
     LV(uint32_t, mvv[CO_RB]);
     LV(float, prv[CO_RB]);
 #pragma unroll
@@ -339,8 +388,8 @@ CO_DEV void co_receive_batch(CoWave &w, CoTree &t, int k0, int nb, const float *
       uint32_t leaf = WAVE_BCAST(leafv, k);
       int n = WAVE_BCAST(nv, k);
       FOR_LANES {
-        uint32_t at = (k < nb && lane < n) ? leaf + 2u + (uint32_t)lane : 0u;
-        L(mvv[k]) = A[at].z;
+        uint32_t ad = (k < nb && lane < n) ? leaf + 2u + (uint32_t)lane : 0u;
+        L(mvv[k]) = A[ad].z;
       }
     }
 #pragma unroll
@@ -364,33 +413,36 @@ CO_DEV void co_receive_batch(CoWave &w, CoTree &t, int k0, int nb, const float *
   }
   CO_PROF_ADD(w, 9, CO_CLK() - tA);
   tA = CO_CLK();
-  /* ---- C: draw i belongs to the leaf k with offs[k] <= i < offs[k+1] */
-  for (int base = 0; base < total; base += CO_WAVE) {
-    int cnt = total - base < CO_WAVE ? total - base : CO_WAVE;
-    LV(uint32_t, r);
-    CO_MT_DRAW(w.mt, w.gc.rng_idx, cnt, r);
-    FOR_LANES {
-      if (lane < cnt) {
-        int i = base + lane;
-        int k = 0;
-        for (int j = 1; j < CO_RB; ++j) k += (j < nb && offs[j] <= i) ? 1 : 0;
-        tn[k * CO_RS + (i - offs[k])] = co_u2f(CO_GAMMA_BITS[L(r) % CO_NUM_GAMMA]);
+  /* ---- C: `total` outputs of the game's generator; at most one twist in between */
+  {
+    int done = 0;
+    while (done < total) {
+      if (w.gc.rng_idx >= CO_MT_N) {
+        co_mt_twist(w.mt);
+        w.gc.rng_idx = 0;
       }
+      int cnt = total - done;
+      if (cnt > CO_MT_N - w.gc.rng_idx) cnt = CO_MT_N - w.gc.rng_idx;
+      if (cnt > CO_WAVE * CO_RC) cnt = CO_WAVE * CO_RC;
+      co_receive_draws(w, tn, offs, nb, w.gc.rng_idx, done, cnt);
+      w.gc.rng_idx += cnt;
+      done += cnt;
     }
   }
   WAVE_SYNC();
   CO_PROF_ADD(w, 10, CO_CLK() - tA);
   tA = CO_CLK();
-  /* ---- D: lane k owns leaf k */
-  LV(float, denomv);
+  /* ---- D: lane k owns leaf k; sequential float additions in edge order, reading four
+   * entries ahead to keep the LDS latency off the dependent add chain (x + 0.0f == x) */
+  LV(float, scv);
+  LV(float, dscv);
   FOR_LANES {
-    L(denomv) = 0.0f;
+    L(scv) = 0.0f;
+    L(dscv) = 0.0f;
     if (lane < nb) {
       const int n = L(nv);
-      float *fp = tp + lane * CO_RS;
-      float *dn = tn + lane * CO_RS;
-      /* the sums are sequential float additions in edge order; reading four entries
-       * ahead keeps the LDS latency off the dependent add chain (x + 0.0f == x) */
+      const float *fp = tp + lane * CO_RS;
+      const float *dn = tn + lane * CO_RS;
       float sum = 0.0f, dsum = 0.0f;
       for (int e = 0; e < n; e += 4) {
         float a0 = fp[e], a1 = fp[e + 1], a2 = fp[e + 2], a3 = fp[e + 3];
@@ -405,89 +457,54 @@ CO_DEV void co_receive_batch(CoWave &w, CoTree &t, int k0, int nb, const float *
         dsum += e + 3 < n ? d3 : 0.0f;
       }
       float one_minus = (float)1 - w.epsilon;
-      float scalar = (float)(1.0 / (double)sum * (double)one_minus);
-      float dscalar = (float)(1.0 / (double)dsum * (double)w.epsilon);
-      float max_prob = 0.0f;
-      for (int e = 0; e < n; e += 4) {
-        float a0 = fp[e], a1 = fp[e + 1], a2 = fp[e + 2], a3 = fp[e + 3];
-        float d0 = dn[e], d1 = dn[e + 1], d2 = dn[e + 2], d3 = dn[e + 3];
-        float w0 = a0 * scalar + d0 * dscalar, w1 = a1 * scalar + d1 * dscalar;
-        float w2 = a2 * scalar + d2 * dscalar, w3 = a3 * scalar + d3 * dscalar;
-        fp[e] = w0;
-        max_prob = w0 > max_prob ? w0 : max_prob;
-        if (e + 1 < n) { fp[e + 1] = w1; max_prob = w1 > max_prob ? w1 : max_prob; }
-        if (e + 2 < n) { fp[e + 2] = w2; max_prob = w2 > max_prob ? w2 : max_prob; }
-        if (e + 3 < n) { fp[e + 3] = w3; max_prob = w3 > max_prob ? w3 : max_prob; }
-      }
-      float denom = 511.0f / max_prob;
-      int final_sum = 0;
-      for (int e = 0; e < n; e += 4) {
-        float x4[4] = {fp[e], fp[e + 1], fp[e + 2], fp[e + 3]};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if (e + i < n) {
-            float x = x4[i] * denom;
-            float fl = __builtin_truncf(x);
-            int q = (int)fl;
-            if (x - fl >= 0.5f) q += 1;
-            if (!(q >= 1)) q = 1;
-            final_sum += q;
-            tq[lane * CO_RS + e + i] = (uint8_t)((q >> 8) & 1);
-            dn[e + i] = co_u2f((uint32_t)(q & 255)); /* low byte parked in the noise table */
-          }
-        }
-      }
-      L(denomv) = (float)(1.0 / (double)(float)final_sum);
+      L(scv) = (float)(1.0 / (double)sum * (double)one_minus);
+      L(dscv) = (float)(1.0 / (double)dsum * (double)w.epsilon);
     }
   }
-  WAVE_SYNC();
   CO_PROF_ADD(w, 11, CO_CLK() - tA);
   tA = CO_CLK();
-  /* ---- F: a leaf that waits for its evaluation has no children (all_visited is born
-   * true, node.h:186), so its edge words are just the move id: plain stores, no reload */
+  /* ---- E: per leaf, lanes = edges.  max and the integer sum are order independent.  A leaf
+   * that waits for its evaluation has no children (all_visited is born true, node.h:186), so
+   * its edge words are just the move id: plain stores, no reload */
   for (int k = 0; k < nb; ++k) {
     uint32_t leaf = WAVE_BCAST(leafv, k);
     int n = WAVE_BCAST(nv, k);
-    float den = WAVE_BCAST(denomv, k);
+    float scalar = WAVE_BCAST(scv, k), dscalar = WAVE_BCAST(dscv, k);
+    LV(float, wt);
     FOR_LANES {
+      float a = tp[k * CO_RS + (lane < n ? lane : 0)] * scalar;
+      float d = tn[k * CO_RS + (lane < n ? lane : 0)] * dscalar;
+      L(wt) = lane < n ? a + d : 0.0f;
+    }
+    float max_prob = WAVE_MAX_F32(wt); /* weights are >= 0, as the reference's max_prob start value */
+    float denom = 511.0f / max_prob;
+    LV(int, qv);
+    FOR_LANES {
+      int q = 0;
       if (lane < n) {
-        uint32_t q = co_f2u(tn[k * CO_RS + lane]) | ((uint32_t)tq[k * CO_RS + lane] << 8);
-        A[leaf + 2 + lane].z = (uint32_t)tm[k * CO_RS + lane] | ((q & 511u) << 7);
+        float x = L(wt) * denom;
+        float fl = __builtin_truncf(x);
+        q = (int)fl;
+        if (x - fl >= 0.5f) q += 1;
+        if (!(q >= 1)) q = 1;
+        A[leaf + 2 + lane].z = (uint32_t)tm[k * CO_RS + lane] | ((uint32_t)(q & 511) << 7);
       }
-      if (lane == 63) A[leaf + 1].y = co_f2u(den);
+      L(qv) = q;
+    }
+    int final_sum = WAVE_SUM_I32(qv);
+    float den = (float)(1.0 / (double)(float)final_sum);
+    FOR_LANES {
+      if (lane == 0) A[leaf + 1].y = co_f2u(den);
     }
   }
   WAVE_SYNC();
   CO_PROF_ADD(w, 12, CO_CLK() - tA);
   tA = CO_CLK();
   /* ---- G: backups, lane = path level.  The slot of a shared ancestor must receive the
-   * leaves' contributions in request order (float addition is not associative).  All
-   * slots are fetched up front; leaf k then starts from the value left by the latest
-   * earlier leaf that touched the same slot (register forwarding) instead of re-reading
-   * memory, so the 16 read-modify-writes cost one memory round trip, not sixteen. */
+   * leaves' contributions in request order (float addition is not associative).  The slots
+   * were fetched in phase A; leaf k starts from the value left by the latest earlier leaf of
+   * the batch that touched the same slot (register forwarding) instead of re-reading memory. */
   {
-    LV(uint32_t, at[CO_RB]);
-    LV(uint32_t, ny[CO_RB]);
-    LV(uint32_t, nw[CO_RB]);
-    LV(int, on[CO_RB]);
-#pragma unroll
-    for (int k = 0; k < CO_RB; ++k) {
-      int D = WAVE_BCAST(dv, k);
-      const uint32_t *pp = w.pend_path + (size_t)(k < nb ? k0 + k : k0) * CO_PATH_MAX;
-      FOR_LANES {
-        L(on[k]) = (k < nb && lane <= D);
-        L(at[k]) = pp[L(on[k]) ? lane : 0];
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < CO_RB; ++k) {
-      FOR_LANES {
-        if (!L(on[k])) L(at[k]) = 0u;
-        uint4 sl = A[L(at[k])]; /* unconditional: inactive lanes read unit 0 */
-        L(ny[k]) = sl.y;
-        L(nw[k]) = sl.w & ~0x100u; /* all_visited := false */
-      }
-    }
 #pragma unroll
     for (int k = 0; k < CO_RB; ++k) {
       int D = WAVE_BCAST(dv, k);

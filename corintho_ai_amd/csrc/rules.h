@@ -54,32 +54,30 @@ CO_DEV void co_decode_move(int id, int *is_place, int *piece, int *from, int *to
   }
 }
 
-/* game.cpp:193-242 for one move id */
-CO_DEV int co_basic_legal(uint64_t board, uint32_t meta, int id) {
-  int is_place, piece, from, to;
-  co_decode_move(id, &is_place, &piece, &from, &to);
-  uint32_t nb = co_nib(board, to);
-  if (is_place) {
-    uint32_t left = CO_META_PIECE(meta, CO_META_TO_PLAY(meta) * 3 + piece);
-    if (left == 0) return 0;
-    if ((nb & 7u) == 0) return 1;
-    if (nb & 8u) return 0;
-    if (piece == 0) return 0;
-    if (piece == 1) return !(nb & 6u);
-    return !((nb & 4u) || ((nb & 1u) && !(nb & 2u)));
-  }
-  uint32_t na = co_nib(board, from);
-  if ((na & 7u) == 0 || (nb & 7u) == 0) return 0;
-  if ((na | nb) & 8u) return 0;
-  return co_nib_bottom(na) - co_nib_top(nb) == 1;
+/* every 4th bit of x (bits 4c + k, k given by the caller's shift) gathered into bits 0..15 */
+CO_DEV uint32_t co_plane(uint64_t x) {
+  x &= 0x1111111111111111ull;
+  x = (x | (x >> 3)) & 0x0303030303030303ull;
+  x = (x | (x >> 6)) & 0x000F000F000F000Full;
+  x = (x | (x >> 12)) & 0x000000FF000000FFull;
+  x = (x | (x >> 24)) & 0xFFFFull;
+  return (uint32_t)x;
 }
 
-/* game.cpp:28-43.  out[3] = 96-bit legal mask; returns is_lines.  Uniform. */
+/* game.cpp:28-43.  out[3] = 96-bit legal mask; returns is_lines.  Uniform.
+ * The board is split into four 16-cell bit planes (base, column, capital, frozen); basic
+ * legality of all 96 moves (game.cpp:193-242) is then ~80 wave-uniform bit operations on
+ * those planes -- scalar work, no per-lane code -- and only the 34 candidate lines are
+ * tested one per lane. */
 CO_DEV int co_legal_moves(uint64_t board, uint32_t meta, uint32_t out[3]) {
-  /* ---- the 34 candidate lines, in the reference's scan order:
-   * lanes 0-11 rows (i = j/3; long, left triple, right triple), 12-23 columns,
-   * 24-29 long diagonals (main: long, upper, lower; anti: ...), 30-33 short
-   * diagonals.  Every candidate is an arithmetic progression of cells. */
+  const uint32_t B = co_plane(board), C = co_plane(board >> 1), A = co_plane(board >> 2), F = co_plane(board >> 3);
+  const uint32_t N = B | C | A;             /* non-empty */
+  const uint32_t E = ~N & 0xFFFFu;          /* empty */
+  const uint32_t T2 = A, T1 = C & ~A, T0 = B & ~C & ~A; /* top piece (game.cpp:158-168) */
+  /* ---- the 34 candidate lines, in the reference's scan order: lanes 0-11 rows (i = j/3;
+   * long, left triple, right triple), 12-23 columns, 24-29 long diagonals (main: long, upper,
+   * lower; anti: ...), 30-33 short diagonals.  Every candidate is an arithmetic progression
+   * of cells; it is a line iff all its cells lie in one top-piece plane. */
   LV(int, match);
   LV(int, ctop);
   LV(int, cbase);
@@ -104,13 +102,11 @@ CO_DEV int co_legal_moves(uint64_t board, uint32_t meta, uint32_t out[3]) {
       c0 = s == 0 ? 2 : s == 1 ? 1 : s == 2 ? 7 : 4; step = (s & 1) ? 5 : 3; count = 3;
       base = 90 + 3 * s;
     }
-    int t0 = count ? co_nib_top(co_nib(board, c0)) : -1;
-    int ok = t0 >= 0;
-    for (int q = 1; q < 4; ++q) {
-      if (q < count) ok = ok && (co_nib_top(co_nib(board, c0 + q * step)) == t0);
-    }
-    L(match) = ok;
-    L(ctop) = t0;
+    uint32_t M = (1u << c0) | (1u << (c0 + step)) | (1u << (c0 + 2 * step));
+    if (count == 4) M |= 1u << (c0 + 3 * step);
+    int t = (T0 & M) == M ? 0 : (T1 & M) == M ? 1 : (T2 & M) == M ? 2 : -1;
+    L(match) = count != 0 && t >= 0;
+    L(ctop) = t;
     L(cbase) = base;
   }
   uint64_t cand = WAVE_BALLOT(match);
@@ -138,7 +134,7 @@ CO_DEV int co_legal_moves(uint64_t board, uint32_t meta, uint32_t out[3]) {
         int ec = k == 1 ? 3 : 0;
         for (int kk = 0; kk < 4; ++kk) {
           int cell = is_col ? (ec * 4 + kk) : (kk * 4 + ec);
-          if (co_nib(board, cell) & 4u) continue;
+          if ((A >> cell) & 1u) continue;
           /* moves kk -> kk-1 and kk -> kk+1 along that line of cells */
           if (kk > 0) {
             int id = is_col ? (24 + ec * 3 + (kk - 1)) : (36 + (kk - 1) * 4 + ec);
@@ -152,18 +148,30 @@ CO_DEV int co_legal_moves(uint64_t board, uint32_t meta, uint32_t out[3]) {
       }
     }
   }
-  /* ---- basic legality of all 96 moves: lanes 0..63 -> ids 0..63, lanes 0..31 -> ids 64..95 */
-  LV(int, la);
-  LV(int, lb);
-  FOR_LANES {
-    L(la) = co_basic_legal(board, meta, lane);
-    L(lb) = lane < 32 ? co_basic_legal(board, meta, 64 + lane) : 0;
-  }
-  uint64_t ba = WAVE_BALLOT(la);
-  uint64_t bb = WAVE_BALLOT(lb);
-  out[0] = m0 & (uint32_t)ba;
-  out[1] = m1 & (uint32_t)(ba >> 32);
-  out[2] = m2 & (uint32_t)bb;
+  /* ---- basic legality of all 96 moves on the planes.
+   * place (canPlace, game.cpp:193-220): an empty cell takes anything; a frozen one nothing;
+   * a column goes on a bare base; a capital on anything without a capital except a bare base */
+  const uint32_t NF = N & ~F;
+  const uint32_t tp3 = CO_META_TO_PLAY(meta) * 3;
+  uint32_t pb = CO_META_PIECE(meta, tp3 + 0) ? E : 0u;
+  uint32_t pc = CO_META_PIECE(meta, tp3 + 1) ? (E | (NF & B & ~C & ~A)) : 0u;
+  uint32_t pa = CO_META_PIECE(meta, tp3 + 2) ? (E | (NF & ~A & ~(B & ~C))) : 0u;
+  /* move a -> b (canMove, game.cpp:222-232): both non-empty, neither frozen,
+   * bottom(a) - top(b) == 1, i.e. (bottom 1 on top 0) or (bottom 2 on top 1) */
+  const uint32_t Bo1 = ~B & C, Bo2 = ~B & ~C & A;
+  const uint32_t R = NF & (NF >> 1) & ((Bo1 & (T0 >> 1)) | (Bo2 & (T1 >> 1))) & 0x7777u; /* from col < 3 */
+  const uint32_t D = NF & (NF >> 4) & ((Bo1 & (T0 >> 4)) | (Bo2 & (T1 >> 4))) & 0x0FFFu; /* from row < 3 */
+  const uint32_t Lf = NF & (NF << 1) & ((Bo1 & (T0 << 1)) | (Bo2 & (T1 << 1))) & 0xEEEEu; /* from col > 0 */
+  const uint32_t U = NF & (NF << 4) & ((Bo1 & (T0 << 4)) | (Bo2 & (T1 << 4))) & 0xFFF0u;  /* from row > 0 */
+  /* move ids (move.cpp:11-42): right r*3+c, down 12+cell, left 24+r*3+(c-1), up 36+cell-4 */
+  const uint32_t rid = (R & 7u) | (((R >> 4) & 7u) << 3) | (((R >> 8) & 7u) << 6) | (((R >> 12) & 7u) << 9);
+  const uint32_t lid = ((Lf >> 1) & 7u) | (((Lf >> 5) & 7u) << 3) | (((Lf >> 9) & 7u) << 6) | (((Lf >> 13) & 7u) << 9);
+  const uint32_t b0 = rid | (D << 12) | (lid << 24);
+  const uint32_t b1 = (lid >> 8) | ((U >> 4) << 4) | (pb << 16);
+  const uint32_t b2 = pc | (pa << 16);
+  out[0] = m0 & b0;
+  out[1] = m1 & b1;
+  out[2] = m2 & b2;
   return is_lines;
 }
 
