@@ -144,12 +144,14 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     dist = None
     torch = None
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("CORINTHO_FORCE_DIST") == "1"  # the latter: 1-rank rehearsal of the RCCL path
+    if use_dist:
         import torch
         import torch.distributed as dist
 
         torch.cuda.set_device(local_rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from corintho_ai_amd import NET_MLP12X100, NET_RESCNN4, NET_RESCNN4_X3, Trainer, nets
@@ -169,7 +171,7 @@ def main():
     tr.set_net(kind, weights)
 
     gatherer = None
-    if world > 1:
+    if use_dist:
         from corintho_ai_amd.dist import SampleGather
 
         gatherer = SampleGather(tr, G, on_device=True)
@@ -182,7 +184,7 @@ def main():
         done = tr.run()
         if not done:
             raise RuntimeError("generation did not finish")
-        if world > 1:
+        if use_dist:
             t0 = time.perf_counter()
             gatherer.gather()  # one RCCL all-gather of the un-augmented samples per generation
             if timed:
@@ -195,7 +197,7 @@ def main():
             totals["peak_arena_units"] = max(totals["peak_arena_units"], st["peak_arena_units"])
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -207,7 +209,7 @@ def main():
         one_step(s, True)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -303,7 +305,7 @@ def main():
         if world == 1 and args.cpu_games > 0:
             out["cpu_baseline"] = cpu_baseline(args, weights, "mlp12x100" if args.net == "mlp12x100" else "rescnn4")
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
