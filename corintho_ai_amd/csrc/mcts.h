@@ -639,25 +639,25 @@ CO_DEV void co_search(CoWave &w, CoTree &t, CoRoot &rc) {
         int e = base + lane;
         float uu = CO_NEG_INF;
         if (base > 0 && e < n) L(ev) = A[cur + 2 + e];
-        if (e < n) {
+        {
+          /* branch-free: every lane evaluates both forms and selects (one f64 pair per level
+           * whatever the mix of edges; divergent branches here cost more than they save) */
           uint4 s = L(ev);
           float prob = (float)((s.z >> 7) & 511u) * denom;
-          if (s.x != CO_NONE) {
-            int r = co_slot_result(s);
-            if ((!co_res_known(r) || co_res_drawn(r)) && !co_slot_all_visited(s)) {
-              if (co_res_drawn(r)) {
-                uu = prob * v_sqrt;
-              } else {
-                float pv = prob * v_sqrt;
-                float cv = (float)co_slot_visits(s);
-                double a = -1.0 * (double)co_u2f(s.y) / (double)cv;
-                double b = (double)pv / ((double)cv + 1.0);
-                uu = (float)(a + b);
-              }
-            }
-          } else {
-            uu = prob * v_sqrt;
-          }
+          float pv = prob * v_sqrt;
+          int r = (int)(s.w & 0xFFu);
+          int has_child = s.x != CO_NONE;
+          int drawn = (r == CO_RESULT_DRAW) | (r == CO_DEDUCED_DRAW);
+          int searchable = ((r == CO_RESULT_NONE) | drawn) & !((s.w >> 8) & 1u);
+          int vis = co_slot_visits(s);
+          float cv = (float)(vis > 0 ? vis : 1);
+          double a = -1.0 * (double)co_u2f(s.y) / (double)cv;
+          double b = (double)pv / ((double)cv + 1.0);
+          float uv = (float)(a + b);
+          float uc = drawn ? pv : uv;           /* visited child (trainmc.cpp:561-569) */
+          uc = searchable ? uc : CO_NEG_INF;
+          uu = has_child ? uc : pv;             /* unvisited edge (:575-577) */
+          uu = e < n ? uu : CO_NEG_INF;
         }
         L(u) = uu;
       }

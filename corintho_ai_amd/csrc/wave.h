@@ -107,8 +107,8 @@ extern thread_local int co_emu_block_idx;
 #define CO_DPP_XOR2 0x4E        /* quad_perm [2,3,0,1] */
 #define CO_DPP_HALF_MIRROR 0x141
 #define CO_DPP_MIRROR 0x140
-#define CO_DPP_I(v, ctrl) __builtin_amdgcn_update_dpp(0, (v), (ctrl), 0xF, 0xF, false)
-#define CO_DPP_F(v, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (ctrl), 0xF, 0xF, false))
+#define CO_DPP_I(v, ctrl) __builtin_amdgcn_mov_dpp((v), (ctrl), 0xF, 0xF, false)
+#define CO_DPP_F(v, ctrl) __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), (ctrl), 0xF, 0xF, false))
 __device__ __forceinline__ float co_fmaxsel(float a, float b) { return b > a ? b : a; }
 __device__ __forceinline__ float co_wave_max_f32(float v) {
   v = co_fmaxsel(v, CO_DPP_F(v, CO_DPP_XOR1));
