@@ -653,6 +653,33 @@ extern "C" int ca_trainer_net_forward(ca_trainer *t, int slot, const float *stat
   })
 }
 
+/* kernel-only timing of a network on `rows` resident rows (HIP events on the engine's stream);
+ * diagnostics and the per-kernel roofline of bench.py */
+extern "C" int ca_trainer_net_bench(ca_trainer *t, int slot, const float *states, int32_t rows, int32_t reps, float *ms_per_call) {
+  CA_GUARD({
+    if (slot < 0 || slot > 1 || !t->nets[slot]) throw EngineError(CA_ERR_STATE, "net slot not set");
+    if ((size_t)rows > t->nets[slot]->max_rows()) throw EngineError(CA_ERR_ARG, "net_bench: too many rows");
+    std::vector<float> pad((size_t)rows * CO_STATE_STRIDE, 0.0f);
+    for (int r = 0; r < rows; ++r)
+      memcpy(&pad[(size_t)r * CO_STATE_STRIDE], states + (size_t)r * CO_GAME_STATE_SIZE, CO_GAME_STATE_SIZE * 4);
+    DevBuf<int32_t> d_n;
+    d_n.alloc(1);
+    rt_h2d(t->nn_in.p, pad.data(), pad.size() * 4, t->stream);
+    rt_h2d(d_n.p, &rows, 4, t->stream);
+    t->nets[slot]->forward(t->nn_in.p, rows, d_n.p, t->nn_eval.p, t->nn_probs.p, t->stream); /* warm */
+    rt_event_t e0, e1;
+    rt_event_create(&e0);
+    rt_event_create(&e1);
+    rt_event_record(e0, t->stream);
+    for (int i = 0; i < reps; ++i) t->nets[slot]->forward(t->nn_in.p, rows, d_n.p, t->nn_eval.p, t->nn_probs.p, t->stream);
+    rt_event_record(e1, t->stream);
+    rt_sync(t->stream);
+    *ms_per_call = rt_event_elapsed_ms(e0, e1) / (float)reps;
+    rt_event_destroy(e0);
+    rt_event_destroy(e1);
+  })
+}
+
 extern "C" int ca_expand_samples(int device, const float *state_policy, const float *outcome, int32_t n, float *gs, float *ev,
                                  float *pr) {
   /* host-side K7 for gathered shards: same gathers as co_k_write_samples */

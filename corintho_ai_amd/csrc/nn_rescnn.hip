@@ -414,13 +414,23 @@ template <int CS, int TAP>
 __device__ __forceinline__ void rc3_conv_tap(f32x16 (&acc)[RC3_NP][2], const uint32_t (&ph)[RC3_NP][4][4],
                                              const uint32_t (&pl)[RC3_NP][4][4], const uint32_t *w, int lane, bool okL,
                                              bool okR) {
+  /* the weight fragments of K step s+1 are requested from LDS before the MFMAs of step s
+   * issue (two register sets), so the LDS latency is paid once per tap, not once per step */
+  u32x4 ah[2][2], al[2][2];
+#pragma unroll
+  for (int to = 0; to < 2; ++to) {
+    ah[0][to] = *reinterpret_cast<const u32x4 *>(w + (((0 * 2 + to) * 2 + 0) * 64 + lane) * 4);
+    al[0][to] = *reinterpret_cast<const u32x4 *>(w + (((0 * 2 + to) * 2 + 1) * 64 + lane) * 4);
+  }
 #pragma unroll
   for (int s = 0; s < CS; ++s) {
-    u32x4 ah[2], al[2];
+    const int cur = s & 1, nxt = cur ^ 1;
+    if (s + 1 < CS) {
 #pragma unroll
-    for (int to = 0; to < 2; ++to) {
-      ah[to] = *reinterpret_cast<const u32x4 *>(w + (((s * 2 + to) * 2 + 0) * 64 + lane) * 4);
-      al[to] = *reinterpret_cast<const u32x4 *>(w + (((s * 2 + to) * 2 + 1) * 64 + lane) * 4);
+      for (int to = 0; to < 2; ++to) {
+        ah[nxt][to] = *reinterpret_cast<const u32x4 *>(w + ((((s + 1) * 2 + to) * 2 + 0) * 64 + lane) * 4);
+        al[nxt][to] = *reinterpret_cast<const u32x4 *>(w + ((((s + 1) * 2 + to) * 2 + 1) * 64 + lane) * 4);
+      }
     }
 #pragma unroll
     for (int np = 0; np < RC3_NP; ++np) {
@@ -433,13 +443,13 @@ __device__ __forceinline__ void rc3_conv_tap(f32x16 (&acc)[RC3_NP][2], const uin
       const bf16x8 Bh = __builtin_bit_cast(bf16x8, bh), Bl = __builtin_bit_cast(bf16x8, bl);
 #pragma unroll
       for (int to = 0; to < 2; ++to)
-        acc[np][to] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[to]), Bh, acc[np][to], 0, 0, 0);
+        acc[np][to] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[cur][to]), Bh, acc[np][to], 0, 0, 0);
 #pragma unroll
       for (int to = 0; to < 2; ++to)
-        acc[np][to] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[to]), Bl, acc[np][to], 0, 0, 0);
+        acc[np][to] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[cur][to]), Bl, acc[np][to], 0, 0, 0);
 #pragma unroll
       for (int to = 0; to < 2; ++to)
-        acc[np][to] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[to]), Bh, acc[np][to], 0, 0, 0);
+        acc[np][to] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[cur][to]), Bh, acc[np][to], 0, 0, 0);
     }
   }
 }

@@ -123,6 +123,13 @@ class Trainer:
                                                            _f32(pr, "pr")))
         return ev, pr
 
+    def net_bench(self, states, reps=20, slot=0):
+        """kernel-only milliseconds per evaluation of `states` (diagnostics)"""
+        s = np.ascontiguousarray(states, dtype=np.float32)
+        ms = C.c_float()
+        _lib.check(self._L, self._L.ca_trainer_net_bench(self._t, slot, _f32(s, "states"), s.shape[0], reps, C.byref(ms)))
+        return ms.value
+
     def export_samples(self):
         n = self.num_samples()
         sp = np.zeros((n, GAME_STATE_SIZE + NUM_MOVES), np.float32)

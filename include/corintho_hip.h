@@ -111,6 +111,10 @@ int ca_trainer_run(ca_trainer *t, int64_t max_iterations, int32_t *all_done);
  * states [n][70] -> evals [n], probs [n][96] */
 int ca_trainer_net_forward(ca_trainer *t, int slot, const float *states, int32_t n, float *evals, float *probs);
 
+/* Kernel-only time of one network evaluation of `rows` resident rows (average of `reps`
+ * launches, HIP events) -- diagnostics */
+int ca_trainer_net_bench(ca_trainer *t, int slot, const float *states, int32_t rows, int32_t reps, float *ms_per_call);
+
 /* Un-augmented samples for the multi-GPU gather: n = num_samples() rows of
  * (state[70], policy[96]) + outcome[n] in game order; the x8 symmetry expansion
  * is applied after the gather by ca_expand_samples. */
