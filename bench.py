@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--no-mlp-extra", action="store_true", help="skip the extra generations (other networks) reported under detail.variants")
     ap.add_argument("--stagger", action="store_true", help="keep the reference's staggered start")
     ap.add_argument("--arena-units", type=int, default=0)
+    ap.add_argument("--pools", type=int, default=0, help="independent game pools on separate streams per GPU (0 = engine default)")
     ap.add_argument("--cpu-games", type=int, default=64, help="games of the bounded CPU-baseline sample (0 = skip)")
     return ap.parse_args()
 
@@ -167,7 +168,8 @@ def main():
         flop_per_row = nets.rescnn4_flop_per_row()
 
     tr = Trainer(G, "", 12345, args.sims, args.spe, args.c_puct, args.epsilon, 0, 1, False, device=local_rank,
-                 stagger=args.stagger, arena_units=args.arena_units, game_base=rank * G, total_games=world * G)
+                 stagger=args.stagger, arena_units=args.arena_units, game_base=rank * G, total_games=world * G,
+                 pools=args.pools)
     tr.set_net(kind, weights)
 
     gatherer = None
@@ -177,7 +179,7 @@ def main():
         gatherer = SampleGather(tr, G, on_device=True)
 
     totals = {"searches": 0, "evals": 0, "plies": 0, "iterations": 0, "mcts_ms": 0.0, "nn_ms": 0.0, "pack_ms": 0.0,
-              "nn_rows": 0, "gather_ms": 0.0, "samples": 0, "peak_arena_units": 0}
+              "nn_rows": 0, "nn_launches": 0, "mcts_launches": 0, "gather_ms": 0.0, "samples": 0, "peak_arena_units": 0}
 
     def one_step(step_index, timed):
         tr.reset(12345 + step_index)
@@ -191,8 +193,10 @@ def main():
                 totals["gather_ms"] += (time.perf_counter() - t0) * 1e3
         if timed:
             st = tr.stats()
-            for k in ("searches", "evals", "plies", "iterations", "mcts_ms", "nn_ms", "pack_ms", "nn_rows"):
+            for k in ("searches", "evals", "plies", "iterations", "mcts_ms", "nn_ms", "pack_ms", "nn_rows", "nn_launches",
+                      "mcts_launches"):
                 totals[k] += st[k]
+            totals["pools"] = st["pools"]
             totals["samples"] += tr.num_samples()
             totals["peak_arena_units"] = max(totals["peak_arena_units"], st["peak_arena_units"])
 
@@ -235,14 +239,42 @@ def main():
                         "frac": achieved / peak, "traffic": measured_traffic(kname, args),
                         "issued_frac": (3.0 if args.net == "rescnn4x3" else 1.0) * achieved / peak,
                         "algorithmic": "%.1f KFLOP/row x %d rows" % (flop_per_row / 1e3, totals["nn_rows"]),
-                        "avg_launch_ms": totals["nn_ms"] / max(totals["iterations"], 1)}
+                        "avg_launch_ms": totals["nn_ms"] / max(totals["nn_launches"], 1)}
         else:
             achieved = totals["searches"] * BYTES_PER_SIM / max(mcts_s, 1e-12) / 1e9
             roofline = {"kernel": "co_k_mcts_step", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                         "traffic": measured_traffic("co_k_mcts_step", args),
                         "algorithmic": "%.0f B/simulation x %d simulations" % (BYTES_PER_SIM, totals["searches"]),
-                        "avg_launch_ms": totals["mcts_ms"] / max(totals["iterations"], 1)}
+                        "avg_launch_ms": totals["mcts_ms"] / max(totals["mcts_launches"], 1)}
+        npools = int(totals.get("pools", 1))
+        roofline["streams"] = npools
+        if npools > 1:
+            # The timed region runs the games as `npools` pools on separate streams, so the durations
+            # above are those of kernels SHARING the GPU with the other pool's kernels (their sum
+            # exceeds the wall time).  One more generation with a single pool gives the same kernel's
+            # rate when it has the GPU to itself.
+            t1 = Trainer(G, "", 12345, args.sims, args.spe, args.c_puct, args.epsilon, 0, 1, False, device=local_rank,
+                         stagger=args.stagger, arena_units=args.arena_units, game_base=rank * G,
+                         total_games=world * G, pools=1)
+            t1.set_net(kind, weights)
+            t1.reset(1000)
+            t1.run()
+            t1.reset(0)
+            tu = time.perf_counter()
+            t1.run()
+            du = time.perf_counter() - tu
+            su = t1.stats()
+            if roofline["kernel"] == "co_k_mcts_step":
+                a1 = su["searches"] * BYTES_PER_SIM / max(su["mcts_ms"] * 1e-3, 1e-12) / 1e9
+                l1 = su["mcts_ms"] / max(su["mcts_launches"], 1)
+            else:
+                a1 = su["nn_rows"] * flop_per_row / max(su["nn_ms"] * 1e-3, 1e-12) / 1e12
+                l1 = su["nn_ms"] / max(su["nn_launches"], 1)
+            roofline["unshared"] = {"achieved": a1, "frac": a1 / roofline["peak"], "avg_launch_ms": l1,
+                                    "games_per_s_single_pool": G / du,
+                                    "note": "same kernel, same workload, one pool on one stream (nothing else on the GPU)"}
+            del t1
         out = {
             "metric": "self-play games/sec at %d sims/move" % args.sims,
             "value": value,
@@ -258,8 +290,8 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "%d parallel self-play games per GPU, %d sims/move, %d searches/eval, %s (random init, seed 0), "
-                            "fused on-device search + inference, %s" % (G, args.sims, args.spe, args.net,
-                                                                        "staggered start" if args.stagger else "no stagger"),
+                            "fused on-device search + inference, %d pool(s) per GPU, %s"
+                            % (G, args.sims, args.spe, args.net, npools, "staggered start" if args.stagger else "no stagger"),
                 "games_per_gpu": G, "sims_per_move": args.sims, "searches_per_eval": args.spe, "net": args.net,
                 "c_puct": args.c_puct, "epsilon": args.epsilon, "parallelism": "games sharded x%d" % world,
             },

@@ -34,6 +34,7 @@ class CaConfig(C.Structure):
         ("trace", C.c_int32),
         ("game_base", C.c_int32),
         ("total_games", C.c_int32),
+        ("pools", C.c_int32),
     ]
 
 
@@ -51,6 +52,7 @@ class CaStats(C.Structure):
         ("mcts_launches", C.c_int64),
         ("nn_launches", C.c_int64),
         ("nn_rows", C.c_int64),
+        ("pools", C.c_int64),
     ]
 
 

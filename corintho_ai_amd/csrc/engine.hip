@@ -80,6 +80,21 @@ struct DevBuf {
   ~DevBuf() { release(); }
 };
 
+#define CO_MAX_POOLS 4
+#define CO_POOL_POLL 8 /* fused training: iterations between polls of a pool's counter */
+
+/* one independent slice of the games in fused training (run_pools) */
+struct Pool {
+  rt_stream_t st;
+  int lo, n, row_base;
+  bool finished;
+  int idle;
+  rt_event_t ev[2][CO_POOL_POLL * 3]; /* per window parity: start / after search / after network */
+  rt_event_t polled[2];
+  int launched[2];          /* iterations recorded in ev[parity] */
+  unsigned long long *word; /* pinned: counter word copied at the end of window parity 0 / 1 */
+};
+
 struct ca_trainer {
   ca_config cfg;
   int G = 0, spe = 0;
@@ -105,7 +120,22 @@ struct ca_trainer {
   double mcts_ms = 0, nn_ms = 0, pack_ms = 0;
   int64_t mcts_launches = 0, nn_launches = 0, nn_rows = 0;
 
-  ~ca_trainer() { rt_stream_destroy(stream); }
+  std::vector<Pool> pools;
+  void free_pools() {
+    for (auto &q : pools) {
+      for (int w = 0; w < 2; ++w) {
+        for (auto &e : q.ev[w]) rt_event_destroy(e);
+        rt_event_destroy(q.polled[w]);
+      }
+      rt_host_free(q.word);
+      rt_stream_destroy(q.st);
+    }
+    pools.clear();
+  }
+  ~ca_trainer() {
+    free_pools();
+    rt_stream_destroy(stream);
+  }
 
   void init(const ca_config &c) {
     cfg = c;
@@ -141,7 +171,7 @@ struct ca_trainer {
     if (cfg.trace) trace.alloc((size_t)G * CO_TRACE_CAP);
     all_done.alloc(1);
     row_counter.alloc(1);
-    pack_counter.alloc(2);
+    pack_counter.alloc(2 * CO_MAX_POOLS);
 
     reset_games(cfg.seed);
     memset(&P, 0, sizeof P);
@@ -179,7 +209,7 @@ struct ca_trainer {
     rt_h2d(games.p, hg.data(), hg.size() * sizeof(GameCtl), stream);
     rt_h2d(trees.p, ht.data(), ht.size() * sizeof(TreeCtl), stream);
     rt_memset(row_counter.p, 0, 8, stream);
-    rt_memset(pack_counter.p, 0, 16, stream);
+    rt_memset(pack_counter.p, 0, 16 * CO_MAX_POOLS, stream);
     rt_sync(stream);
     iterations = 0;
     trainer_iteration = 0;
@@ -224,6 +254,9 @@ struct ca_trainer {
     P.row_counter = nullptr; /* counted in fused mode only */
     P.fused_pack = 0;
     P.defer_handover = 0;
+    P.pool_lo = 0;
+    P.pool_n = G;
+    P.pool_row_base = 0;
     P.pack_counter = pack_counter.p;
 #ifdef CO_PROF
     prof.alloc((size_t)G * 16 + 24);
@@ -442,109 +475,195 @@ struct ca_trainer {
     nets[slot]->forward(d_in, rows_cap, d_rows, d_eval, d_probs, stream);
   }
 
+  /* Fused training as independent pools of games on separate streams:
+   * every pool runs the loop of main.pyx:142-168 on its own slice of the game arrays and of
+   * the batch buffers; the GPU overlaps one pool's search kernel with another's network
+   * kernel and fills launch tails.  Per-game results do not depend on the pooling. */
+  bool run_pools(int64_t max_iterations, int npools) {
+    const int poll = CO_POOL_POLL;
+    if ((int)pools.size() != npools) {
+      free_pools();
+      pools.resize(npools);
+      for (int p = 0; p < npools; ++p) {
+        Pool &q = pools[p];
+        rt_stream_create(&q.st);
+        q.lo = (int)((int64_t)G * p / npools);
+        q.n = (int)((int64_t)G * (p + 1) / npools) - q.lo;
+        q.row_base = q.lo * spe;
+        for (int w = 0; w < 2; ++w) {
+          for (auto &e : q.ev[w]) rt_event_create(&e);
+          rt_event_create(&q.polled[w]);
+        }
+        rt_host_alloc((void **)&q.word, 16);
+      }
+    }
+    for (auto &q : pools) {
+      q.finished = false;
+      q.idle = 0;
+      q.launched[0] = q.launched[1] = 0;
+    }
+    rt_sync(stream);
+    P.to_play = -1;
+    P.row_counter = nullptr;
+    P.fused_pack = 1;
+    P.defer_handover = 1;
+    int64_t it = 0;
+    int in_window = 0, window = 0;
+    bool all_finished = false;
+    std::string failure;
+    /* The host never waits for the window it has just queued: at the end of window w it queues
+     * an asynchronous copy of each pool's counter and then reads the copy made at the end of
+     * window w-1, so every stream always holds at least one window of work.  A pool is
+     * therefore seen to be finished one window late; the launches in between find no running
+     * game and no batch row. */
+    auto collect = [&](Pool &q, int parity) {
+      if (!q.launched[parity]) return;
+      rt_event_sync(q.polled[parity]);
+      for (int k = 0; k < q.launched[parity]; ++k) {
+        mcts_ms += rt_event_elapsed_ms(q.ev[parity][k * 3], q.ev[parity][k * 3 + 1]);
+        nn_ms += rt_event_elapsed_ms(q.ev[parity][k * 3 + 1], q.ev[parity][k * 3 + 2]);
+      }
+      q.launched[parity] = 0;
+      unsigned long long c = q.word[parity];
+      q.finished = (c >> 32) == 0;
+      if (!q.finished && (c & 0xFFFFFFFFull) == 0) {
+        if (++q.idle > 16) failure = "No requests during training"; /* main.pyx:161-163 */
+      } else {
+        q.idle = 0;
+      }
+    };
+    while (!all_finished && (max_iterations <= 0 || it < max_iterations)) {
+      const int parity = window & 1;
+      for (int p = 0; p < npools; ++p) {
+        Pool &q = pools[p];
+        if (q.finished) continue;
+        EngineParams pp = P;
+        pp.iteration = trainer_iteration;
+        pp.pool_lo = q.lo;
+        pp.pool_n = q.n;
+        pp.pool_row_base = q.row_base;
+        pp.pack_counter = pack_counter.p + 2 * p;
+        rt_event_t *e = &q.ev[parity][in_window * 3];
+        rt_event_record(e[0], q.st);
+        RT_LAUNCH(co_k_mcts_step, q.n, CO_WAVE, q.st, pp);
+        rt_event_record(e[1], q.st);
+        const int32_t *d_rows = (const int32_t *)(pack_counter.p + 2 * p + (trainer_iteration & 1));
+        nets[0]->forward(nn_in.p + (size_t)q.row_base * CO_STATE_STRIDE, q.n * spe, d_rows, nn_eval.p + q.row_base,
+                         nn_probs.p + (size_t)q.row_base * CO_NUM_MOVES, q.st);
+        rt_event_record(e[2], q.st);
+        q.launched[parity] = in_window + 1;
+        ++mcts_launches;
+        ++nn_launches;
+      }
+      const int counter_slot = trainer_iteration & 1;
+      ++trainer_iteration;
+      ++iterations;
+      ++it;
+      ++in_window;
+      if (in_window == poll || (max_iterations > 0 && it == max_iterations)) {
+        for (auto &q : pools) {
+          if (q.finished) continue;
+          rt_d2h(&q.word[parity], pack_counter.p + 2 * (&q - &pools[0]) + counter_slot, 8, q.st);
+          rt_event_record(q.polled[parity], q.st);
+        }
+        all_finished = true;
+        for (auto &q : pools) {
+          if (!q.finished) collect(q, parity ^ 1);
+          if (!q.finished) all_finished = false;
+        }
+        in_window = 0;
+        ++window;
+        if (!failure.empty()) break;
+      }
+    }
+    /* drain: read what is still in flight (the last window, or both after an iteration cap) */
+    for (auto &q : pools) {
+      rt_sync(q.st);
+      for (int w = 0; w < 2; ++w) collect(q, (window + w) & 1);
+    }
+    P.fused_pack = 0;
+    P.defer_handover = 0;
+    P.pool_lo = 0;
+    P.pool_n = G;
+    P.pool_row_base = 0;
+    P.pack_counter = pack_counter.p;
+    host_games_valid = false;
+    scan_valid_for = -99;
+    if (!failure.empty()) throw EngineError(CA_ERR_ENGINE, failure);
+    pack(-1); /* refresh the done flag and the batch description */
+    check_errors();
+    nn_rows = 0;
+    for (int g = 0; g < G; ++g) nn_rows += host_games[g].evals; /* every consumed row was evaluated once */
+    return finished;
+  }
+
   bool run(int64_t max_iterations) {
     if (!nets[0]) throw EngineError(CA_ERR_STATE, "ca_trainer_run: no network set (ca_trainer_set_net)");
     if (cfg.testing && !nets[1]) throw EngineError(CA_ERR_STATE, "arena mode needs both networks");
-    const bool self_pack = !cfg.testing; /* training: K3 packs its own requests, no K4 */
-    const int poll = cfg.testing ? 1 : 8; /* iterations between host polls of the done flag */
-    std::vector<rt_event_t> ev((size_t)poll * 4);
+    if (!cfg.testing) {
+      int npools = cfg.pools > 0 ? cfg.pools : (G >= 2048 ? 2 : 1);
+      if (npools > CO_MAX_POOLS) npools = CO_MAX_POOLS;
+      if (npools > G) npools = G;
+      return run_pools(max_iterations, npools);
+    }
+    /* arena (main.pyx:142-168 with is_testing): one model is served per iteration and the
+     * host flips the model when the batch comes back empty, so every iteration is polled;
+     * requests are packed by K4 in game order (the reference's request order) */
+    std::vector<rt_event_t> ev(4);
     for (auto &e : ev) rt_event_create(&e);
-    int to_play = cfg.testing ? 0 : -1;
+    int to_play = 0;
     if (iterations == 0) rt_memset(req_offset.p, 0, ((size_t)G + 1) * 4, stream);
-    P.row_counter = self_pack ? nullptr : row_counter.p;
-    P.fused_pack = self_pack ? 1 : 0;
-    P.defer_handover = self_pack ? 1 : 0;
+    P.row_counter = row_counter.p;
+    P.fused_pack = 0;
+    P.defer_handover = 0;
     int64_t it = 0;
     int idle_flips = 0;
-    int in_window = 0;
     while (!finished && (max_iterations <= 0 || it < max_iterations)) {
-      /* main.pyx:142-168: doIteration -> requests -> predict, all on the device */
       P.to_play = to_play;
       P.iteration = trainer_iteration;
-      rt_event_t *e = &ev[(size_t)in_window * 4];
-      if (!self_pack && iterations > 0) RT_LAUNCH(co_k_scan, 1, CO_WAVE, stream, P); /* offsets at entry (trainer.cpp:208-215) */
-      rt_event_record(e[0], stream);
+      if (iterations > 0) RT_LAUNCH(co_k_scan, 1, CO_WAVE, stream, P); /* offsets at entry (trainer.cpp:208-215) */
+      rt_event_record(ev[0], stream);
       RT_LAUNCH(co_k_mcts_step, G, CO_WAVE, stream, P);
-      rt_event_record(e[1], stream);
-      const int32_t *d_rows;
-      if (self_pack) {
-        d_rows = (const int32_t *)(pack_counter.p + (trainer_iteration & 1)); /* low word = rows */
-      } else {
-        RT_LAUNCH(co_k_scan, 1, CO_WAVE, stream, P);
-        RT_LAUNCH(co_k_compact, G, CO_WAVE, stream, P);
-        d_rows = req_offset.p + G;
-      }
-      rt_event_record(e[2], stream);
-      int slot = (cfg.testing && to_play == 0) ? 1 : 0; /* get_predictions, main.pyx:74-81 */
-      nets[slot]->forward(nn_in.p, G * spe, d_rows, nn_eval.p, nn_probs.p, stream);
-      rt_event_record(e[3], stream);
-      const int counter_slot = trainer_iteration & 1;
-      if (to_play == -1) ++trainer_iteration;
+      rt_event_record(ev[1], stream);
+      RT_LAUNCH(co_k_scan, 1, CO_WAVE, stream, P);
+      RT_LAUNCH(co_k_compact, G, CO_WAVE, stream, P);
+      rt_event_record(ev[2], stream);
+      int slot = to_play == 0 ? 1 : 0; /* get_predictions, main.pyx:74-81 */
+      nets[slot]->forward(nn_in.p, G * spe, req_offset.p + G, nn_eval.p, nn_probs.p, stream);
+      rt_event_record(ev[3], stream);
       ++iterations;
       ++it;
       ++mcts_launches;
       ++nn_launches;
-      ++in_window;
-      if (in_window == poll || (max_iterations > 0 && it == max_iterations)) {
-        int32_t tot_done[2];
-        if (self_pack) {
-          unsigned long long c = 0;
-          rt_d2h(&c, pack_counter.p + counter_slot, 8, stream);
-          rt_sync(stream);
-          tot_done[0] = (int32_t)(c & 0xFFFFFFFFull);
-          tot_done[1] = (c >> 32) == 0; /* no game still running */
+      int32_t tot_done[2];
+      rt_d2h(&tot_done[0], req_offset.p + G, 4, stream);
+      rt_d2h(&tot_done[1], all_done.p, 4, stream);
+      rt_sync(stream);
+      finished = tot_done[1] != 0;
+      mcts_ms += rt_event_elapsed_ms(ev[0], ev[1]);
+      pack_ms += rt_event_elapsed_ms(ev[1], ev[2]);
+      nn_ms += rt_event_elapsed_ms(ev[2], ev[3]);
+      if (!finished) {
+        /* main.pyx:150-154: flip the model when it has no request */
+        if (tot_done[0] == 0) {
+          to_play = 1 - to_play;
+          if (++idle_flips > 4) throw EngineError(CA_ERR_ENGINE, "arena: no model has requests");
         } else {
-          rt_d2h(&tot_done[0], req_offset.p + G, 4, stream);
-          rt_d2h(&tot_done[1], all_done.p, 4, stream);
-          rt_sync(stream);
-        }
-        finished = tot_done[1] != 0;
-        for (int k = 0; k < in_window; ++k) {
-          rt_event_t *q = &ev[(size_t)k * 4];
-          mcts_ms += rt_event_elapsed_ms(q[0], q[1]);
-          pack_ms += rt_event_elapsed_ms(q[1], q[2]);
-          nn_ms += rt_event_elapsed_ms(q[2], q[3]);
-        }
-        in_window = 0;
-        if (cfg.testing && !finished) {
-          /* main.pyx:150-154: flip the model when it has no request */
-          if (tot_done[0] == 0) {
-            to_play = 1 - to_play;
-            if (++idle_flips > 4) throw EngineError(CA_ERR_ENGINE, "arena: no model has requests");
-          } else {
-            idle_flips = 0;
-          }
-        }
-        /* main.pyx:161-163 raises when a training iteration yields no request.  With deferred
-         * hand-overs a single empty batch is legal (every running game may be between turns),
-         * so only a run of empty polls means that no game can make progress any more. */
-        if (!cfg.testing && !finished) {
-          if (tot_done[0] == 0) {
-            if (++idle_flips > 16) throw EngineError(CA_ERR_ENGINE, "No requests during training");
-          } else {
-            idle_flips = 0;
-          }
+          idle_flips = 0;
         }
       }
     }
     rt_sync(stream);
     for (auto &e : ev) rt_event_destroy(e);
     P.row_counter = nullptr;
-    P.fused_pack = 0;
-    P.defer_handover = 0;
     host_games_valid = false;
     scan_valid_for = -99;
     pack(to_play); /* refresh the done flag and the batch description */
     check_errors();
-    if (self_pack) {
-      nn_rows = 0;
-      for (int g = 0; g < G; ++g) nn_rows += host_games[g].evals; /* every consumed row was evaluated once */
-    } else {
-      unsigned long long rows = 0;
-      rt_d2h(&rows, row_counter.p, 8, stream);
-      rt_sync(stream);
-      nn_rows = (int64_t)rows;
-    }
+    unsigned long long rows = 0;
+    rt_d2h(&rows, row_counter.p, 8, stream);
+    rt_sync(stream);
+    nn_rows = (int64_t)rows;
     return finished;
   }
 };
@@ -722,6 +841,7 @@ extern "C" int ca_trainer_stats(ca_trainer *t, ca_stats *out) {
     out->mcts_launches = t->mcts_launches;
     out->nn_launches = t->nn_launches;
     out->nn_rows = t->nn_rows;
+    out->pools = t->pools.empty() ? 1 : (int64_t)t->pools.size();
   })
 }
 

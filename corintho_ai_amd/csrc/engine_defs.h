@@ -123,6 +123,10 @@ struct EngineParams {
    * cleared for the next iteration.  The network kernels read the low word. */
   int32_t fused_pack;
   int32_t defer_handover; /* fused mode: end a game's step at the hand-over (see mcts.h co_choose_move_and_continue) */
+  /* fused training runs the games as independent pools on separate streams, so that one pool's
+   * search overlaps another pool's network kernel: this launch covers games [pool_lo, pool_lo +
+   * pool_n) and its batch rows start at row pool_row_base of nn_in / nn_eval / nn_probs */
+  int32_t pool_lo, pool_n, pool_row_base;
   unsigned long long *pack_counter; /* [2] */
   unsigned long long *prof;         /* [G][8] cycle stamps, profiling builds (-DCO_PROF) only */
 };

@@ -13,8 +13,8 @@ CO_CONST int32_t CO_SPACE_SYM[8][16] = CO_SPACE_SYM_INIT;
 CO_CONST int32_t CO_MOVE_SYM[8][96] = CO_MOVE_SYM_INIT;
 
 CO_KERNEL co_k_mcts_step(EngineParams P) {
-  int g = CO_BLOCK_IDX;
-  if (g < P.num_games) co_mcts_step_wave(P, g);
+  int g = P.pool_lo + CO_BLOCK_IDX;
+  if (CO_BLOCK_IDX < P.pool_n && g < P.num_games) co_mcts_step_wave(P, g);
 }
 
 /* is game g part of the batch of model `to_play` (trainer.cpp:42-46, 84-98)? */

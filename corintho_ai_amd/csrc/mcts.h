@@ -1143,7 +1143,7 @@ CO_DEV int co_sp_do_iteration(CoWave &w, const float *eval, const float *probs) 
 /* Trainer::doIteration for game g (trainer.cpp:164-236): the body of the
  * `omp parallel for`, one wavefront per game. */
 CO_DEV void co_mcts_step_wave(const EngineParams &P, int g) {
-  if (P.fused_pack && g == 0) {
+  if (P.fused_pack && g == P.pool_lo) {
     FOR_LANES {
       if (lane == 0) P.pack_counter[(P.iteration + 1) & 1] = 0ull;
     }
@@ -1199,7 +1199,7 @@ CO_DEV void co_mcts_step_wave(const EngineParams &P, int g) {
      * (any order: a row's evaluation does not depend on its position) and copy */
     int n = w.gc.n_pending;
     unsigned long long old = co_atomic_add_u64(P.pack_counter + (P.iteration & 1), (1ull << 32) | (unsigned long long)n);
-    int base = (int)(unsigned)(old & 0xFFFFFFFFull);
+    int base = P.pool_row_base + (int)(unsigned)(old & 0xFFFFFFFFull);
     w.gc.row_off = base;
     const float *src = w.req;
     float *dst = P.nn_in + (size_t)base * CO_STATE_STRIDE;

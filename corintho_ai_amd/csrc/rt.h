@@ -31,6 +31,7 @@ inline void rt_stream_destroy(rt_stream_t) {}
 inline void rt_event_create(rt_event_t *) {}
 inline void rt_event_destroy(rt_event_t) {}
 inline void rt_event_record(rt_event_t, rt_stream_t) {}
+inline void rt_event_sync(rt_event_t) {}
 inline float rt_event_elapsed_ms(rt_event_t, rt_event_t) { return 0.0f; }
 inline void rt_host_alloc(void **p, size_t n) { rt_malloc(p, n); }
 inline void rt_host_free(void *p) { free(p); }
@@ -80,6 +81,7 @@ inline void rt_stream_destroy(rt_stream_t s) { (void)hipStreamDestroy(s); }
 inline void rt_event_create(rt_event_t *e) { RT_CHECK(hipEventCreate(e)); }
 inline void rt_event_destroy(rt_event_t e) { (void)hipEventDestroy(e); }
 inline void rt_event_record(rt_event_t e, rt_stream_t s) { RT_CHECK(hipEventRecord(e, s)); }
+inline void rt_event_sync(rt_event_t e) { RT_CHECK(hipEventSynchronize(e)); }
 inline float rt_event_elapsed_ms(rt_event_t a, rt_event_t b) {
   float ms = 0.0f;
   RT_CHECK(hipEventElapsedTime(&ms, a, b));

@@ -62,6 +62,9 @@ typedef struct ca_config {
    * order and parity = global index % 2 (trainer.cpp:243-255).  0/0 = unsharded. */
   int32_t game_base;
   int32_t total_games;
+  /* fused training: number of independent game pools run on separate HIP streams of the same
+   * GPU (one pool's search overlaps another's network kernel); 0 = automatic */
+  int32_t pools;
 } ca_config;
 
 const char *ca_last_error(void);
@@ -140,6 +143,7 @@ typedef struct ca_stats {
   double mcts_ms, nn_ms, pack_ms; /* device time by kernel family (fused mode, HIP events) */
   int64_t mcts_launches, nn_launches;
   int64_t nn_rows;       /* rows evaluated by the network kernels */
+  int64_t pools;         /* pools the last ca_trainer_run used (1 in arena mode) */
 } ca_stats;
 int ca_trainer_stats(ca_trainer *t, ca_stats *out);
 /* per-game: {to_play, done, result, n_samples, n_pending, error, mate_turn, plies} */

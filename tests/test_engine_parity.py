@@ -310,6 +310,29 @@ def test_fused_mode_equals_compat_mode_with_same_network(engine):
 
 
 @pytest.mark.parametrize("engine", ENGINES)
+def test_fused_pools_do_not_change_any_game(engine):
+    """fused training split into independent pools on separate streams (ca_config.pools):
+    samples, score and per-game evaluation counts are those of the single-pool run, for
+    even and ragged splits, staggered starts and a run resumed after an iteration cap"""
+    G, S_, spe = 13, 40, 8
+    w = nets.init_mlp12x100(seed=3, bn_noise=True)
+    runs = []
+    for pools in (1, 2, 3, 4):
+        t = make_trainer(engine, G, "", 77, S_, spe, 1.0, 0.25, 0, 1, False, pools=pools)
+        t.set_net(1, w)
+        if pools == 3:
+            assert not t.run(max_iterations=11)
+            assert not t.run(max_iterations=5)
+        assert t.run()
+        runs.append((H.get_samples(t), t.score(), t.stats()["nn_rows"]))
+    for r in runs[1:]:
+        for x, y in zip(r[0], runs[0][0]):
+            assert x.tobytes() == y.tobytes()
+        assert r[1] == runs[0][1]
+        assert r[2] == runs[0][2]
+
+
+@pytest.mark.parametrize("engine", ENGINES)
 def test_mlp_matches_float32_restatement(engine):
     """policy/value within 1e-4 (fp32) of the numpy restatement of wrapper.py:256-271"""
     G, spe = 64, 16
