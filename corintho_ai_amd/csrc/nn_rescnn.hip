@@ -163,11 +163,14 @@ __device__ __forceinline__ void rc_epilogue(float (&out)[RC_NB][4][4], const f32
 
 /* ---- heads, shared by both precisions: x = the trunk output of this wave's RC_NB
  * positions (fp32, accumulator layout); feat_w = RC_NB x 96 floats of LDS owned by the wave */
-__device__ __forceinline__ void rc_heads_dense(const RcParams &P, const float *feat_w, int rows, int pos_base, int lane,
-                                               int q, int c);
+__device__ __forceinline__ void rc_dense_policy(const RcParams &P, const float *wpol, const float *feat16, int rows,
+                                                int pos_base, int lane);
+__device__ __forceinline__ void rc_dense_value(const RcParams &P, const float *wv1, const float *wv2, const float *feat16,
+                                               int rows, int pos_base, int lane);
 
-__device__ __forceinline__ void rc_heads(const RcParams &P, const float (&x)[RC_NB][4][4], float *feat_w, int rows,
-                                         int pos_base, int lane, int q, int c) {
+__device__ __forceinline__ void rc_heads(const RcParams &P, const float (&x)[RC_NB][4][4], float *feat_wg, int wave,
+                                         int rows, int row0, int lane, int q, int c) {
+  float *feat_w = feat_wg + wave * RC_NB * 96;
   /* ---- heads.  1x1 convolutions: out rows 0..3 policy planes, 4..5 value planes */
   f32x4 h1[RC_NB];
 #pragma unroll
@@ -200,47 +203,29 @@ __device__ __forceinline__ void rc_heads(const RcParams &P, const float (&x)[RC_
       }
   }
   __syncthreads();
-  rc_heads_dense(P, feat_w, rows, pos_base, lane, q, c);
+  /* the workgroup's 16 positions = one column tile: wave 0 policy, wave 1 value */
+  if (wave == 0) rc_dense_policy(P, P.wpol, feat_wg, rows, row0, lane);
+  if (wave == 1) rc_dense_value(P, P.wv1, P.wv2, feat_wg, rows, row0, lane);
 }
 
-/* dense layers + softmax/tanh on the RC_NB positions whose flattened head features sit in
- * feat_w (policy [0,64), value [64,96) per position); MFMA columns = positions */
-__device__ __forceinline__ void rc_heads_dense(const RcParams &P, const float *feat_w, int rows, int pos_base, int lane,
-                                               int q, int c) {
-  /* dense layers with the wave's positions as MFMA columns (column c < RC_NB) */
-  const bool col_ok = c < RC_NB;
-  const float *feat = feat_w + (col_ok ? c : 0) * 96;
+/* Dense heads on 16 positions at once (one full MFMA column tile): `feat` = 16 x 96 floats of
+ * LDS (flattened head features of consecutive positions pos_base .. pos_base + 15), column c =
+ * position.  One wave runs the policy head (Dense 64 -> 96, softmax) of a tile, another its
+ * value head (Dense 32 -> 64, ReLU, Dense 64 -> 1, tanh), so the dense weights are read once
+ * per 16 positions and no MFMA column is idle. */
+__device__ __forceinline__ void rc_dense_policy(const RcParams &P, const float *wpol, const float *feat16, int rows,
+                                                int pos_base, int lane) {
+  const int q = lane >> 4, c = lane & 15;
+  const float *feat = feat16 + c * 96;
   f32x4 pl[6];
 #pragma unroll
   for (int to = 0; to < 6; ++to) pl[to] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int s = 0; s < 16; ++s) {
-    const float b = col_ok ? feat[4 * s + q] : 0.0f;
+    const float b = feat[4 * s + q];
 #pragma unroll
     for (int to = 0; to < 6; ++to)
-      pl[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(P.wpol[(s * 6 + to) * 64 + lane], b, pl[to], 0, 0, 0);
-  }
-  f32x4 v1[4];
-#pragma unroll
-  for (int to = 0; to < 4; ++to) v1[to] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int s = 0; s < 8; ++s) {
-    const float b = col_ok ? feat[64 + 4 * s + q] : 0.0f;
-#pragma unroll
-    for (int to = 0; to < 4; ++to)
-      v1[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(P.wv1[(s * 4 + to) * 64 + lane], b, v1[to], 0, 0, 0);
-  }
-  f32x4 v2 = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const float4 b4 = *reinterpret_cast<const float4 *>(P.bv1 + 16 * t + 4 * q);
-    const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float hv = v1[t][r] + bb[r];
-      hv = hv > 0.0f ? hv : 0.0f;
-      v2 = __builtin_amdgcn_mfma_f32_16x16x4f32(P.wv2[(t * 4 + r) * 64 + lane], hv, v2, 0, 0, 0);
-    }
+      pl[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(wpol[(s * 6 + to) * 64 + lane], b, pl[to], 0, 0, 0);
   }
   /* softmax over the 96 logits of column c: registers (to, r) in the lane, q across lanes */
   float lg[6][4];
@@ -264,20 +249,51 @@ __device__ __forceinline__ void rc_heads_dense(const RcParams &P, const float *f
   for (int to = 0; to < 6; ++to)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      lg[to][r] = expf(lg[to][r] - m);
+      /* exp(x) = 2^(x log2 e) on the hardware exponential (1 ulp; x <= 0 here) */
+      lg[to][r] = __builtin_amdgcn_exp2f((lg[to][r] - m) * 1.44269504088896340736f);
       sum += lg[to][r];
     }
   sum += __shfl_xor(sum, 16, 64);
   sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.0f / sum;
   const int pos = pos_base + c;
-  if (col_ok && pos < rows) {
+  if (pos < rows) {
 #pragma unroll
     for (int to = 0; to < 6; ++to) {
-      float4 p = make_float4(lg[to][0] / sum, lg[to][1] / sum, lg[to][2] / sum, lg[to][3] / sum);
+      float4 p = make_float4(lg[to][0] * inv, lg[to][1] * inv, lg[to][2] * inv, lg[to][3] * inv);
       *reinterpret_cast<float4 *>(P.probs + (size_t)pos * CO_NUM_MOVES + 16 * to + 4 * q) = p;
     }
-    if (q == 0) P.eval[pos] = tanhf(v2[0] + P.bv2[0]);
   }
+}
+
+__device__ __forceinline__ void rc_dense_value(const RcParams &P, const float *wv1, const float *wv2, const float *feat16,
+                                               int rows, int pos_base, int lane) {
+  const int q = lane >> 4, c = lane & 15;
+  const float *feat = feat16 + c * 96;
+  f32x4 v1[4];
+#pragma unroll
+  for (int to = 0; to < 4; ++to) v1[to] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const float b = feat[64 + 4 * s + q];
+#pragma unroll
+    for (int to = 0; to < 4; ++to)
+      v1[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv1[(s * 4 + to) * 64 + lane], b, v1[to], 0, 0, 0);
+  }
+  f32x4 v2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const float4 b4 = *reinterpret_cast<const float4 *>(P.bv1 + 16 * t + 4 * q);
+    const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float hv = v1[t][r] + bb[r];
+      hv = hv > 0.0f ? hv : 0.0f;
+      v2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv2[(t * 4 + r) * 64 + lane], hv, v2, 0, 0, 0);
+    }
+  }
+  const int pos = pos_base + c;
+  if (q == 0 && pos < rows) P.eval[pos] = tanhf(v2[0] + P.bv2[0]);
 }
 
 __global__ __launch_bounds__(256, 2) void co_k_rescnn_forward(RcParams P) {
@@ -323,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void co_k_rescnn_forward(RcParams P) {
     rc_epilogue<true, true>(x, acc, x, P.epi + (size_t)(2 + 2 * b) * 192, q);
   }
 
-  rc_heads(P, x, &lds_feat[wave][0][0], rows, row0 + wave * RC_NB, lane, q, c);
+  rc_heads(P, x, &lds_feat[0][0][0], wave, rows, row0, lane, q, c);
 }
 
 /* ======================================================================
@@ -351,7 +367,10 @@ __global__ __launch_bounds__(256, 2) void co_k_rescnn_forward(RcParams P) {
 #define RC3_STEM_CHUNK 1024 /* u32: 1 k-step x 2 out tiles x {hi,lo} x 64 lanes x 4 */
 #define RC3_CONV_CHUNK 4096 /* u32: 4 k-steps ... = 16 KB */
 #define RC3_TRUNK_WORDS (9 * RC3_STEM_CHUNK + 72 * RC3_CONV_CHUNK)
-#define RC3_LDS_BYTES (2 * 3 * RC3_CONV_CHUNK * 4 + 8 * RC_NB * 96 * 4)
+/* head weights staged once per workgroup behind the two trunk groups and the head features:
+ * 1x1 fragments (2048 words), policy dense (6144), value dense 1 (2048), value dense 2 (1024) */
+#define RC3_HEAD_WORDS (2048 + 6144 + 2048 + 1024)
+#define RC3_LDS_BYTES (2 * 3 * RC3_CONV_CHUNK * 4 + 8 * RC_NB * 96 * 4 + RC3_HEAD_WORDS * 4)
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -362,7 +381,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 struct Rc3Params {
   RcParams base;          /* dense heads + epilogue parameters, in/out pointers */
   const uint32_t *wtrunk; /* RC3_TRUNK_WORDS, bf16 hi/lo fragments */
-  const float *whead32;   /* [32 steps][64 lanes] 1x1 convs in the 32x32x2 operand order */
+  const uint32_t *whead3; /* RC3_HEAD_WORDS: [4 steps][hi, lo][64 lanes][4 words] 1x1 head convs in fragment order,
+                           * then the fp32 dense weights wpol, wv1, wv2 as in RcParams */
 };
 
 /* weights stream through LDS in groups of three taps (one kernel row): 27 groups, group
@@ -528,6 +548,22 @@ __device__ __forceinline__ void rc3_epilogue(float (&out)[RC3_NP][2][16], const 
     }
 }
 
+#ifdef CO_PROF
+/* diagnostic builds: cycles of wave 0 of every workgroup by phase (tools/prof_nn.py) */
+__device__ unsigned long long rc3_prof[8];
+#define RC3_STAMP(slot)                                                              \
+  {                                                                                  \
+    unsigned long long now_ = __builtin_readcyclecounter();                          \
+    if (tid == 0) atomicAdd(&rc3_prof[slot], now_ - stamp_);                         \
+    stamp_ = now_;                                                                   \
+  }
+extern "C" int ca_net_prof(unsigned long long out[8]) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(rc3_prof), sizeof(rc3_prof)) == hipSuccess ? 0 : 1;
+}
+#else
+#define RC3_STAMP(slot)
+#endif
+
 __global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_x3(Rc3Params Q) {
   const RcParams &P = Q.base;
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[]; /* 2 weight groups + head features */
@@ -539,7 +575,16 @@ __global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_x3(Rc3Params Q) {
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, h = lane >> 5, p2 = (lane >> 4) & 1, c = lane & 15;
   const bool okL = (c & 3) != 0, okR = (c & 3) != 3;
+#ifdef CO_PROF
+  unsigned long long stamp_ = __builtin_readcyclecounter();
+  const unsigned long long start_ = stamp_;
+#endif
   rc3_stage(Q.wtrunk, lds_w, 0, wave, lane);
+  /* the head weights ride along with the first group (the wait before the first MFMA covers them) */
+  uint32_t *lds_head = lds_dyn + 2 * RC3_GROUP_WORDS + 8 * RC_NB * 96;
+  for (int p = wave; p < RC3_HEAD_WORDS / 256; p += 8)
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(Q.whead3 + p * 256 + lane * 4),
+                                     (void __attribute__((address_space(3))) *)(lds_head + p * 256), 16, 0, 0);
 
   /* input planes: register 4g + i of tile 0 = channel 8g + 4h + i:
    * g 0: h 0 the cell's board bits, h 1 reserves 0..3; g 1: h 0 reserves 4..5 (+ padding), h 1 zeros */
@@ -561,33 +606,54 @@ __global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_x3(Rc3Params Q) {
   }
   uint32_t ph[RC3_NP][4][4], pl[RC3_NP][4][4];
   rc3_pack(ph, pl, x);
+  RC3_STAMP(0)
   f32x16 acc[RC3_NP][2];
   float y[RC3_NP][2][16];
   int ch = 0;
   rc3_conv3x3<1>(acc, ph, pl, ch, Q.wtrunk, lds_w, wave, lane, okL, okR);
+  RC3_STAMP(1)
   rc3_epilogue<false>(x, acc, x, P.epi, h);
   rc3_pack(ph, pl, x);
+  RC3_STAMP(2)
   for (int b = 0; b < 4; ++b) {
     rc3_conv3x3<4>(acc, ph, pl, ch, Q.wtrunk, lds_w, wave, lane, okL, okR);
+    RC3_STAMP(3)
     rc3_epilogue<false>(y, acc, x, P.epi + (size_t)(1 + 2 * b) * 192, h);
     rc3_pack(ph, pl, y);
+    RC3_STAMP(2)
     rc3_conv3x3<4>(acc, ph, pl, ch, Q.wtrunk, lds_w, wave, lane, okL, okR);
+    RC3_STAMP(3)
     rc3_epilogue<true>(x, acc, x, P.epi + (size_t)(2 + 2 * b) * 192, h);
     rc3_pack(ph, pl, x);
+    RC3_STAMP(2)
   }
-  /* heads: the two 1x1 convolutions on v_mfma_f32_32x32x2_f32 (k-slot h <-> channel of
-   * register reg of tile T), fp32; output rows 0..3 policy planes (h 0), 4..5 value (h 1) */
+  /* heads: the two 1x1 convolutions as one more split-precision step on the operands packed
+   * after the last block (no tap shift); output rows 0..3 policy planes (h 0), 4..5 value (h 1) */
   float *feat_w = &lds_feat[wave][0][0];
+  u32x4 hh[4], hl[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    hh[s] = *reinterpret_cast<const u32x4 *>(lds_head + ((s * 2 + 0) * 64 + lane) * 4);
+    hl[s] = *reinterpret_cast<const u32x4 *>(lds_head + ((s * 2 + 1) * 64 + lane) * 4);
+  }
 #pragma unroll
   for (int np = 0; np < RC3_NP; ++np) {
     f32x16 h1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) h1[i] = 0.0f;
 #pragma unroll
-    for (int T = 0; T < 2; ++T)
+    for (int s = 0; s < 4; ++s) {
+      u32x4 bh, bl;
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(Q.whead32[(T * 16 + r) * 64 + lane], x[np][T][r], h1, 0, 0, 0);
+      for (int m = 0; m < 4; ++m) {
+        bh[m] = ph[np][s][m];
+        bl[m] = pl[np][s][m];
+      }
+      const bf16x8 Bh = __builtin_bit_cast(bf16x8, bh), Bl = __builtin_bit_cast(bf16x8, bl);
+      h1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, hh[s]), Bh, h1, 0, 0, 0);
+      h1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, hh[s]), Bl, h1, 0, 0, 0);
+      h1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, hl[s]), Bh, h1, 0, 0, 0);
+    }
     const float4 b4 = *reinterpret_cast<const float4 *>(P.head_epi + 4 * h);
     const float4 a4 = *reinterpret_cast<const float4 *>(P.head_epi + 16 + 4 * h);
     const float4 c4 = *reinterpret_cast<const float4 *>(P.head_epi + 32 + 4 * h);
@@ -604,8 +670,22 @@ __global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_x3(Rc3Params Q) {
       if (h == 1 && r < 2) feat_w[pw * 96 + 64 + c * 2 + r] = v;
     }
   }
+  RC3_STAMP(4)
   __syncthreads();
-  rc_heads_dense(P, feat_w, rows, row0 + wave * 4, lane, lane >> 4, c);
+  /* 32 positions = two column tiles: waves 0, 1 run their policy heads, waves 2, 3 their value heads */
+  const float *lds_dense = reinterpret_cast<const float *>(lds_head + 2048);
+  if (wave < 2)
+    rc_dense_policy(P, lds_dense, &lds_feat[0][0][0] + wave * 16 * 96, rows, row0 + wave * 16, lane);
+  else if (wave < 4)
+    rc_dense_value(P, lds_dense + 6144, lds_dense + 6144 + 2048, &lds_feat[0][0][0] + (wave - 2) * 16 * 96, rows,
+                   row0 + (wave - 2) * 16, lane);
+  RC3_STAMP(5)
+#ifdef CO_PROF
+  if (tid == 0) {
+    atomicAdd(&rc3_prof[6], __builtin_readcyclecounter() - start_);
+    atomicAdd(&rc3_prof[7], 1ull);
+  }
+#endif
 }
 
 /* ------------------------------------------------------------------ host */
@@ -733,7 +813,7 @@ static inline float rc_bf16_to_f(uint16_t h) {
 
 struct ResCnnX3Net : ResCnnNet {
   uint32_t *d_trunk3 = nullptr;
-  float *d_whead32 = nullptr;
+  uint32_t *d_whead3 = nullptr;
   ResCnnX3Net(const float *w, size_t max_rows, rt_stream_t s) : ResCnnNet(w, max_rows, s) {
     std::vector<uint32_t> tr(RC3_TRUNK_WORDS, 0u);
     const float *p = w;
@@ -765,29 +845,37 @@ struct ResCnnX3Net : ResCnnNet {
       off += 9 * chunk;
       p += (size_t)9 * cin * 64 + 5 * 64;
     }
-    /* 1x1 head convolutions in 32x32x2 order: step (T, reg), lane (h, i): channel
-     * 32T + (reg&3) + 8(reg>>2) + 4h, output row i (0..3 policy, 4..5 value) */
+    /* 1x1 head convolutions as hi/lo fragments of one more K loop (same k-slot order as the
+     * trunk): output row i = 0..3 policy planes, 4..5 value planes, the rest zero */
     const float *pk = p, *vk = pk + 64 * 4 + 4 * 5 + 64 * 96 + 96;
-    std::vector<float> wh32(32 * 64, 0.0f);
-    for (int T = 0; T < 2; ++T)
-      for (int r = 0; r < 16; ++r)
-        for (int h = 0; h < 2; ++h)
-          for (int i = 0; i < 32; ++i) {
-            int k = 32 * T + (r & 3) + 8 * (r >> 2) + 4 * h;
+    std::vector<uint32_t> wh3(4 * 2 * 64 * 4, 0u);
+    for (int st = 0; st < 4; ++st)
+      for (int h = 0; h < 2; ++h)
+        for (int i = 0; i < 32; ++i)
+          for (int j = 0; j < 8; ++j) {
+            int T = st >> 1, a = st & 1;
+            int k = 32 * T + 4 * h + 8 * (2 * a + (j >> 2)) + (j & 3);
             float v = i < 4 ? pk[k * 4 + i] : i < 6 ? vk[k * 2 + (i - 4)] : 0.0f;
-            wh32[(size_t)(T * 16 + r) * 64 + 32 * h + i] = v;
+            uint16_t hi = rc_bf16_rne(v);
+            uint16_t lo = rc_bf16_rne(v - rc_bf16_to_f(hi));
+            size_t lane = 32 * h + i;
+            wh3[(((size_t)st * 2 + 0) * 64 + lane) * 4 + j / 2] |= (uint32_t)hi << (16 * (j & 1));
+            wh3[(((size_t)st * 2 + 1) * 64 + lane) * 4 + j / 2] |= (uint32_t)lo << (16 * (j & 1));
           }
     rt_malloc((void **)&d_trunk3, tr.size() * 4);
     rt_h2d(d_trunk3, tr.data(), tr.size() * 4, s);
     RT_CHECK(hipFuncSetAttribute((const void *)co_k_rescnn_forward_x3, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  RC3_LDS_BYTES));
-    rt_malloc((void **)&d_whead32, wh32.size() * 4);
-    rt_h2d(d_whead32, wh32.data(), wh32.size() * 4, s);
+    rt_malloc((void **)&d_whead3, (size_t)RC3_HEAD_WORDS * 4);
+    rt_h2d(d_whead3, wh3.data(), wh3.size() * 4, s);
+    rt_d2d(d_whead3 + 2048, P.wpol, 6144 * 4, s); /* the dense weights in the base class's MFMA order */
+    rt_d2d(d_whead3 + 2048 + 6144, P.wv1, 2048 * 4, s);
+    rt_d2d(d_whead3 + 2048 + 6144 + 2048, P.wv2, 1024 * 4, s);
     rt_sync(s);
   }
   ~ResCnnX3Net() override {
     rt_free(d_trunk3);
-    rt_free(d_whead32);
+    rt_free(d_whead3);
   }
   int kind() const override { return CO_NET_RESCNN4_X3; }
   void forward(const float *d_in, int32_t rows_cap, const int32_t *d_rows, float *d_eval, float *d_probs,
@@ -801,7 +889,7 @@ struct ResCnnX3Net : ResCnnNet {
     q.base.eval = d_eval;
     q.base.probs = d_probs;
     q.wtrunk = d_trunk3;
-    q.whead32 = d_whead32;
+    q.whead3 = d_whead3;
     hipLaunchKernelGGL(co_k_rescnn_forward_x3, dim3(grid), dim3(512), RC3_LDS_BYTES, s, q);
     RT_CHECK(hipGetLastError());
   }
