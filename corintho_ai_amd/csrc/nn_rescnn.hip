@@ -429,27 +429,48 @@ __device__ __forceinline__ uint32_t rc3_tap(uint32_t v, bool okL, bool okR) {
   return s;
 }
 
-/* ph/pl[np][s][m]: K step s = 2T + a, word m = channels (reg 8a + 2m, 8a + 2m + 1) of tile T */
-template <int CS, int TAP>
-__device__ __forceinline__ void rc3_conv_tap(f32x16 (&acc)[RC3_NP][2], const uint32_t (&ph)[RC3_NP][4][4],
-                                             const uint32_t (&pl)[RC3_NP][4][4], const uint32_t *w, int lane, bool okL,
-                                             bool okR) {
-  /* the weight fragments of K step s+1 are requested from LDS before the MFMAs of step s
-   * issue (two register sets), so the LDS latency is paid once per tap, not once per step */
+/* tap as a value: after full unrolling every call site has a constant tap and folds to one case */
+__device__ __forceinline__ uint32_t rc3_tap_sel(uint32_t v, int tap, bool okL, bool okR) {
+  switch (tap) {
+    case 0: return rc3_tap<0>(v, okL, okR);
+    case 1: return rc3_tap<1>(v, okL, okR);
+    case 2: return rc3_tap<2>(v, okL, okR);
+    case 3: return rc3_tap<3>(v, okL, okR);
+    case 4: return rc3_tap<4>(v, okL, okR);
+    case 5: return rc3_tap<5>(v, okL, okR);
+    case 6: return rc3_tap<6>(v, okL, okR);
+    case 7: return rc3_tap<7>(v, okL, okR);
+    default: return rc3_tap<8>(v, okL, okR);
+  }
+}
+
+/* One staged group = taps 3G .. 3G + 2, CS K steps each.  ph/pl[np][s][m]: K step s = 2T + a,
+ * word m = channels (reg 8a + 2m, 8a + 2m + 1) of tile T.  The weight fragments of step i + 1
+ * (also across the tap boundary) are requested from LDS before the MFMAs of step i issue (two
+ * register sets), so the LDS latency is paid once per group. */
+template <int CS, int G>
+__device__ __forceinline__ void rc3_conv_group(f32x16 (&acc)[RC3_NP][2], const uint32_t (&ph)[RC3_NP][4][4],
+                                               const uint32_t (&pl)[RC3_NP][4][4], const uint32_t *wg, int lane,
+                                               bool okL, bool okR) {
+  constexpr int tw = CS == 1 ? RC3_STEM_CHUNK : RC3_CONV_CHUNK;
+  constexpr int N = 3 * CS;
   u32x4 ah[2][2], al[2][2];
 #pragma unroll
   for (int to = 0; to < 2; ++to) {
-    ah[0][to] = *reinterpret_cast<const u32x4 *>(w + (((0 * 2 + to) * 2 + 0) * 64 + lane) * 4);
-    al[0][to] = *reinterpret_cast<const u32x4 *>(w + (((0 * 2 + to) * 2 + 1) * 64 + lane) * 4);
+    ah[0][to] = *reinterpret_cast<const u32x4 *>(wg + (((0 * 2 + to) * 2 + 0) * 64 + lane) * 4);
+    al[0][to] = *reinterpret_cast<const u32x4 *>(wg + (((0 * 2 + to) * 2 + 1) * 64 + lane) * 4);
   }
 #pragma unroll
-  for (int s = 0; s < CS; ++s) {
-    const int cur = s & 1, nxt = cur ^ 1;
-    if (s + 1 < CS) {
+  for (int idx = 0; idx < N; ++idx) {
+    const int cur = idx & 1, nxt = cur ^ 1;
+    const int tg = idx / CS, s = idx % CS;
+    if (idx + 1 < N) {
+      const int tg1 = (idx + 1) / CS, s1 = (idx + 1) % CS;
+      const uint32_t *w1 = wg + tg1 * tw;
 #pragma unroll
       for (int to = 0; to < 2; ++to) {
-        ah[nxt][to] = *reinterpret_cast<const u32x4 *>(w + ((((s + 1) * 2 + to) * 2 + 0) * 64 + lane) * 4);
-        al[nxt][to] = *reinterpret_cast<const u32x4 *>(w + ((((s + 1) * 2 + to) * 2 + 1) * 64 + lane) * 4);
+        ah[nxt][to] = *reinterpret_cast<const u32x4 *>(w1 + (((s1 * 2 + to) * 2 + 0) * 64 + lane) * 4);
+        al[nxt][to] = *reinterpret_cast<const u32x4 *>(w1 + (((s1 * 2 + to) * 2 + 1) * 64 + lane) * 4);
       }
     }
 #pragma unroll
@@ -457,8 +478,8 @@ __device__ __forceinline__ void rc3_conv_tap(f32x16 (&acc)[RC3_NP][2], const uin
       u32x4 bh, bl;
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
-        bh[m] = rc3_tap<TAP>(ph[np][s][m], okL, okR);
-        bl[m] = rc3_tap<TAP>(pl[np][s][m], okL, okR);
+        bh[m] = rc3_tap_sel(ph[np][s][m], 3 * G + tg, okL, okR);
+        bl[m] = rc3_tap_sel(pl[np][s][m], 3 * G + tg, okL, okR);
       }
       const bf16x8 Bh = __builtin_bit_cast(bf16x8, bh), Bl = __builtin_bit_cast(bf16x8, bl);
 #pragma unroll
@@ -489,17 +510,11 @@ __device__ __forceinline__ void rc3_conv3x3(f32x16 (&acc)[RC3_NP][2], const uint
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                         \
     __syncthreads();                                                                         \
     if (ch + 1 < RC3_NUM_GROUPS) rc3_stage(wtrunk, lds_w + ((ch + 1) & 1) * RC3_GROUP_WORDS, ch + 1, wave, lane); \
-    const uint32_t *wg = lds_w + (ch & 1) * RC3_GROUP_WORDS;                                 \
-    constexpr int tw = CS == 1 ? RC3_STEM_CHUNK : RC3_CONV_CHUNK;                            \
-    rc3_conv_tap<CS, 3 * G + 0>(acc, ph, pl, wg, lane, okL, okR);                            \
-    rc3_conv_tap<CS, 3 * G + 1>(acc, ph, pl, wg + tw, lane, okL, okR);                       \
-    rc3_conv_tap<CS, 3 * G + 2>(acc, ph, pl, wg + 2 * tw, lane, okL, okR);                   \
+    rc3_conv_group<CS, G>(acc, ph, pl, lds_w + (ch & 1) * RC3_GROUP_WORDS, lane, okL, okR);  \
     ++ch;                                                                                    \
   }
   RC3_GROUP(0) RC3_GROUP(1) RC3_GROUP(2)
 #undef RC3_GROUP
-#define RC3_TAP(T)
-#undef RC3_TAP
 }
 
 /* fp32 tile values -> the packed hi/lo operands of the next convolution */
