@@ -51,19 +51,20 @@ def parse():
     ap.add_argument("--no-mlp-extra", action="store_true", help="skip the extra generations (other networks) reported under detail.variants")
     ap.add_argument("--stagger", action="store_true", help="keep the reference's staggered start")
     ap.add_argument("--arena-units", type=int, default=0)
+    ap.add_argument("--no-unshared", action="store_true", help="skip the extra single-pool generation behind roofline.unshared (profiling runs)")
     ap.add_argument("--pools", type=int, default=0, help="independent game pools on separate streams per GPU (0 = engine default)")
     ap.add_argument("--cpu-games", type=int, default=64, help="games of the bounded CPU-baseline sample (0 = skip)")
     return ap.parse_args()
 
 
-def measured_traffic(kernel, args):
+def measured_traffic(kernel, args, npools):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
-    (profiles/r01_pmc.json; PMC counters cannot be collected from inside an un-profiled run).
-    Only valid for the workload those passes were taken on; otherwise null."""
-    if (args.games, args.sims, args.spe, args.net) != (4096, 400, 16, "rescnn4x3"):
+    (profiles/r01_d_pmc.json; PMC counters cannot be collected from inside an un-profiled run).
+    Only valid for the workload those passes were taken on (the default one); otherwise null."""
+    if (args.games, args.sims, args.spe, args.net, npools) != (4096, 400, 16, "rescnn4x3", 2):
         return None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r01_d_pmc.json")) as f:
             return json.load(f)["kernels"][kernel]["traffic_bytes_per_launch"]
     except Exception:
         return None
@@ -228,6 +229,7 @@ def main():
         value = games_total / dt
         nn_s = totals["nn_ms"] * 1e-3
         mcts_s = totals["mcts_ms"] * 1e-3
+        npools = int(totals.get("pools", 1))
         # dominant kernel = the family with more device time on rank 0
         if nn_s >= mcts_s:
             achieved = totals["nn_rows"] * flop_per_row / max(nn_s, 1e-12) / 1e12
@@ -236,7 +238,7 @@ def main():
                      "rescnn4x3": "co_k_rescnn_forward_x3"}[args.net]
             roofline = {"kernel": kname,
                         "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                        "frac": achieved / peak, "traffic": measured_traffic(kname, args),
+                        "frac": achieved / peak, "traffic": measured_traffic(kname, args, npools),
                         "issued_frac": (3.0 if args.net == "rescnn4x3" else 1.0) * achieved / peak,
                         "algorithmic": "%.1f KFLOP/row x %d rows" % (flop_per_row / 1e3, totals["nn_rows"]),
                         "avg_launch_ms": totals["nn_ms"] / max(totals["nn_launches"], 1)}
@@ -244,12 +246,11 @@ def main():
             achieved = totals["searches"] * BYTES_PER_SIM / max(mcts_s, 1e-12) / 1e9
             roofline = {"kernel": "co_k_mcts_step", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                        "traffic": measured_traffic("co_k_mcts_step", args),
+                        "traffic": measured_traffic("co_k_mcts_step", args, npools),
                         "algorithmic": "%.0f B/simulation x %d simulations" % (BYTES_PER_SIM, totals["searches"]),
                         "avg_launch_ms": totals["mcts_ms"] / max(totals["mcts_launches"], 1)}
-        npools = int(totals.get("pools", 1))
         roofline["streams"] = npools
-        if npools > 1:
+        if npools > 1 and not args.no_unshared:
             # The timed region runs the games as `npools` pools on separate streams, so the durations
             # above are those of kernels SHARING the GPU with the other pool's kernels (their sum
             # exceeds the wall time).  One more generation with a single pool gives the same kernel's

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Diagnostic A/B: time whole generations with two prebuilt engine libraries in the same process
+on the same GPU, alternating, so that box-to-box variance cancels.
+usage: ab.py libA.so libB.so [net] [games] [reps] [pools]"""
+import ctypes as C
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from corintho_ai_amd import NET_MLP12X100, NET_RESCNN4, NET_RESCNN4_X3, Trainer, _lib, nets  # noqa: E402
+
+libs = sys.argv[1:3]
+net = sys.argv[3] if len(sys.argv) > 3 else "rescnn4x3"
+G = int(sys.argv[4]) if len(sys.argv) > 4 else 4096
+reps = int(sys.argv[5]) if len(sys.argv) > 5 else 3
+pools = int(sys.argv[6]) if len(sys.argv) > 6 else 1
+kind = {"mlp12x100": NET_MLP12X100, "rescnn4": NET_RESCNN4, "rescnn4x3": NET_RESCNN4_X3}[net]
+w = nets.init_mlp12x100(0) if net == "mlp12x100" else nets.init_rescnn4(0)
+ts = []
+for path in libs:
+    L = _lib.declare(C.CDLL(os.path.abspath(path)))
+    t = Trainer(G, "", 12345, 400, 16, 1.0, 0.25, 0, 1, False, stagger=False, pools=pools, _cdll=L)
+    t.set_net(kind, w)
+    t.reset(1)
+    t.run()
+    ts.append(t)
+acc = [[0.0, 0.0, 0.0] for _ in libs]
+for r in range(reps):
+    for i, t in enumerate(ts):
+        t.reset(100 + r)
+        t0 = time.perf_counter()
+        t.run()
+        dt = time.perf_counter() - t0
+        st = t.stats()
+        acc[i][0] += dt * 1e3
+        acc[i][1] += st["mcts_ms"]
+        acc[i][2] += st["nn_ms"]
+for path, a in zip(libs, acc):
+    print("%-28s wall %.1f ms  search %.1f ms  network %.1f ms   (%d games, %s, %d pool(s), mean of %d)" %
+          (os.path.basename(path), a[0] / reps, a[1] / reps, a[2] / reps, G, net, pools, reps))

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Turns the rocprofv3 results of tools/profile_round.sh (rocpd sqlite files under
+gpurun_out/prof_<tag>_{stats,fetch,write,sq}) into the committed summaries:
+profiles/<tag>_kernel_stats.md and profiles/<tag>_pmc.json.
+usage: make_profiles.py <tag> "<command that was profiled>" [results-dir] [output-dir] """
+import collections
+import glob
+import json
+import os
+import sqlite3
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag, cmd = sys.argv[1], sys.argv[2]
+SRC = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "gpurun_out")
+DST = sys.argv[4] if len(sys.argv) > 4 else os.path.join(ROOT, "profiles")
+
+
+def db_of(kind):
+    f = glob.glob(os.path.join(SRC, "prof_%s_%s" % (tag, kind), "**", "*.db"), recursive=True)
+    return sqlite3.connect(f[0]) if f else None
+
+
+def counters(db):
+    cols = [r[1] for r in db.execute("pragma table_info(counters_collection)")]
+    kcol = "kernel_name" if "kernel_name" in cols else "name"
+    acc = collections.defaultdict(lambda: collections.defaultdict(float))
+    disp = collections.defaultdict(set)
+    for k, did, c, v in db.execute("select %s, dispatch_id, counter_name, value from counters_collection" % kcol):
+        k = k.split("(")[0]
+        acc[k][c] += v
+        disp[(k, c)].add(did)
+    return {k: {c: (acc[k][c] / max(len(disp[(k, c)]), 1), len(disp[(k, c)])) for c in acc[k]} for k in acc}
+
+
+lines = ["# %s: kernel statistics (rocprofv3 --kernel-trace --stats), MI355X gfx950, ROCm 7.2" % tag, "",
+         "Command: `%s`" % cmd, "", "| kernel | calls | total (us) | average (us) | share % |", "|---|---:|---:|---:|---:|"]
+db = db_of("stats")
+for name, calls, total, avg, pct in db.execute("select name, total_calls, total_duration, average, percentage from top_kernels"):
+    lines.append("| `%s` | %d | %.1f | %.3f | %.2f |" % (name.split("(")[0], calls, total, avg, pct))
+pmc = {"tag": tag, "command": cmd,
+       "note": "rocprofv3 --pmc passes, one counter group per pass with --kernel-trace only. FETCH_SIZE / WRITE_SIZE "
+               "are in KB (rocprofv3 units); HBM traffic per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 bytes "
+               "(gfx950 correction of MI355X_MICROARCH.md: FETCH_SIZE counts 64-byte requests as 32).",
+       "kernels": {}}
+f, w = db_of("fetch"), db_of("write")
+if f and w:
+    cf, cw = counters(f), counters(w)
+    for k in cf:
+        if k in cw and "FETCH_SIZE" in cf[k] and "WRITE_SIZE" in cw[k]:
+            fe, n = cf[k]["FETCH_SIZE"]
+            wr, _ = cw[k]["WRITE_SIZE"]
+            pmc["kernels"][k] = {"launches": n, "FETCH_SIZE_KB_per_launch": fe, "WRITE_SIZE_KB_per_launch": wr,
+                                 "traffic_bytes_per_launch": (2.0 * fe + wr) * 1024.0}
+sq = db_of("sq")
+if sq:
+    lines += ["", "SQ counters per launch (own pass):", "", "| kernel | counter | per launch |", "|---|---|---:|"]
+    for k, d in counters(sq).items():
+        if not k.startswith("co_k_") or k in ("co_k_scan", "co_k_compact"):
+            continue
+        for c in sorted(d):
+            lines.append("| `%s` | %s | %.0f |" % (k, c, d[c][0]))
+        pmc["kernels"].setdefault(k, {})["sq"] = {c: d[c][0] for c in d}
+os.makedirs(DST, exist_ok=True)
+with open(os.path.join(DST, "%s_kernel_stats.md" % tag), "w") as fh:
+    fh.write("\n".join(lines) + "\n")
+with open(os.path.join(DST, "%s_pmc.json" % tag), "w") as fh:
+    json.dump(pmc, fh, indent=1)
+print("\n".join(lines))
+print(json.dumps(pmc["kernels"], indent=1)[:1500])
