@@ -50,6 +50,7 @@ def parse():
                          "mlp12x100 = the reference's own net")
     ap.add_argument("--no-mlp-extra", action="store_true", help="skip the extra generations (other networks) reported under detail.variants")
     ap.add_argument("--stagger", action="store_true", help="keep the reference's staggered start")
+    ap.add_argument("--tflite", default="", help="with --net mlp12x100: weights imported from a reference TFLite checkpoint")
     ap.add_argument("--arena-units", type=int, default=0)
     ap.add_argument("--no-unshared", action="store_true", help="skip the extra single-pool generation behind roofline.unshared (profiling runs)")
     ap.add_argument("--pools", type=int, default=0, help="independent game pools on separate streams per GPU (0 = engine default)")
@@ -160,7 +161,12 @@ def main():
 
     G = args.games
     if args.net == "mlp12x100":
-        weights = nets.init_mlp12x100(0)
+        if args.tflite:
+            from corintho_ai_amd.tflite_import import mlp12x100_from_tflite
+
+            weights = mlp12x100_from_tflite(args.tflite)
+        else:
+            weights = nets.init_mlp12x100(0)
         kind = NET_MLP12X100
         flop_per_row = 2.0 * (70 * 100 + 11 * 100 * 100 + 100 + 100 * 96)
     else:
