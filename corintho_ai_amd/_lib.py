@@ -64,6 +64,9 @@ EXPORTS = [
     "ca_trainer_run", "ca_trainer_net_forward", "ca_trainer_net_bench", "ca_trainer_export_samples", "ca_trainer_pack_samples_device", "ca_trainer_reset", "ca_expand_samples", "ca_trainer_stats",
     "ca_trainer_game_info", "ca_trainer_trace", "ca_rules_legal_moves", "ca_rules_do_move", "ca_rng_draw",
     "ca_fp_probe",
+    "ca_tourney_create", "ca_tourney_destroy", "ca_tourney_add_player", "ca_tourney_add_match", "ca_tourney_all_done",
+    "ca_tourney_num_requests", "ca_tourney_write_requests", "ca_tourney_do_iteration", "ca_tourney_write_scores",
+    "ca_tourney_num_matches", "ca_tourney_match_info", "ca_tourney_match_score", "ca_tourney_trace", "ca_tourney_stats",
 ]
 
 
@@ -97,9 +100,24 @@ def declare(L):
     L.ca_rules_do_move.argtypes = [C.c_int, u64p, u32p, i32p, C.c_int32, f32p]
     L.ca_rng_draw.argtypes = [C.c_int, C.c_uint32, C.c_int32, C.c_int32, u32p]
     L.ca_fp_probe.argtypes = [C.c_int, f32p, C.c_int32, f32p]
+    L.ca_tourney_create.argtypes = [C.c_int, C.c_uint32, C.c_int, C.POINTER(vp)]
+    L.ca_tourney_destroy.argtypes = [vp]
+    L.ca_tourney_destroy.restype = None
+    L.ca_tourney_add_player.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_int32]
+    L.ca_tourney_add_match.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32]
+    L.ca_tourney_all_done.argtypes = [vp, i32p]
+    L.ca_tourney_num_requests.argtypes = [vp, C.c_int32, i32p]
+    L.ca_tourney_write_requests.argtypes = [vp, f32p, C.c_int32]
+    L.ca_tourney_do_iteration.argtypes = [vp, f32p, f32p, C.c_int32, C.c_int32]
+    L.ca_tourney_write_scores.argtypes = [vp, C.c_char_p]
+    L.ca_tourney_num_matches.argtypes = [vp, i32p]
+    L.ca_tourney_match_info.argtypes = [vp, C.c_int32, i32p]
+    L.ca_tourney_match_score.argtypes = [vp, C.c_int32, f32p]
+    L.ca_tourney_trace.argtypes = [vp, C.c_int32, i32p, C.c_int32, i32p]
+    L.ca_tourney_stats.argtypes = [vp, C.POINTER(CaStats)]
     for name in EXPORTS:
         fn = getattr(L, name)
-        if name not in ("ca_last_error", "ca_trainer_destroy"):
+        if name not in ("ca_last_error", "ca_trainer_destroy", "ca_tourney_destroy"):
             fn.restype = C.c_int
     return L
 

@@ -10,6 +10,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <fstream>
+#include <map>
 #include <memory>
 #include <random>
 #include <string>
@@ -110,7 +112,7 @@ struct ca_trainer {
   /* host state */
   int64_t iterations = 0;
   int32_t trainer_iteration = 0; /* Trainer::searches_done_ (train mode only) */
-  int scan_valid_for = -99;      /* to_play the current req_offset/nn_in describe */
+  int scan_valid_for = 0;      /* to_play / model id the current req_offset/nn_in describe (if scan_valid) */
   int32_t last_total = 0;
   bool finished = false;
   std::vector<GameCtl> host_games;
@@ -119,6 +121,14 @@ struct ca_trainer {
   std::unique_ptr<CoNet> nets[2];
   double mcts_ms = 0, nn_ms = 0, pack_ms = 0;
   int64_t mcts_launches = 0, nn_launches = 0, nn_rows = 0;
+
+  /* tournament mode (ca_tourney): per-match players, per-match seeds, the reference's read offsets */
+  bool tourney = false;
+  std::vector<PlayerCfg> host_pcfg; /* [2G] */
+  std::vector<uint32_t> match_seeds; /* [G] */
+  DevBuf<PlayerCfg> pcfg;
+  DevBuf<int32_t> read_offset;
+  bool scan_valid = false;
 
   std::vector<Pool> pools;
   void free_pools() {
@@ -172,6 +182,11 @@ struct ca_trainer {
     all_done.alloc(1);
     row_counter.alloc(1);
     pack_counter.alloc(2 * CO_MAX_POOLS);
+    if (tourney) {
+      pcfg.alloc(host_pcfg.size());
+      rt_h2d(pcfg.p, host_pcfg.data(), host_pcfg.size() * sizeof(PlayerCfg), stream);
+      read_offset.alloc((size_t)G);
+    }
 
     reset_games(cfg.seed);
     memset(&P, 0, sizeof P);
@@ -193,11 +208,12 @@ struct ca_trainer {
     std::vector<TreeCtl> ht(T);
     for (int g = 0; g < G; ++g) {
       uint32_t *x = &st[(size_t)g * CO_MT_N];
-      x[0] = seeds[cfg.game_base + g];
+      x[0] = tourney ? match_seeds[g] : seeds[cfg.game_base + g];
       for (int i = 1; i < CO_MT_N; ++i) x[i] = 1812433253u * (x[i - 1] ^ (x[i - 1] >> 30)) + (uint32_t)i;
       memset(&hg[g], 0, sizeof(GameCtl));
       hg[g].parity = (cfg.game_base + g) % 2;
       hg[g].rng_idx = CO_MT_N;
+      hg[g].pos_meta = CO_META_START; /* Match::root_ = Node{} (match.h:91): the empty board */
     }
     for (size_t t = 0; t < T; ++t) {
       ht[t].root = CO_NONE;
@@ -213,7 +229,7 @@ struct ca_trainer {
     rt_sync(stream);
     iterations = 0;
     trainer_iteration = 0;
-    scan_valid_for = -99;
+    scan_valid = false;
     last_total = 0;
     finished = false;
     host_games_valid = false;
@@ -236,6 +252,8 @@ struct ca_trainer {
     P.game_base = cfg.game_base;
     P.cap_units = cap;
     P.trace_on = cfg.trace;
+    P.pcfg = tourney ? pcfg.p : nullptr;
+    P.read_offset = tourney ? read_offset.p : nullptr;
     P.games = games.p;
     P.trees = trees.p;
     P.arena = arena.p;
@@ -268,7 +286,7 @@ struct ca_trainer {
 
   /* offsets + compact batch for model `to_play` (K4) */
   void pack(int to_play) {
-    if (scan_valid_for == to_play) return;
+    if (scan_valid && scan_valid_for == to_play) return;
     P.to_play = to_play;
     RT_LAUNCH(co_k_scan, 1, CO_WAVE, stream, P);
     RT_LAUNCH(co_k_compact, G, CO_WAVE, stream, P);
@@ -279,6 +297,7 @@ struct ca_trainer {
     last_total = tot_done[0];
     finished = tot_done[1] != 0;
     scan_valid_for = to_play;
+    scan_valid = true;
   }
 
   void fetch_games() {
@@ -324,7 +343,7 @@ struct ca_trainer {
     if (to_play == -1) ++trainer_iteration;
     ++iterations;
     ++mcts_launches;
-    scan_valid_for = -99;
+    scan_valid = false;
     host_games_valid = false;
     pack(to_play);
     check_errors();
@@ -346,6 +365,47 @@ struct ca_trainer {
     rt_sync(stream);
     for (int r = 0; r < last_total; ++r)
       memcpy(out + (size_t)r * CO_GAME_STATE_SIZE, &tmp[(size_t)r * CO_STATE_STRIDE], CO_GAME_STATE_SIZE * 4);
+  }
+
+  /* ---- Tourney (tourney.cpp) on the same pool: one match per game slot ---- */
+  int32_t tourney_num_requests(int id) {
+    pack(id);
+    return last_total;
+  }
+  void tourney_write_requests(float *out, int id) {
+    pack(id);
+    if (last_total == 0) return;
+    std::vector<float> tmp((size_t)last_total * CO_STATE_STRIDE);
+    rt_d2h(tmp.data(), nn_in.p, tmp.size() * 4, stream);
+    rt_sync(stream);
+    for (int r = 0; r < last_total; ++r)
+      memcpy(out + (size_t)r * CO_GAME_STATE_SIZE, &tmp[(size_t)r * CO_STATE_STRIDE], CO_GAME_STATE_SIZE * 4);
+  }
+  /* Tourney::doIteration (tourney.cpp:53-70).  `rows` = rows of the caller's two arrays: the
+   * reference reads them at its own offset table (quirk 10), so the whole arrays travel. */
+  void tourney_do_iteration(const float *evals, const float *probs, int32_t rows, int id) {
+    size_t cap = (size_t)G * spe;
+    if (rows < 0 || (size_t)rows > cap) rows = (int32_t)cap;
+    P.to_play = id;
+    RT_LAUNCH(co_k_scan, 1, CO_WAVE, stream, P); /* offsets at entry */
+    if (rows > 0 && evals && probs) {
+      rt_h2d(nn_eval.p, evals, (size_t)rows * 4, stream);
+      rt_h2d(nn_probs.p, probs, (size_t)rows * CO_NUM_MOVES * 4, stream);
+    }
+    P.iteration = trainer_iteration;
+    RT_LAUNCH(co_k_mcts_step, G, CO_WAVE, stream, P);
+    ++iterations;
+    ++mcts_launches;
+    scan_valid = false;
+    host_games_valid = false;
+    pack(id);
+    check_errors();
+  }
+  bool tourney_all_done() {
+    fetch_games();
+    for (int g = 0; g < G; ++g)
+      if (!host_games[g].done) return false;
+    return true;
   }
 
   int32_t num_samples() {
@@ -588,7 +648,7 @@ struct ca_trainer {
     P.pool_row_base = 0;
     P.pack_counter = pack_counter.p;
     host_games_valid = false;
-    scan_valid_for = -99;
+    scan_valid = false;
     if (!failure.empty()) throw EngineError(CA_ERR_ENGINE, failure);
     pack(-1); /* refresh the done flag and the batch description */
     check_errors();
@@ -657,7 +717,7 @@ struct ca_trainer {
     for (auto &e : ev) rt_event_destroy(e);
     P.row_counter = nullptr;
     host_games_valid = false;
-    scan_valid_for = -99;
+    scan_valid = false;
     pack(to_play); /* refresh the done flag and the batch description */
     check_errors();
     unsigned long long rows = 0;
@@ -731,6 +791,167 @@ extern "C" int ca_trainer_pack_samples_device(ca_trainer *t, void *d_sp, void *d
   CA_GUARD(*n_rows = t->pack_samples_device((float *)d_sp, (float *)d_oc, cap_rows))
 }
 extern "C" int ca_trainer_reset(ca_trainer *t, int32_t seed) { CA_GUARD(t->reset_games(seed)) }
+/* ------------------------------------------------------------------ Tourney C ABI */
+struct ca_tourney {
+  int device = 0;
+  uint32_t arena_units = 0;
+  int trace = 0;
+  std::map<int, PlayerCfg> players;            /* Tourney::players_ (tourney.h:42) */
+  std::vector<std::pair<int, int>> matches;    /* addMatch order */
+  std::mt19937 generator;                      /* default constructed: seed 5489 (tourney.h:43) */
+  std::vector<uint32_t> seeds;
+  std::unique_ptr<ca_trainer> pool;            /* built at the first query after the last addMatch */
+
+  ca_trainer &built() {
+    if (pool) return *pool;
+    if (matches.empty()) throw EngineError(CA_ERR_STATE, "tourney without matches");
+    auto t = std::make_unique<ca_trainer>();
+    t->tourney = true;
+    ca_config c;
+    memset(&c, 0, sizeof c);
+    c.num_games = (int32_t)matches.size();
+    c.device = device;
+    c.testing = 1;
+    c.no_stagger = 1;
+    c.trace = trace;
+    c.arena_units = arena_units;
+    c.c_puct = 1.0f;
+    c.max_searches = 1;
+    c.searches_per_eval = 1;
+    for (auto &m : matches) {
+      for (int side = 0; side < 2; ++side) {
+        const PlayerCfg &p = players.at(side == 0 ? m.first : m.second);
+        t->host_pcfg.push_back(p);
+        if (!p.random) {
+          c.max_searches = std::max(c.max_searches, p.max_searches);
+          c.searches_per_eval = std::max(c.searches_per_eval, p.searches_per_eval);
+        }
+      }
+    }
+    t->match_seeds = seeds;
+    t->init(c);
+    pool = std::move(t);
+    return *pool;
+  }
+};
+
+extern "C" int ca_tourney_create(int device, uint32_t arena_units, int trace, ca_tourney **out) {
+  int rc = ca_device_check(device);
+  if (rc != CA_OK) return rc;
+  CA_GUARD({
+    if (!out) throw EngineError(CA_ERR_ARG, "null output pointer");
+    auto t = std::make_unique<ca_tourney>();
+    t->device = device;
+    t->arena_units = arena_units;
+    t->trace = trace;
+    *out = t.release();
+  })
+}
+extern "C" void ca_tourney_destroy(ca_tourney *t) { delete t; }
+
+extern "C" int ca_tourney_add_player(ca_tourney *t, int32_t player_id, int32_t model_id, int32_t max_searches,
+                                     int32_t searches_per_eval, float c_puct, float epsilon, int32_t random) {
+  CA_GUARD({
+    if (t->pool) throw EngineError(CA_ERR_STATE, "addPlayer after the tournament has started");
+    if (!random && (max_searches <= 0 || searches_per_eval <= 0)) throw EngineError(CA_ERR_ARG, "addPlayer: bad search settings");
+    PlayerCfg p;
+    memset(&p, 0, sizeof p);
+    p.player_id = player_id;
+    p.model_id = model_id;
+    p.max_searches = max_searches;
+    p.searches_per_eval = searches_per_eval;
+    p.c_puct = c_puct;
+    p.epsilon = epsilon;
+    p.random = random ? 1 : 0;
+    t->players[player_id] = p;
+  })
+}
+
+extern "C" int ca_tourney_add_match(ca_tourney *t, int32_t player1, int32_t player2, int32_t logging) {
+  CA_GUARD({
+    (void)logging; /* match log files are not written */
+    if (t->pool) throw EngineError(CA_ERR_STATE, "addMatch after the tournament has started");
+    if (!t->players.count(player1) || !t->players.count(player2)) throw EngineError(CA_ERR_ARG, "addMatch: unknown player");
+    if (t->players[player1].random && t->players[player2].random)
+      throw EngineError(CA_ERR_ARG, "addMatch: at most one random player per match (match.cpp:72)");
+    t->matches.emplace_back(player1, player2);
+    t->seeds.push_back((uint32_t)t->generator()); /* tourney.cpp:86 */
+  })
+}
+
+extern "C" int ca_tourney_all_done(ca_tourney *t, int32_t *out) { CA_GUARD(*out = t->built().tourney_all_done() ? 1 : 0) }
+extern "C" int ca_tourney_num_requests(ca_tourney *t, int32_t id, int32_t *out) {
+  CA_GUARD(*out = t->built().tourney_num_requests(id))
+}
+extern "C" int ca_tourney_write_requests(ca_tourney *t, float *game_states, int32_t id) {
+  CA_GUARD(t->built().tourney_write_requests(game_states, id))
+}
+extern "C" int ca_tourney_do_iteration(ca_tourney *t, const float *evaluations, const float *probabilities,
+                                       int32_t rows, int32_t id) {
+  CA_GUARD(t->built().tourney_do_iteration(evaluations, probabilities, rows, id))
+}
+extern "C" int ca_tourney_num_matches(ca_tourney *t, int32_t *out) { CA_GUARD(*out = (int32_t)t->matches.size()) }
+/* out[8] = {player id 1, player id 2, done, result (util.h:57-64, first player's view), side to move, pending
+ * requests, plies, error} */
+extern "C" int ca_tourney_match_info(ca_tourney *t, int32_t match, int32_t out[8]) {
+  CA_GUARD({
+    ca_trainer &p = t->built();
+    if (match < 0 || match >= p.G) throw EngineError(CA_ERR_ARG, "match index out of range");
+    p.fetch_games();
+    const GameCtl &gc = p.host_games[match];
+    out[0] = t->matches[match].first;
+    out[1] = t->matches[match].second;
+    out[2] = gc.done;
+    out[3] = gc.result;
+    out[4] = gc.to_play;
+    out[5] = gc.done ? 0 : gc.n_pending;
+    out[6] = gc.plies;
+    out[7] = gc.error;
+  })
+}
+extern "C" int ca_tourney_match_score(ca_tourney *t, int32_t match, float *out) {
+  CA_GUARD({
+    ca_trainer &p = t->built();
+    if (match < 0 || match >= p.G) throw EngineError(CA_ERR_ARG, "match index out of range");
+    p.fetch_games();
+    *out = ca_trainer::game_score(p.host_games[match]); /* Match::score, match.cpp:52-58 */
+  })
+}
+/* Tourney::writeScores, tourney.cpp:33-41: "id1 id2 score" per finished match */
+extern "C" int ca_tourney_write_scores(ca_tourney *t, const char *filename) {
+  CA_GUARD({
+    ca_trainer &p = t->built();
+    p.fetch_games();
+    std::ofstream f(filename);
+    if (!f) throw EngineError(CA_ERR_ARG, std::string("cannot open ") + filename);
+    for (int g = 0; g < p.G; ++g)
+      if (p.host_games[g].done)
+        f << t->matches[g].first << ' ' << t->matches[g].second << ' ' << ca_trainer::game_score(p.host_games[g]) << '\n';
+  })
+}
+extern "C" int ca_trainer_trace(ca_trainer *t, int game, int32_t *out, int32_t cap, int32_t *n);
+extern "C" int ca_trainer_stats(ca_trainer *t, ca_stats *out);
+extern "C" int ca_tourney_trace(ca_tourney *t, int32_t match, int32_t *out, int32_t cap, int32_t *n_out) {
+  ca_trainer *p = nullptr;
+  try {
+    p = &t->built();
+  } catch (const std::exception &e) {
+    g_last_error = e.what();
+    return CA_ERR_STATE;
+  }
+  return ca_trainer_trace(p, match, out, cap, n_out);
+}
+extern "C" int ca_tourney_stats(ca_tourney *t, ca_stats *out) {
+  ca_trainer *p = nullptr;
+  try {
+    p = &t->built();
+  } catch (const std::exception &e) {
+    g_last_error = e.what();
+    return CA_ERR_STATE;
+  }
+  return ca_trainer_stats(p, out);
+}
+
 /* diagnostic builds (-DCO_PROF): summed in-kernel cycle stamps, see mcts.h; not in the public header */
 extern "C" int ca_trainer_prof(ca_trainer *t, unsigned long long out[36]) {
   CA_GUARD({

@@ -78,6 +78,15 @@ struct GameCtl {
   int32_t trace_len;
   int32_t row_off;    /* fused mode: first row of this game's requests in the compact batch */
   int32_t resume;     /* fused mode: the new mover's first searches of a turn were deferred to the next step */
+  /* tournament matches only: Match::root_, the position on the board (match.h:91) */
+  uint32_t pos_lo, pos_hi, pos_meta, pos_pad;
+};
+
+/* one side of a tournament match: Player, match.h:13-31 */
+struct PlayerCfg {
+  int32_t max_searches, searches_per_eval;
+  float c_puct, epsilon;
+  int32_t model_id, random, player_id, pad;
 };
 
 struct TreeCtl {
@@ -101,6 +110,11 @@ struct EngineParams {
   int32_t game_base;   /* global index of local game 0 (multi-GPU shard): parity = (base + g) % 2 */
   uint32_t cap_units;  /* arena units per tree */
   int32_t trace_on;
+  /* tournament mode (Match / Tourney): per-match players [2G]; to_play then carries the MODEL id
+   * whose matches run (Match::to_play, match.cpp:42-44); read_offset[G] = the reference's
+   * offset table of Tourney::doIteration (tourney.cpp:55-62) */
+  const PlayerCfg *pcfg;
+  int32_t *read_offset;
   /* pool */
   GameCtl *games;
   TreeCtl *trees;

@@ -18,9 +18,10 @@ CO_KERNEL co_k_mcts_step(EngineParams P) {
 }
 
 /* is game g part of the batch of model `to_play` (trainer.cpp:42-46, 84-98)? */
-CO_DEV int co_game_active(const GameCtl &gc, int to_play) {
+CO_DEV int co_game_active(const EngineParams &P, int g, const GameCtl &gc) {
   if (gc.done) return 0;
-  if (to_play == 0 || to_play == 1) return gc.to_play == (to_play + gc.parity) % 2;
+  if (P.pcfg) return P.pcfg[2 * g + gc.to_play].model_id == P.to_play; /* tourney.cpp:26, 46, 66 */
+  if (P.to_play == 0 || P.to_play == 1) return gc.to_play == (P.to_play + gc.parity) % 2;
   return 1;
 }
 
@@ -36,7 +37,7 @@ CO_KERNEL co_k_scan(EngineParams P) {
       int g = lane * chunk + i;
       if (g < G) {
         GameCtl gc = P.games[g];
-        if (co_game_active(gc, P.to_play)) s += gc.n_pending;
+        if (co_game_active(P, g, gc)) s += gc.n_pending;
         notdone += !gc.done;
       }
     }
@@ -65,7 +66,17 @@ CO_KERNEL co_k_scan(EngineParams P) {
       if (g < G) {
         GameCtl gc = P.games[g];
         P.req_offset[g] = s;
-        if (co_game_active(gc, P.to_play)) s += gc.n_pending;
+        if (co_game_active(P, g, gc)) s += gc.n_pending;
+      }
+    }
+    if (lane == 0 && P.read_offset) {
+      /* Tourney::doIteration's own table (tourney.cpp:55-62): match i reads at
+       * the running sum of num_requests(i - 1) over the ACTIVE i, not at its row of writeRequests */
+      int offset = 0;
+      P.read_offset[0] = 0;
+      for (int i = 1; i < G; ++i) {
+        if (co_game_active(P, i, P.games[i])) offset += P.games[i - 1].n_pending;
+        P.read_offset[i] = offset;
       }
     }
     if (lane == 0) {
@@ -80,7 +91,7 @@ CO_KERNEL co_k_compact(EngineParams P) {
   int g = CO_BLOCK_IDX;
   if (g >= P.num_games) return;
   GameCtl gc = P.games[g];
-  if (!co_game_active(gc, P.to_play)) return;
+  if (!co_game_active(P, g, gc)) return;
   int n = gc.n_pending;
   const float *src = P.req + (size_t)g * P.searches_per_eval * CO_STATE_STRIDE;
   float *dst = P.nn_in + (size_t)P.req_offset[g] * CO_STATE_STRIDE;

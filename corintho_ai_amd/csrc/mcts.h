@@ -58,6 +58,7 @@ struct CoWave {
   /* config */
   int max_searches, spe, testing, trace_on, defer_handover;
   float c_puct, epsilon;
+  const PlayerCfg *pc; /* tournament match: the two players' settings, else null */
 };
 
 /* ---- slot helpers.  slot = {child, eval bits, mp | visits<<16, result | all_visited<<8} */
@@ -1120,6 +1121,121 @@ CO_DEV int co_choose_move_and_continue(CoWave &w) {
   return 0;
 }
 
+/* Tournament matches (match.h, match.cpp): the two sides search with their own settings */
+CO_DEV void co_use_player(CoWave &w, int p) {
+  if (!w.pc) return;
+  w.max_searches = w.pc[p].max_searches;
+  w.spe = w.pc[p].searches_per_eval;
+  w.c_puct = w.pc[p].c_puct;
+  w.epsilon = w.pc[p].epsilon;
+}
+
+/* std::uniform_int_distribution<int32_t>(0, n - 1)(generator_) of match.cpp:199-200 as libstdc++
+ * (GCC >= 11) computes it on a 32-bit generator: Lemire's nearly divisionless method, one
+ * 64-bit product per draw, a draw consumed even for n == 1 */
+CO_DEV uint32_t co_uniform_below(CoWave &w, uint32_t n) {
+  unsigned long long product = (unsigned long long)co_mt_next(w.mt, &w.gc.rng_idx) * (unsigned long long)n;
+  uint32_t low = (uint32_t)product;
+  if (low < n) {
+    uint32_t threshold = (0u - n) % n;
+    while (low < threshold) {
+      product = (unsigned long long)co_mt_next(w.mt, &w.gc.rng_idx) * (unsigned long long)n;
+      low = (uint32_t)product;
+    }
+  }
+  return (uint32_t)(product >> 32);
+}
+
+/* the k-th (0-based) set bit of a 96-bit legal-move mask = Node::move_id(k) */
+CO_DEV int co_nth_move(const uint32_t lm[3], int k) {
+  for (int wd = 0; wd < 3; ++wd) {
+    int c = co_popc32(lm[wd]);
+    if (k < c) {
+      uint32_t m = lm[wd];
+      for (int i = 0; i < k; ++i) m &= m - 1u;
+      return wd * 32 + co_ffs64((uint64_t)m) - 1;
+    }
+    k -= c;
+  }
+  return -1;
+}
+
+/* Match::chooseMoveAndContinue, match.cpp:207-251 (+ chooseMove :192-205, endGame :163-190).
+ * gc.pos_* is Match::root_; a random player (players_[i] == nullptr) has no tree.  Returns
+ * "game over". */
+CO_DEV int co_match_choose_move_and_continue(CoWave &w) {
+  int need_eval = 0;
+  while (!need_eval) {
+    if (w.gc.error) return 0;
+    int p = w.gc.to_play;
+    uint64_t board = (uint64_t)w.gc.pos_lo | ((uint64_t)w.gc.pos_hi << 32);
+    uint32_t meta = w.gc.pos_meta;
+    int choice;
+    int terminal, tres;
+    if (w.pc[p].random) {
+      uint32_t lm[3];
+      co_legal_moves(board, meta, lm);
+      int n = co_popc32(lm[0]) + co_popc32(lm[1]) + co_popc32(lm[2]);
+      choice = co_nth_move(lm, (int)co_uniform_below(w, (uint32_t)n));
+      co_trace_push(w, -2);
+      co_trace_push(w, choice);
+      w.gc.plies++;
+      co_do_move(&board, &meta, choice);
+      uint32_t lm2[3];
+      int lines = co_legal_moves(board, meta, lm2);
+      terminal = (lm2[0] | lm2[1] | lm2[2]) == 0u;
+      tres = lines ? CO_RESULT_LOSS : CO_RESULT_DRAW;
+    } else {
+      choice = co_choose_move(w, w.me, (float *)0);
+      if (w.gc.error) return 0;
+      co_trace_push(w, choice);
+      w.gc.plies++;
+      co_do_move(&board, &meta, choice);
+      uint4 nrs = co_load_unit(w.me.A, co_load_unit(w.me.A, w.me.tc.root + 1).x);
+      tres = co_slot_result(nrs);
+      terminal = co_res_terminal(tres);
+    }
+    w.gc.pos_lo = (uint32_t)board;
+    w.gc.pos_hi = (uint32_t)(board >> 32);
+    w.gc.pos_meta = meta;
+    int depth = w.gc.plies; /* root_->depth() */
+    if (terminal) {
+      if (tres == CO_RESULT_DRAW) w.gc.result = CO_RESULT_DRAW;
+      else if (p == 1) w.gc.result = CO_RESULT_LOSS;
+      else w.gc.result = CO_RESULT_WIN;
+      return 1;
+    }
+    w.gc.to_play = 1 - p;
+    {
+      CoTree tmp = w.me;
+      w.me = w.opp;
+      w.opp = tmp;
+    }
+    co_use_player(w, 1 - p);
+    if (w.pc[1 - p].random) continue;
+    CoTree &me = w.me;
+    if (me.tc.root == CO_NONE) {
+      int res;
+      uint32_t b = co_create_node(w, me, board, meta, depth, CO_NONE, CO_NONE, &res);
+      if (b == CO_NONE) return 0;
+      me.tc.root = b;
+      return co_mc_do_iteration(w, me, (const float *)0, (const float *)0);
+    }
+    need_eval = co_receive_opponent_move(w, me, choice, board, meta, depth);
+    if (!need_eval) need_eval = !co_mc_do_iteration(w, me, (const float *)0, (const float *)0);
+  }
+  return 0;
+}
+
+/* Match::doIteration, match.cpp:67-79 */
+CO_DEV int co_match_do_iteration(CoWave &w, const float *eval, const float *probs) {
+  if (w.pc[w.gc.to_play].random) return co_match_choose_move_and_continue(w);
+  int done = co_mc_do_iteration(w, w.me, eval, probs);
+  if (w.gc.error) return 0;
+  if (done) return co_match_choose_move_and_continue(w);
+  return 0;
+}
+
 /* SelfPlayer::doIteration, selfplayer.cpp:115-122 */
 CO_DEV int co_sp_do_iteration(CoWave &w, const float *eval, const float *probs) {
   int done;
@@ -1150,7 +1266,9 @@ CO_DEV void co_mcts_step_wave(const EngineParams &P, int g) {
   }
   GameCtl gc = P.games[g];
   if (gc.done || gc.error) return;
-  if (P.to_play == 0 || P.to_play == 1) {
+  if (P.pcfg) {
+    if (P.pcfg[2 * g + gc.to_play].model_id != P.to_play) return; /* tourney.cpp:66 */
+  } else if (P.to_play == 0 || P.to_play == 1) {
     if (gc.to_play != (P.to_play + gc.parity) % 2) return;
   } else if (P.stagger_div > 0) {
     if ((P.game_base + g) / P.stagger_div > P.iteration) {
@@ -1186,13 +1304,16 @@ CO_DEV void co_mcts_step_wave(const EngineParams &P, int g) {
   w.defer_handover = P.defer_handover;
   w.c_puct = P.c_puct;
   w.epsilon = P.epsilon;
+  w.pc = P.pcfg ? P.pcfg + 2 * g : (const PlayerCfg *)0;
+  co_use_player(w, gc.to_play);
   CO_PROF_ADD(w, 4, 1ull);
   unsigned long long t_wave0 = CO_CLK();
 #if defined(CO_PROF) && !defined(CO_EMU)
   unsigned long long t_real0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  int off = P.fused_pack ? gc.row_off : P.req_offset[g];
-  int done = co_sp_do_iteration(w, P.nn_eval + off, P.nn_probs + (size_t)off * CO_NUM_MOVES);
+  int off = P.fused_pack ? gc.row_off : P.read_offset ? P.read_offset[g] : P.req_offset[g];
+  int done = w.pc ? co_match_do_iteration(w, P.nn_eval + off, P.nn_probs + (size_t)off * CO_NUM_MOVES)
+                  : co_sp_do_iteration(w, P.nn_eval + off, P.nn_probs + (size_t)off * CO_NUM_MOVES);
   if (done) w.gc.done = 1;
   if (P.fused_pack && !w.gc.done && !w.gc.error) {
     /* Trainer::writeRequests fused into the step: reserve rows of the compact batch

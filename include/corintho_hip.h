@@ -151,6 +151,42 @@ int ca_trainer_game_info(ca_trainer *t, int game, int32_t out[8]);
 /* per-ply trace of one game, same record format as the oracle's; returns words via *n */
 int ca_trainer_trace(ca_trainer *t, int game, int32_t *out, int32_t cap, int32_t *n);
 
+/* ---- Tourney: replaces `class Tourney` of corintho_ai/cpp/include/tourney.h:13-46
+ * consumed by corintho_ai/rating/tourney.pyx:15-31.  One match = one slot of a device pool
+ * (two search trees, one wavefront); the pool is built at the first query after the last
+ * ca_tourney_add_match.  Model ids are the caller's (negative = the dummy ids of random
+ * players, tourney.pyx:131-134). ---- */
+typedef struct ca_tourney ca_tourney;
+/* Tourney(num_threads, log_folder), tourney.h:15 (threads and log folder have no device meaning) */
+int ca_tourney_create(int device, uint32_t arena_units, int trace, ca_tourney **out);
+void ca_tourney_destroy(ca_tourney *t);
+/* Tourney::addPlayer, tourney.cpp:72-78 */
+int ca_tourney_add_player(ca_tourney *t, int32_t player_id, int32_t model_id, int32_t max_searches,
+                          int32_t searches_per_eval, float c_puct, float epsilon, int32_t random);
+/* Tourney::addMatch, tourney.cpp:80-96: the match's generator is seeded with the next output of
+ * the tourney's default-constructed std::mt19937; `logging` is accepted and ignored */
+int ca_tourney_add_match(ca_tourney *t, int32_t player1, int32_t player2, int32_t logging);
+/* Tourney::all_done, tourney.cpp:14-21 */
+int ca_tourney_all_done(ca_tourney *t, int32_t *out);
+/* Tourney::num_requests(id), tourney.cpp:23-31 */
+int ca_tourney_num_requests(ca_tourney *t, int32_t id, int32_t *out);
+/* Tourney::writeRequests(game_states, id), tourney.cpp:43-51: [num_requests(id)][70] */
+int ca_tourney_write_requests(ca_tourney *t, float *game_states, int32_t id);
+/* Tourney::doIteration(eval, probs, id), tourney.cpp:53-70.  `rows` = rows of the two caller
+ * arrays (eval[rows], probs[rows][96]): matches read them through the reference's own offset
+ * table (tourney.cpp:55-62), which can differ from the writeRequests order */
+int ca_tourney_do_iteration(ca_tourney *t, const float *evaluations, const float *probabilities, int32_t rows,
+                            int32_t id);
+/* Tourney::writeScores, tourney.cpp:33-41 */
+int ca_tourney_write_scores(ca_tourney *t, const char *filename);
+int ca_tourney_num_matches(ca_tourney *t, int32_t *out);
+/* out[8] = {player id 1, player id 2, done, result for the first player, side to move, pending requests, plies, error} */
+int ca_tourney_match_info(ca_tourney *t, int32_t match, int32_t out[8]);
+/* Match::score, match.cpp:52-58 */
+int ca_tourney_match_score(ca_tourney *t, int32_t match, float *out);
+int ca_tourney_trace(ca_tourney *t, int32_t match, int32_t *out, int32_t cap, int32_t *n);
+int ca_tourney_stats(ca_tourney *t, ca_stats *out);
+
 /* rule layer on a batch of positions (one wavefront each): legal-move masks + is_lines */
 int ca_rules_legal_moves(int device, const uint64_t *boards, const uint32_t *metas, int32_t n, uint32_t *masks /* [n][3] */,
                          int32_t *is_lines);

@@ -9,6 +9,7 @@
 #include "corintho_oracle.h"
 
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
@@ -1291,5 +1292,324 @@ void co_trainer_counters(const co_trainer *t, int64_t out[4]) {
     out[1] += t->games[i].ctr.leaf_evals;
     out[2] += t->games[i].ctr.nodes_created;
     out[3] += t->games[i].ctr.plies;
+  }
+}
+
+/* ================================================================== Match / Tourney
+ * The "next" row of SURVEY 8f.1: tournaments between any number of models
+ * (ref: match.h:13-103, match.cpp, tourney.h, tourney.cpp; Python driver rating/tourney.pyx). */
+
+/* ref: match.h:13-31 */
+typedef struct {
+  int player_id, model_id, max_searches, searches_per_eval;
+  float c_puct, epsilon;
+  int random;
+} player_t;
+
+/* std::uniform_int_distribution<int32_t>(0, n - 1)(std::mt19937 &) as libstdc++ (GCC >= 11,
+ * bits/uniform_int_dist.h) computes it for a 32-bit generator: Lemire's nearly divisionless
+ * method on one 64-bit product per draw; n == 1 still consumes a draw.  Checked against the
+ * C++ library itself by tests/test_tourney.py.  (match.cpp:199-200) */
+static uint32_t uniform_below(co_mt19937 *g, uint32_t n) {
+  uint64_t product = (uint64_t)mt_next(g) * (uint64_t)n;
+  uint32_t low = (uint32_t)product;
+  if (low < n) {
+    uint32_t threshold = (uint32_t)(0u - n) % n;
+    while (low < threshold) {
+      product = (uint64_t)mt_next(g) * (uint64_t)n;
+      low = (uint32_t)product;
+    }
+  }
+  return (uint32_t)(product >> 32);
+}
+uint32_t co_uniform_below(co_mt19937 *g, uint32_t n) { return uniform_below(g, n); }
+
+/* ref: match.h:34-103 */
+typedef struct {
+  co_mt19937 generator;
+  float *to_eval;
+  trainmc_t players[2];
+  int is_random[2]; /* players_[i] == nullptr */
+  int ids[2], model_ids[2];
+  node_t *root; /* Match::root_: the position on the board */
+  int to_play;
+  int8_t result;
+  counters_t ctr, root_ctr;
+  int trace_on;
+  int32_t *trace;
+  int n_trace, cap_trace;
+} match_t;
+
+static void match_trace_push(match_t *m, int32_t v) {
+  if (!m->trace_on) return;
+  if (m->n_trace == m->cap_trace) {
+    m->cap_trace = m->cap_trace ? m->cap_trace * 2 : 256;
+    m->trace = (int32_t *)realloc(m->trace, sizeof(int32_t) * (size_t)m->cap_trace);
+  }
+  m->trace[m->n_trace++] = v;
+}
+
+/* ref: match.cpp:15-35 */
+static match_t *match_new(uint32_t seed, const player_t *p1, const player_t *p2) {
+  match_t *m = (match_t *)calloc(1, sizeof *m);
+  mt_seed(&m->generator, seed);
+  int cap = p1->max_searches > p2->max_searches ? p1->max_searches : p2->max_searches;
+  m->to_eval = (float *)calloc((size_t)CO_GAME_STATE_SIZE * (size_t)cap, sizeof(float));
+  const player_t *pp[2] = {p1, p2};
+  for (int i = 0; i < 2; ++i) {
+    m->is_random[i] = pp[i]->random;
+    m->ids[i] = pp[i]->player_id;
+    m->model_ids[i] = pp[i]->model_id;
+    if (!pp[i]->random)
+      mc_init(&m->players[i], &m->generator, m->to_eval, pp[i]->max_searches, pp[i]->searches_per_eval,
+              pp[i]->c_puct, pp[i]->epsilon, 1, &m->ctr);
+  }
+  m->root = node_new_start(&m->root_ctr);
+  m->result = kResultNone;
+  return m;
+}
+
+static void match_free(match_t *m) {
+  for (int i = 0; i < 2; ++i)
+    if (!m->is_random[i]) mc_free(&m->players[i]);
+  if (m->root) node_delete(m->root);
+  free(m->to_eval);
+  free(m->trace);
+  free(m);
+}
+
+/* ref: match.cpp:42-50 */
+static int match_to_play(const match_t *m) { return m->model_ids[m->to_play]; }
+static int match_num_requests(const match_t *m) {
+  if (m->is_random[m->to_play]) return 0;
+  return m->players[m->to_play].n_searched;
+}
+
+/* ref: match.cpp:52-58 */
+static float match_score(const match_t *m) {
+  if (m->result == kResultLoss) return 0.0f;
+  if (m->result == kResultWin) return 1.0f;
+  return 0.5f;
+}
+
+/* ref: match.cpp:163-190 */
+static void match_end_game(match_t *m) {
+  if (m->root->result == kResultDraw) m->result = kResultDraw;
+  else if (m->to_play == 1) m->result = kResultLoss;
+  else m->result = kResultWin;
+  for (int i = 0; i < 2; ++i)
+    if (!m->is_random[i]) mc_null_root(&m->players[i]);
+  free(m->to_eval);
+  m->to_eval = NULL;
+}
+
+/* ref: match.cpp:192-205 */
+static int match_choose_move(match_t *m) {
+  int choice;
+  if (m->is_random[m->to_play]) {
+    int n = m->root->num_legal_moves;
+    choice = n_move_id(m->root, (int)uniform_below(&m->generator, (uint32_t)n));
+    match_trace_push(m, -2);
+  } else {
+    const node_t *r = m->players[m->to_play].root;
+    if (m->trace_on) {
+      match_trace_push(m, m->to_play);
+      match_trace_push(m, r->depth);
+      match_trace_push(m, r->visits);
+      match_trace_push(m, r->result);
+      match_trace_push(m, fbits(r->evaluation));
+      int n = 0;
+      for (const node_t *c = r->first_child; c; c = c->next_sibling) ++n;
+      match_trace_push(m, n);
+      for (const node_t *c = r->first_child; c; c = c->next_sibling) {
+        match_trace_push(m, c->child_id);
+        match_trace_push(m, c->visits);
+        match_trace_push(m, fbits(c->evaluation));
+        match_trace_push(m, c->result);
+        match_trace_push(m, c->all_visited);
+      }
+    }
+    choice = mc_choose_move(&m->players[m->to_play], NULL, NULL);
+  }
+  match_trace_push(m, choice);
+  m->ctr.plies++;
+  return choice;
+}
+
+/* ref: match.cpp:207-251 */
+static int match_choose_move_and_continue(match_t *m) {
+  int need_eval = 0;
+  while (!need_eval) {
+    int choice = match_choose_move(m);
+    node_t *next = node_new_child(&m->root->game, NULL, NULL, choice, m->root->depth + 1, &m->root_ctr);
+    node_delete(m->root);
+    m->root = next;
+    if (n_terminal(m->root)) {
+      match_end_game(m);
+      return 1;
+    }
+    m->to_play = 1 - m->to_play;
+    if (m->is_random[m->to_play]) continue;
+    trainmc_t *me = &m->players[m->to_play];
+    if (me->root == NULL) {
+      mc_create_root(me, &m->root->game, m->root->depth);
+      return mc_do_iteration(me, NULL, NULL);
+    }
+    need_eval = mc_receive_opponent_move(me, choice, &m->root->game, m->root->depth);
+    if (!need_eval) need_eval = !mc_do_iteration(me, NULL, NULL);
+  }
+  return 0;
+}
+
+/* ref: match.cpp:67-79 */
+static int match_do_iteration(match_t *m, const float *eval, const float *probs) {
+  if (m->is_random[m->to_play]) return match_choose_move_and_continue(m);
+  int done = mc_do_iteration(&m->players[m->to_play], eval, probs);
+  if (done) return match_choose_move_and_continue(m);
+  return 0;
+}
+
+/* ref: tourney.h:13-46 */
+#define CO_TOURNEY_MAX_PLAYERS 1024
+struct co_tourney {
+  match_t **matches;
+  uint8_t *is_done;
+  int n_matches, cap_matches;
+  player_t players[CO_TOURNEY_MAX_PLAYERS];
+  uint8_t has_player[CO_TOURNEY_MAX_PLAYERS];
+  co_mt19937 generator; /* default constructed: seed 5489 (tourney.h:43) */
+  int num_threads;
+  int trace_on;
+};
+
+co_tourney *co_tourney_create(int num_threads) {
+  co_tourney *t = (co_tourney *)calloc(1, sizeof *t);
+  mt_seed(&t->generator, 5489u);
+  t->num_threads = num_threads > 0 ? num_threads : 1;
+  return t;
+}
+
+void co_tourney_destroy(co_tourney *t) {
+  if (!t) return;
+  for (int i = 0; i < t->n_matches; ++i) match_free(t->matches[i]);
+  free(t->matches);
+  free(t->is_done);
+  free(t);
+}
+
+/* ref: tourney.cpp:72-78 */
+int co_tourney_add_player(co_tourney *t, int player_id, int model_id, int max_searches, int searches_per_eval,
+                          float c_puct, float epsilon, int random) {
+  if (player_id < 0 || player_id >= CO_TOURNEY_MAX_PLAYERS) return -1;
+  player_t p = {player_id, model_id, max_searches, searches_per_eval, c_puct, epsilon, random};
+  t->players[player_id] = p;
+  t->has_player[player_id] = 1;
+  return 0;
+}
+
+/* ref: tourney.cpp:80-96 (log files are not part of the restatement) */
+int co_tourney_add_match(co_tourney *t, int player1, int player2) {
+  if (player1 < 0 || player1 >= CO_TOURNEY_MAX_PLAYERS || !t->has_player[player1]) return -1;
+  if (player2 < 0 || player2 >= CO_TOURNEY_MAX_PLAYERS || !t->has_player[player2]) return -1;
+  if (t->n_matches == t->cap_matches) {
+    t->cap_matches = t->cap_matches ? t->cap_matches * 2 : 64;
+    t->matches = (match_t **)realloc(t->matches, sizeof(match_t *) * (size_t)t->cap_matches);
+    t->is_done = (uint8_t *)realloc(t->is_done, (size_t)t->cap_matches);
+  }
+  match_t *m = match_new(mt_next(&t->generator), &t->players[player1], &t->players[player2]);
+  m->trace_on = t->trace_on;
+  t->matches[t->n_matches] = m;
+  t->is_done[t->n_matches] = 0;
+  return t->n_matches++;
+}
+
+/* ref: tourney.cpp:14-21 */
+int co_tourney_all_done(const co_tourney *t) {
+  for (int i = 0; i < t->n_matches; ++i)
+    if (!t->is_done[i]) return 0;
+  return 1;
+}
+
+/* ref: tourney.cpp:23-31 */
+int co_tourney_num_requests(const co_tourney *t, int id) {
+  int count = 0;
+  for (int i = 0; i < t->n_matches; ++i)
+    if (!t->is_done[i] && match_to_play(t->matches[i]) == id) count += match_num_requests(t->matches[i]);
+  return count;
+}
+
+/* ref: tourney.cpp:43-51 (Match::writeRequests match.cpp:60-65) */
+void co_tourney_write_requests(const co_tourney *t, float *game_states, int id) {
+  int offset = 0;
+  for (int i = 0; i < t->n_matches; ++i) {
+    if (!t->is_done[i] && match_to_play(t->matches[i]) == id) {
+      int n = match_num_requests(t->matches[i]);
+      memcpy(game_states + (size_t)offset * CO_GAME_STATE_SIZE, t->matches[i]->to_eval,
+             sizeof(float) * (size_t)n * CO_GAME_STATE_SIZE);
+      offset += n;
+    }
+  }
+}
+
+/* ref: tourney.cpp:53-70.  The offset table is the reference's: match i
+ * reads from the running sum of the request counts of matches j - 1 for the ACTIVE j <= i,
+ * which equals its row in writeRequests only while every unfinished match waits for `id`. */
+void co_tourney_do_iteration(co_tourney *t, const float *eval, const float *probs, int id) {
+  int n = t->n_matches;
+  int *offsets = (int *)calloc((size_t)(n > 0 ? n : 1), sizeof(int));
+  int offset = 0;
+  for (int i = 1; i < n; ++i) {
+    if (!t->is_done[i] && match_to_play(t->matches[i]) == id) offset += match_num_requests(t->matches[i - 1]);
+    offsets[i] = offset;
+  }
+#ifdef _OPENMP
+  omp_set_num_threads(t->num_threads);
+#endif
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int i = 0; i < n; ++i) {
+    if (!t->is_done[i] && match_to_play(t->matches[i]) == id) {
+      int done = match_do_iteration(t->matches[i], eval + offsets[i], probs + (size_t)offsets[i] * CO_NUM_MOVES);
+      if (done) t->is_done[i] = 1;
+    }
+  }
+  free(offsets);
+}
+
+/* ref: tourney.cpp:33-41: one line "id1 id2 score" per finished match */
+int co_tourney_write_scores(const co_tourney *t, const char *filename) {
+  FILE *f = fopen(filename, "w");
+  if (!f) return -1;
+  for (int i = 0; i < t->n_matches; ++i)
+    if (t->is_done[i]) fprintf(f, "%d %d %g\n", t->matches[i]->ids[0], t->matches[i]->ids[1], (double)match_score(t->matches[i]));
+  fclose(f);
+  return 0;
+}
+
+/* introspection for the parity tests */
+int co_tourney_num_matches(const co_tourney *t) { return t->n_matches; }
+int co_tourney_match_done(const co_tourney *t, int i) { return t->is_done[i]; }
+float co_tourney_match_score(const co_tourney *t, int i) { return match_score(t->matches[i]); }
+int co_tourney_match_result(const co_tourney *t, int i) { return t->matches[i]->result; }
+int co_tourney_match_to_play(const co_tourney *t, int i) { return t->matches[i]->to_play; }
+int co_tourney_match_num_requests(const co_tourney *t, int i) {
+  return t->is_done[i] ? 0 : match_num_requests(t->matches[i]);
+}
+void co_tourney_enable_trace(co_tourney *t, int on) {
+  t->trace_on = on;
+  for (int i = 0; i < t->n_matches; ++i) t->matches[i]->trace_on = on;
+}
+int co_tourney_trace(const co_tourney *t, int i, int32_t *out, int cap) {
+  const match_t *m = t->matches[i];
+  int n = m->n_trace < cap ? m->n_trace : cap;
+  if (out && n > 0) memcpy(out, m->trace, sizeof(int32_t) * (size_t)n);
+  return m->n_trace;
+}
+void co_tourney_counters(const co_tourney *t, int64_t out[4]) {
+  out[0] = out[1] = out[2] = out[3] = 0;
+  for (int i = 0; i < t->n_matches; ++i) {
+    out[0] += t->matches[i]->ctr.searches;
+    out[1] += t->matches[i]->ctr.leaf_evals;
+    out[2] += t->matches[i]->ctr.nodes_created;
+    out[3] += t->matches[i]->ctr.plies;
   }
 }

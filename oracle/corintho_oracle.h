@@ -95,6 +95,31 @@ int co_trainer_trace(const co_trainer *t, int game, int32_t *out, int cap);
 /* counters summed over games: [searches, leaf_evals, nodes_created, plies] */
 void co_trainer_counters(const co_trainer *t, int64_t out[4]);
 
+/* ---- Match / Tourney (match.h, tourney.h:13-46) ---- */
+typedef struct co_tourney co_tourney;
+co_tourney *co_tourney_create(int num_threads);
+void co_tourney_destroy(co_tourney *t);
+int co_tourney_add_player(co_tourney *t, int player_id, int model_id, int max_searches, int searches_per_eval,
+                          float c_puct, float epsilon, int random);
+int co_tourney_add_match(co_tourney *t, int player1, int player2); /* returns the match index */
+int co_tourney_all_done(const co_tourney *t);
+int co_tourney_num_requests(const co_tourney *t, int id);
+void co_tourney_write_requests(const co_tourney *t, float *game_states, int id);
+void co_tourney_do_iteration(co_tourney *t, const float *eval, const float *probs, int id);
+int co_tourney_write_scores(const co_tourney *t, const char *filename);
+int co_tourney_num_matches(const co_tourney *t);
+int co_tourney_match_done(const co_tourney *t, int i);
+float co_tourney_match_score(const co_tourney *t, int i);
+int co_tourney_match_result(const co_tourney *t, int i);
+int co_tourney_match_to_play(const co_tourney *t, int i);
+int co_tourney_match_num_requests(const co_tourney *t, int i);
+/* per-ply trace as co_trainer_trace; a random player's ply is [-2, choice] */
+void co_tourney_enable_trace(co_tourney *t, int on);
+int co_tourney_trace(const co_tourney *t, int i, int32_t *out, int cap);
+void co_tourney_counters(const co_tourney *t, int64_t out[4]);
+/* std::uniform_int_distribution<int32_t>(0, n - 1) on the generator, as libstdc++ computes it */
+uint32_t co_uniform_below(co_mt19937 *g, uint32_t n);
+
 #ifdef __cplusplus
 }
 #endif

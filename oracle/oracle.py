@@ -81,6 +81,37 @@ def lib():
     L.co_trainer_trace.argtypes = [C.c_void_p, C.c_int, i32p, C.c_int]
     L.co_trainer_trace.restype = C.c_int
     L.co_trainer_counters.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+    vp = C.c_void_p
+    L.co_tourney_create.argtypes = [C.c_int]
+    L.co_tourney_create.restype = vp
+    L.co_tourney_destroy.argtypes = [vp]
+    L.co_tourney_add_player.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int]
+    L.co_tourney_add_player.restype = C.c_int
+    L.co_tourney_add_match.argtypes = [vp, C.c_int, C.c_int]
+    L.co_tourney_add_match.restype = C.c_int
+    L.co_tourney_all_done.argtypes = [vp]
+    L.co_tourney_all_done.restype = C.c_int
+    L.co_tourney_num_requests.argtypes = [vp, C.c_int]
+    L.co_tourney_num_requests.restype = C.c_int
+    L.co_tourney_write_requests.argtypes = [vp, f32p, C.c_int]
+    L.co_tourney_do_iteration.argtypes = [vp, f32p, f32p, C.c_int]
+    L.co_tourney_do_iteration.restype = None
+    L.co_tourney_write_scores.argtypes = [vp, C.c_char_p]
+    L.co_tourney_write_scores.restype = C.c_int
+    L.co_tourney_num_matches.argtypes = [vp]
+    L.co_tourney_num_matches.restype = C.c_int
+    for name in ("match_done", "match_result", "match_to_play", "match_num_requests"):
+        fn = getattr(L, "co_tourney_" + name)
+        fn.argtypes = [vp, C.c_int]
+        fn.restype = C.c_int
+    L.co_tourney_match_score.argtypes = [vp, C.c_int]
+    L.co_tourney_match_score.restype = C.c_float
+    L.co_tourney_enable_trace.argtypes = [vp, C.c_int]
+    L.co_tourney_trace.argtypes = [vp, C.c_int, i32p, C.c_int]
+    L.co_tourney_trace.restype = C.c_int
+    L.co_tourney_counters.argtypes = [vp, C.POINTER(C.c_int64)]
+    L.co_uniform_below.argtypes = [vp, C.c_uint32]
+    L.co_uniform_below.restype = C.c_uint32
     _lib = L
     return L
 
@@ -259,3 +290,70 @@ class Trainer:
         out = (C.c_int64 * 4)()
         lib().co_trainer_counters(self._t, out)
         return {"searches": out[0], "leaf_evals": out[1], "nodes_created": out[2], "plies": out[3]}
+
+
+class Tourney:
+    """The reference's Tourney surface (tourney.h:13-46 / rating/tourney.pyx:15-31) on the oracle."""
+
+    def __init__(self, num_threads=1, log_folder="", trace=False):
+        self._t = lib().co_tourney_create(num_threads)
+        if trace:
+            lib().co_tourney_enable_trace(self._t, 1)
+
+    def __del__(self):
+        if getattr(self, "_t", None):
+            lib().co_tourney_destroy(self._t)
+            self._t = None
+
+    def addPlayer(self, player_id, model_id, max_searches=1600, searches_per_eval=16, c_puct=1.0, epsilon=0.25,
+                  random=False):
+        if lib().co_tourney_add_player(self._t, player_id, model_id, max_searches, searches_per_eval, c_puct, epsilon,
+                                       int(bool(random))) != 0:
+            raise ValueError("addPlayer")
+
+    def addMatch(self, player1, player2, logging=False):
+        if lib().co_tourney_add_match(self._t, player1, player2) < 0:
+            raise ValueError("addMatch: unknown player")
+
+    def all_done(self):
+        return bool(lib().co_tourney_all_done(self._t))
+
+    def num_requests(self, id):
+        return lib().co_tourney_num_requests(self._t, id)
+
+    def writeRequests(self, game_states, id):
+        lib().co_tourney_write_requests(self._t, _f32(game_states), id)
+
+    def doIteration(self, evaluations, probabilities, id):
+        lib().co_tourney_do_iteration(self._t, _f32(evaluations), _f32(probabilities), id)
+
+    def writeScores(self, filename):
+        if lib().co_tourney_write_scores(self._t, str(filename).encode()) != 0:
+            raise OSError("cannot write " + str(filename))
+
+    def num_matches(self):
+        return lib().co_tourney_num_matches(self._t)
+
+    def match_info(self, i):
+        L = lib()
+        return {"done": L.co_tourney_match_done(self._t, i), "result": L.co_tourney_match_result(self._t, i),
+                "to_play": L.co_tourney_match_to_play(self._t, i), "n_pending": L.co_tourney_match_num_requests(self._t, i)}
+
+    def match_score(self, i):
+        return lib().co_tourney_match_score(self._t, i)
+
+    def trace(self, i):
+        n = lib().co_tourney_trace(self._t, i, None, 0)
+        out = np.zeros(max(n, 1), dtype=np.int32)
+        lib().co_tourney_trace(self._t, i, out.ctypes.data_as(C.POINTER(C.c_int32)), n)
+        return out[:n]
+
+    def counters(self):
+        out = (C.c_int64 * 4)()
+        lib().co_tourney_counters(self._t, out)
+        return {"searches": out[0], "leaf_evals": out[1], "nodes_created": out[2], "plies": out[3]}
+
+
+def uniform_below(gen, n):
+    """std::uniform_int_distribution<int32_t>(0, n - 1)(gen) as restated in the oracle"""
+    return int(lib().co_uniform_below(gen._g, n))

@@ -127,3 +127,31 @@ def check_sample_properties(gs, ev, pr, max_per_game=None):
     # every symmetry copy carries the same label
     e = ev.reshape(n, NSYM)
     assert np.all(e == e[:, :1])
+
+
+# ------------------------------------------------------------- tournament loop
+def play_tourney(tourney, model_ids, nets_by_model, rows, record=False, max_rounds=10**6):
+    """rating/tourney.pyx:113-160 play_games: for every model id in turn, evaluate that model's
+    requests and iterate its matches.  The three arrays are allocated once with `rows` rows
+    (tourney.pyx:118-120) and kept, so reads through the reference's offset table are defined."""
+    evals = np.zeros(rows, np.float32)
+    probs = np.zeros((rows, NM), np.float32)
+    game_states = np.zeros((rows, GS), np.float32)
+    log = []
+    rounds = 0
+    while not tourney.all_done():
+        for mid in model_ids:
+            n = tourney.num_requests(mid) if mid >= 0 else 0
+            if n > 0:
+                tourney.writeRequests(game_states, mid)
+                e, p = nets_by_model[mid](game_states[:n])
+                evals[:n] = e
+                probs[:n] = p
+                if record:
+                    log.append((mid, game_states[:n].copy()))
+            elif record:
+                log.append((mid, np.zeros((0, GS), np.float32)))
+            tourney.doIteration(evals, probs, mid)
+        rounds += 1
+        assert rounds < max_rounds, "tournament did not terminate"
+    return {"rounds": rounds, "log": log}

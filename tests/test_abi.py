@@ -66,3 +66,29 @@ def test_cpp_trainer_wrapper_compiles_and_links(tmp_path):
     subprocess.check_call(["g++", "-std=c++17", "-o", str(exe), str(src), "-L" + os.path.dirname(_lib.LIB_PATH),
                            "-lcorintho_hip", "-Wl,-rpath," + os.path.dirname(_lib.LIB_PATH)])
     subprocess.check_call([str(exe)])
+
+
+def test_cpp_tourney_wrapper_compiles_and_links(tmp_path):
+    """corintho_ai_amd/cpp/tourney.{h,cpp}: the reference's Tourney surface over the C ABI"""
+    from corintho_ai_amd import build
+
+    build.build()
+    src = tmp_path / "use.cpp"
+    src.write_text(
+        '#include "%s/corintho_ai_amd/cpp/tourney.cpp"\n'
+        "int main(int argc, char**) {\n"
+        "  if (argc > 100) {  // type-check the reference call pattern (rating/tourney.pyx:63-160)\n"
+        '    Tourney t(4, "logs");\n'
+        "    t.addPlayer(0, 0, 1600, 16, 1.0f, 0.25f, false); t.addPlayer(1, -1, 0, 0, 1.0f, 0.25f, true);\n"
+        "    t.addMatch(0, 1, false);\n"
+        "    float e[64], p[64 * 96], g[64 * 70];\n"
+        "    while (!t.all_done()) { if (t.num_requests(0) > 0) t.writeRequests(g, 0); t.doIteration(e, p, 0); }\n"
+        '    t.writeScores("scores.txt");\n'
+        "  }\n"
+        "  return 0;\n"
+        "}\n" % ROOT
+    )
+    exe = tmp_path / "use"
+    subprocess.check_call(["g++", "-std=c++17", "-o", str(exe), str(src), "-L" + os.path.dirname(_lib.LIB_PATH),
+                           "-lcorintho_hip", "-Wl,-rpath," + os.path.dirname(_lib.LIB_PATH)])
+    subprocess.check_call([str(exe)])

@@ -1,0 +1,123 @@
+"""Match / Tourney: the reference's tournament interface
+(corintho_ai/cpp/include/{match,tourney}.h, rating/tourney.pyx) on the oracle, the emulation
+build and -- with -m gpu -- the MI355X build; bit-exact per-ply traces, request rows, scores."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from corintho_ai_amd import Tourney, _lib
+from oracle import oracle as O
+from tests import harness as H
+from tests.engines import ENGINES, cdll
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _uid_lib():
+    so = os.path.join(HERE, "cxx", "libuid_check.so")
+    src = os.path.join(HERE, "cxx", "uid_check.cpp")
+    if not os.path.exists(so) or os.path.getmtime(src) > os.path.getmtime(so):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, src])
+    L = C.CDLL(so)
+    L.uid_draws.argtypes = [C.c_uint32, C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]
+    return L
+
+
+def test_uniform_int_distribution_restatement_matches_the_cxx_library():
+    """match.cpp:199-200 draws the random player's move with std::uniform_int_distribution on the
+    match's std::mt19937; the restatement must consume the stream exactly as libstdc++ does"""
+    L = _uid_lib()
+    rng = np.random.default_rng(1)
+    for seed in (5489, 1, 0xDEADBEEF):
+        ns = np.concatenate([rng.integers(1, 97, 4000), [1, 1, 2, 96, 3, 1]]).astype(np.int32)
+        want = np.zeros(ns.size, np.int32)
+        nxt = C.c_uint32()
+        L.uid_draws(seed, ns.ctypes.data_as(C.POINTER(C.c_int32)), ns.size, want.ctypes.data_as(C.POINTER(C.c_int32)),
+                    C.byref(nxt))
+        g = O.MT19937(seed)
+        got = [O.uniform_below(g, int(n)) for n in ns]
+        assert got == [int(x) for x in want]
+        assert g() == nxt.value
+
+
+# (player_id, model_id, max_searches, spe, c_puct, epsilon, random)
+PLAYERS_A = [(0, 0, 40, 8, 1.0, 0.25, False), (1, 1, 24, 4, 1.5, 0.25, False), (2, 0, 16, 16, 1.0, 0.0, False),
+             (3, -1, 0, 0, 1.0, 0.25, True)]
+MATCHES_A = [(0, 1), (1, 0), (2, 1), (0, 3), (3, 1), (0, 2), (1, 2), (2, 3)]
+# one network for everybody: every unfinished match then waits for the same id, the case in which
+# the reference's offset table (tourney.cpp:55-62) and its writeRequests order agree
+PLAYERS_B = [(0, 0, 32, 8, 1.0, 0.25, False), (1, 0, 48, 8, 3.0, 0.25, False)]
+MATCHES_B = [(0, 1), (1, 0), (0, 0), (1, 1), (0, 1)]
+
+
+def _build(factory, players, matches):
+    t = factory()
+    for p in players:
+        t.addPlayer(*p)
+    for a, b in matches:
+        t.addMatch(a, b, False)
+    return t
+
+
+def _rows(players, matches):
+    spe = {p[0]: p[3] for p in players}
+    return max(1, sum(spe[a] + spe[b] for a, b in matches))
+
+
+def _nets():
+    return {0: lambda s: H.hash_net(s, 11), 1: lambda s: H.hash_net(s, 22)}
+
+
+@pytest.mark.parametrize("players,matches", [(PLAYERS_A, MATCHES_A), (PLAYERS_B, MATCHES_B)], ids=["mixed", "one_model"])
+def test_oracle_tourney_plays_to_the_end(players, matches):
+    t = _build(lambda: O.Tourney(2, "", trace=True), players, matches)
+    model_ids = sorted({p[1] for p in players})
+    r = H.play_tourney(t, model_ids, _nets(), _rows(players, matches))
+    assert t.all_done() and r["rounds"] > 3
+    for i in range(t.num_matches()):
+        assert t.match_info(i)["done"] == 1
+        assert t.match_score(i) in (0.0, 0.5, 1.0)
+        assert t.match_info(i)["result"] in (1, 2, 3)  # loss / draw / win for the first player
+
+
+@pytest.mark.parametrize("engine", ENGINES)
+@pytest.mark.parametrize("players,matches", [(PLAYERS_A, MATCHES_A), (PLAYERS_B, MATCHES_B)], ids=["mixed", "one_model"])
+def test_tourney_matches_oracle(engine, players, matches, tmp_path):
+    """same players, same pairings, same stand-in networks: every evaluation request of every
+    round, every per-ply trace (incl. the random player's draws), results and the scores file"""
+    model_ids = sorted({p[1] for p in players})
+    rows = _rows(players, matches)
+    e = _build(lambda: Tourney(1, "", trace=True, _cdll=cdll(engine)), players, matches)
+    o = _build(lambda: O.Tourney(2, "", trace=True), players, matches)
+    ra = H.play_tourney(e, model_ids, _nets(), rows, record=True)
+    rb = H.play_tourney(o, model_ids, _nets(), rows, record=True)
+    assert ra["rounds"] == rb["rounds"]
+    assert [(a[0], a[1].tobytes()) for a in ra["log"]] == [(b[0], b[1].tobytes()) for b in rb["log"]]
+    for i in range(len(matches)):
+        assert np.array_equal(e.trace(i), o.trace(i)), "per-ply trace of match %d" % i
+        assert e.match_info(i)["result"] == o.match_info(i)["result"]
+        assert e.match_score(i) == o.match_score(i)
+        assert (e.match_info(i)["player1"], e.match_info(i)["player2"]) == matches[i]
+    c, st = o.counters(), e.stats()
+    assert (st["searches"], st["evals"], st["nodes"], st["plies"]) == (c["searches"], c["leaf_evals"],
+                                                                       c["nodes_created"], c["plies"])
+    fa, fb = tmp_path / "a.txt", tmp_path / "b.txt"
+    e.writeScores(fa)
+    o.writeScores(fb)
+    assert fa.read_text() == fb.read_text() and len(fa.read_text().splitlines()) == len(matches)
+
+
+@pytest.mark.parametrize("engine", ENGINES)
+def test_tourney_argument_errors(engine):
+    t = Tourney(1, "", _cdll=cdll(engine))
+    t.addPlayer(0, 0, 8, 4, 1.0, 0.25, False)
+    t.addPlayer(1, -1, 0, 0, 1.0, 0.25, True)
+    with pytest.raises(_lib.EngineError, match="unknown player"):
+        t.addMatch(0, 7, False)
+    with pytest.raises(_lib.EngineError, match="random"):
+        t.addMatch(1, 1, False)
+    with pytest.raises(_lib.EngineError, match="without matches"):
+        t.all_done()
