@@ -66,7 +66,7 @@ EXPORTS = [
     "ca_fp_probe",
     "ca_tourney_create", "ca_tourney_destroy", "ca_tourney_add_player", "ca_tourney_add_match", "ca_tourney_all_done",
     "ca_tourney_num_requests", "ca_tourney_write_requests", "ca_tourney_do_iteration", "ca_tourney_write_scores",
-    "ca_tourney_num_matches", "ca_tourney_match_info", "ca_tourney_match_score", "ca_tourney_trace", "ca_tourney_stats",
+    "ca_tourney_set_net", "ca_tourney_run", "ca_tourney_num_matches", "ca_tourney_match_info", "ca_tourney_match_score", "ca_tourney_trace", "ca_tourney_stats",
 ]
 
 
@@ -110,6 +110,8 @@ def declare(L):
     L.ca_tourney_write_requests.argtypes = [vp, f32p, C.c_int32]
     L.ca_tourney_do_iteration.argtypes = [vp, f32p, f32p, C.c_int32, C.c_int32]
     L.ca_tourney_write_scores.argtypes = [vp, C.c_char_p]
+    L.ca_tourney_set_net.argtypes = [vp, C.c_int32, C.c_int32, f32p, C.c_size_t]
+    L.ca_tourney_run.argtypes = [vp, C.c_int64, i32p]
     L.ca_tourney_num_matches.argtypes = [vp, i32p]
     L.ca_tourney_match_info.argtypes = [vp, C.c_int32, i32p]
     L.ca_tourney_match_score.argtypes = [vp, C.c_int32, f32p]

@@ -801,6 +801,67 @@ struct ca_tourney {
   std::mt19937 generator;                      /* default constructed: seed 5489 (tourney.h:43) */
   std::vector<uint32_t> seeds;
   std::unique_ptr<ca_trainer> pool;            /* built at the first query after the last addMatch */
+  struct PendingNet {
+    int kind;
+    std::vector<float> w;
+  };
+  std::map<int, PendingNet> net_specs;         /* fused mode: model id -> network (ca_tourney_set_net) */
+  std::map<int, std::unique_ptr<CoNet>> nets;
+
+  /* The loop of rating/tourney.pyx:122-160 with the networks on the GPU: for every model id in
+   * ascending order, pack that model's requests (Tourney::writeRequests), evaluate them, iterate
+   * its matches (Tourney::doIteration, which reads the evaluations through the reference's offset
+   * table).  The evaluation arrays persist between rounds like the driver's, so the result is the
+   * one the compat protocol gives with the same networks. */
+  bool run(int64_t max_rounds) {
+    ca_trainer &p = built();
+    std::vector<int> ids;
+    for (auto &m : matches)
+      for (int pid : {m.first, m.second}) {
+        int id = players.at(pid).model_id;
+        if (std::find(ids.begin(), ids.end(), id) == ids.end()) ids.push_back(id);
+      }
+    std::sort(ids.begin(), ids.end());
+    for (int id : ids) {
+      if (id < 0) continue;
+      if (!nets.count(id)) {
+        auto it = net_specs.find(id);
+        if (it == net_specs.end()) throw EngineError(CA_ERR_STATE, "ca_tourney_run: no network for model id " + std::to_string(id));
+        std::unique_ptr<CoNet> n(co_net_create(it->second.kind, it->second.w.data(), it->second.w.size(),
+                                               (size_t)p.G * p.spe, p.stream));
+        if (!n) throw EngineError(CA_ERR_ARG, "unknown net kind or bad weight count");
+        nets[id] = std::move(n);
+      }
+    }
+    int64_t rounds = 0;
+    bool done = p.tourney_all_done();
+    while (!done && (max_rounds <= 0 || rounds < max_rounds)) {
+      for (int id : ids) {
+        p.P.to_play = id;
+        p.P.iteration = p.trainer_iteration;
+        RT_LAUNCH(co_k_scan, 1, CO_WAVE, p.stream, p.P); /* offsets + batch of model `id` */
+        if (id >= 0) {
+          RT_LAUNCH(co_k_compact, p.G, CO_WAVE, p.stream, p.P);
+          nets[id]->forward(p.nn_in.p, p.G * p.spe, p.req_offset.p + p.G, p.nn_eval.p, p.nn_probs.p, p.stream);
+          ++p.nn_launches;
+        }
+        RT_LAUNCH(co_k_mcts_step, p.G, CO_WAVE, p.stream, p.P);
+        ++p.mcts_launches;
+        ++p.iterations;
+      }
+      ++rounds;
+      p.P.to_play = ids.front();
+      RT_LAUNCH(co_k_scan, 1, CO_WAVE, p.stream, p.P); /* refresh the all-done flag */
+      int32_t d = 0;
+      rt_d2h(&d, p.all_done.p, 4, p.stream);
+      rt_sync(p.stream);
+      done = d != 0;
+    }
+    p.scan_valid = false;
+    p.host_games_valid = false;
+    p.check_errors();
+    return done;
+  }
 
   ca_trainer &built() {
     if (pool) return *pool;
@@ -879,6 +940,20 @@ extern "C" int ca_tourney_add_match(ca_tourney *t, int32_t player1, int32_t play
   })
 }
 
+extern "C" int ca_tourney_set_net(ca_tourney *t, int32_t model_id, int32_t kind, const float *weights, size_t n_floats) {
+  CA_GUARD({
+    if (model_id < 0) throw EngineError(CA_ERR_ARG, "negative model ids are the dummy ids of random players");
+    if (!weights || n_floats == 0) throw EngineError(CA_ERR_ARG, "ca_tourney_set_net: no weights");
+    ca_tourney::PendingNet spec;
+    spec.kind = kind;
+    spec.w.assign(weights, weights + n_floats);
+    t->net_specs[model_id] = std::move(spec);
+    t->nets.erase(model_id);
+  })
+}
+extern "C" int ca_tourney_run(ca_tourney *t, int64_t max_rounds, int32_t *all_done) {
+  CA_GUARD(*all_done = t->run(max_rounds) ? 1 : 0)
+}
 extern "C" int ca_tourney_all_done(ca_tourney *t, int32_t *out) { CA_GUARD(*out = t->built().tourney_all_done() ? 1 : 0) }
 extern "C" int ca_tourney_num_requests(ca_tourney *t, int32_t id, int32_t *out) {
   CA_GUARD(*out = t->built().tourney_num_requests(id))

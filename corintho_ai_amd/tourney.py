@@ -68,6 +68,16 @@ class Tourney:
     def writeScores(self, filename):
         _lib.check(self._L, self._L.ca_tourney_write_scores(self._t, str(filename).encode()))
 
+    # ---- fused mode (not in the reference): the networks run on the GPU too
+    def set_net(self, model_id, kind, weights):
+        w = np.ascontiguousarray(weights, dtype=np.float32)
+        _lib.check(self._L, self._L.ca_tourney_set_net(self._t, model_id, kind, _f32(w, "weights"), w.size))
+
+    def run(self, max_rounds=0):
+        done = C.c_int32()
+        _lib.check(self._L, self._L.ca_tourney_run(self._t, max_rounds, C.byref(done)))
+        return bool(done.value)
+
     # ---- introspection
     def num_matches(self):
         out = C.c_int32()
@@ -96,3 +106,45 @@ class Tourney:
         s = _lib.CaStats()
         _lib.check(self._L, self._L.ca_tourney_stats(self._t, C.byref(s)))
         return {k: getattr(s, k) for k, _ in s._fields_}
+
+
+def read_pairings(player_file, match_file):
+    """The two text files of rating/tourney.pyx:63-111 (get_tourney):
+    players: first line the count, then per player `model_id max_searches searches_per_eval c_puct epsilon random`
+             (player ids are the line numbers);
+    matches: first line the count, then per match `player1 player2 logging`."""
+    players, matches = [], []
+    with open(player_file) as f:
+        n = int(f.readline())
+        for pid in range(n):
+            x = f.readline().split()
+            players.append((pid, int(x[0]), int(x[1]), int(x[2]), float(x[3]), float(x[4]), float(x[5]) == 1.0))
+    with open(match_file) as f:
+        n = int(f.readline())
+        for _ in range(n):
+            a, b, lg = (int(v) for v in f.readline().split())
+            matches.append((a, b, lg == 1))
+    return players, matches
+
+
+def run(model_paths, player_file, match_file, log_folder, num_threads=1, *, device=0):
+    """rating/tourney.pyx:179-end `run`, with the whole tournament on the GPU: `model_paths[i]` is
+    the TFLite checkpoint of model id i (imported by tflite_import), pairings come from the two
+    text files, the result goes to `<log_folder>/scores.txt`."""
+    import os
+
+    from .tflite_import import mlp12x100_from_tflite
+    from .trainer import NET_MLP12X100
+
+    players, matches = read_pairings(player_file, match_file)
+    t = Tourney(num_threads, log_folder, device=device)
+    for p in players:
+        t.addPlayer(*p)
+    for a, b, lg in matches:
+        t.addMatch(a, b, lg)
+    for mid in sorted({p[1] for p in players if p[1] >= 0}):
+        t.set_net(mid, NET_MLP12X100, mlp12x100_from_tflite(model_paths[mid]))
+    t.run()
+    os.makedirs(log_folder, exist_ok=True)
+    t.writeScores(os.path.join(log_folder, "scores.txt"))
+    return t

@@ -177,6 +177,12 @@ int ca_tourney_write_requests(ca_tourney *t, float *game_states, int32_t id);
  * table (tourney.cpp:55-62), which can differ from the writeRequests order */
 int ca_tourney_do_iteration(ca_tourney *t, const float *evaluations, const float *probabilities, int32_t rows,
                             int32_t id);
+/* Fused mode (not in the reference): the networks run on the GPU too.  ca_tourney_set_net
+ * gives model `model_id` its network (kinds and weight layouts as ca_trainer_set_net);
+ * ca_tourney_run plays the loop of rating/tourney.pyx:122-160 on the device, model ids in
+ * ascending order, until every match is done or `max_rounds` rounds have run (0 = no limit). */
+int ca_tourney_set_net(ca_tourney *t, int32_t model_id, int32_t kind, const float *weights, size_t n_floats);
+int ca_tourney_run(ca_tourney *t, int64_t max_rounds, int32_t *all_done);
 /* Tourney::writeScores, tourney.cpp:33-41 */
 int ca_tourney_write_scores(ca_tourney *t, const char *filename);
 int ca_tourney_num_matches(ca_tourney *t, int32_t *out);

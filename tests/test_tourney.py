@@ -121,3 +121,43 @@ def test_tourney_argument_errors(engine):
         t.addMatch(1, 1, False)
     with pytest.raises(_lib.EngineError, match="without matches"):
         t.all_done()
+
+
+@pytest.mark.parametrize("engine", ENGINES)
+def test_fused_tourney_replays_on_the_oracle(engine):
+    """networks on the device (ca_tourney_set_net / ca_tourney_run): the matches are the ones the
+    reference protocol plays when the driver evaluates the same networks"""
+    from corintho_ai_amd import nets
+    from tests.engines import make_trainer
+
+    players = [(0, 0, 40, 8, 1.0, 0.25, False), (1, 1, 32, 8, 1.0, 0.25, False), (2, 1, 24, 4, 2.0, 0.25, False),
+               (3, -1, 0, 0, 1.0, 0.25, True)]
+    matches = [(0, 1), (1, 0), (2, 0), (0, 3), (3, 2), (1, 2)]
+    weights = {0: nets.init_mlp12x100(seed=5, bn_noise=True), 1: nets.init_mlp12x100(seed=6, bn_noise=True)}
+    f = _build(lambda: Tourney(1, "", trace=True, _cdll=cdll(engine)), players, matches)
+    for mid, w in weights.items():
+        f.set_net(mid, 1, w)
+    assert not f.run(max_rounds=3)
+    assert f.run()
+    # the same networks evaluated for the oracle by the engine's kernels
+    evaluators = {}
+    for mid, w in weights.items():
+        t = make_trainer(engine, 64, "", 1, 50, 16, 1.0, 0.25, 0, 1, False)
+        t.set_net(1, w)
+        evaluators[mid] = t
+    o = _build(lambda: O.Tourney(2, "", trace=True), players, matches)
+    H.play_tourney(o, [-1, 0, 1], {mid: (lambda s, t=t: t.net_forward(s)) for mid, t in evaluators.items()},
+                   _rows(players, matches))
+    for i in range(len(matches)):
+        assert np.array_equal(f.trace(i), o.trace(i)), "per-ply trace of match %d" % i
+        assert f.match_score(i) == o.match_score(i)
+
+
+def test_pairing_files_are_read_like_the_reference_driver(tmp_path):
+    from corintho_ai_amd.tourney import read_pairings
+
+    (tmp_path / "players.txt").write_text("3\n0 1600 16 1.0 0.25 0\n4 800 8 1.5 0.1 0\n-1 0 0 1.0 0.25 1\n")
+    (tmp_path / "matches.txt").write_text("2\n0 1 0\n2 0 1\n")
+    players, matches = read_pairings(tmp_path / "players.txt", tmp_path / "matches.txt")
+    assert players == [(0, 0, 1600, 16, 1.0, 0.25, False), (1, 4, 800, 8, 1.5, 0.1, False), (2, -1, 0, 0, 1.0, 0.25, True)]
+    assert matches == [(0, 1, False), (2, 0, True)]
