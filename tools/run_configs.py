@@ -2,7 +2,8 @@
 """Run the other BASELINE.json configurations once each in fused mode and print one JSON
 line per configuration (games/s, device time split, arena high-water mark).
   cfg1: 64 games, 50 sims (plumbing)        cfg4: 4096 games, 1600 sims + Dirichlet noise
-  cfg5: arena, 1024 two-model games, testing=True, 400 sims"""
+  cfg5: arena, 1024 two-model games, testing=True, 400 sims
+  tourney: 1024 matches between 4 players of 2 models (+ a random player), fused"""
 import json
 import os
 import sys
@@ -10,9 +11,9 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from corintho_ai_amd import NET_MLP12X100, NET_RESCNN4_X3, Trainer, nets  # noqa: E402
+from corintho_ai_amd import NET_MLP12X100, NET_RESCNN4_X3, Tourney, Trainer, nets  # noqa: E402
 
-which = sys.argv[1:] or ["cfg1", "cfg4", "cfg5"]
+which = sys.argv[1:] or ["cfg1", "cfg4", "cfg5", "tourney"]
 net_kind = NET_RESCNN4_X3
 w0, w1 = nets.init_rescnn4(0), nets.init_rescnn4(1)
 
@@ -46,3 +47,39 @@ if "cfg4" in which:
     run("cfg4: 4096 games x 1600 sims + Dirichlet (deep-tree stress)", 4096, 1600)
 if "cfg5" in which:
     run("cfg5: arena, 1024 two-model games, greedy 400 sims", 1024, 400, testing=True)
+
+
+def run_tourney(n_matches=1024):
+    """round robin of 4 searching players (2 models, two search budgets) + games against a random player"""
+    def make():
+        t = Tourney(1, "")
+        t.addPlayer(0, 0, 400, 16, 1.0, 0.25, False)
+        t.addPlayer(1, 1, 400, 16, 1.0, 0.25, False)
+        t.addPlayer(2, 0, 100, 16, 1.0, 0.25, False)
+        t.addPlayer(3, 1, 100, 16, 1.0, 0.25, False)
+        t.addPlayer(4, -1, 0, 0, 1.0, 0.25, True)
+        pairs = [(a, b) for a in range(4) for b in range(4) if a != b] + [(0, 4), (4, 1)]
+        for i in range(n_matches):
+            t.addMatch(*pairs[i % len(pairs)], False)
+        t.set_net(0, net_kind, w0)
+        t.set_net(1, net_kind, w1)
+        return t
+
+    t = make()
+    t.run()  # warm (kernels, allocations)
+    t.close()
+    t = make()
+    t0 = time.perf_counter()
+    assert t.run()
+    dt = time.perf_counter() - t0
+    st = t.stats()
+    score = sum(t.match_score(i) for i in range(n_matches)) / n_matches
+    print(json.dumps({"config": "tourney: %d matches, 5 players, 2 models + random" % n_matches, "matches": n_matches,
+                      "net": "rescnn4x3", "seconds": dt, "matches_per_s": n_matches / dt, "iterations": st["iterations"],
+                      "searches": st["searches"], "evals": st["evals"], "plies_per_match": st["plies"] / n_matches,
+                      "mean_first_player_score": score}), flush=True)
+    t.close()
+
+
+if "tourney" in which:
+    run_tourney()
