@@ -1054,73 +1054,6 @@ CO_DEV int co_receive_opponent_move(CoWave &w, CoTree &t, int move_choice, uint6
   return 1;
 }
 
-/* SelfPlayer::chooseMoveAndContinue, selfplayer.cpp:246-291 (+ chooseMove
- * :234-244, endGame :206-232).  Returns "game over". */
-CO_DEV int co_choose_move_and_continue(CoWave &w) {
-  int need_eval = 0;
-  while (!need_eval) {
-    if (w.gc.error) return 0;
-    int p = w.gc.to_play;
-    CoTree &me = w.me;
-    uint4 rs = co_load_unit(me.A, co_load_unit(me.A, me.tc.root + 1).x);
-    if (co_res_known(co_slot_result(rs)) && w.gc.mate_turn == 0) w.gc.mate_turn = w.gc.n_samples + 1;
-    float *sample = (float *)0;
-    if (!w.testing) {
-      if (w.gc.n_samples >= CO_MAX_PLIES) {
-        w.gc.error |= CO_ERR_TOO_MANY_PLIES;
-        return 0;
-      }
-      sample = w.samples + (size_t)w.gc.n_samples * CO_SAMPLE_FLOATS;
-    }
-    int choice = co_choose_move(w, me, sample);
-    if (w.gc.error) return 0;
-    if (!w.testing) w.gc.n_samples++;
-    co_trace_push(w, choice);
-    w.gc.plies++;
-    /* new root of the mover */
-    uint4 h0 = co_load_unit(me.A, me.tc.root);
-    uint4 nrs = co_load_unit(me.A, co_load_unit(me.A, me.tc.root + 1).x);
-    int nres = co_slot_result(nrs);
-    if (co_res_terminal(nres)) {
-      if (nres == CO_RESULT_DRAW) w.gc.result = CO_RESULT_DRAW;
-      else if (p == 1) w.gc.result = CO_RESULT_LOSS;
-      else w.gc.result = CO_RESULT_WIN;
-      return 1;
-    }
-    /* hand over: the opponent becomes the player to move */
-    w.gc.to_play = 1 - p;
-    {
-      CoTree tmp = w.me;
-      w.me = w.opp;
-      w.opp = tmp;
-    }
-    CoTree &opp = w.me; /* the new player to move */
-    uint64_t board = (uint64_t)h0.x | ((uint64_t)h0.y << 32);
-    int depth = (int)CO_META_DEPTH(h0.z);
-    if (opp.tc.root == CO_NONE) {
-      /* first move of the second player: createRoot + doIteration */
-      int res;
-      uint32_t b = co_create_node(w, opp, board, h0.z, depth, CO_NONE, CO_NONE, &res);
-      if (b == CO_NONE) return 0;
-      opp.tc.root = b;
-      return co_mc_do_iteration(w, opp, (const float *)0, (const float *)0);
-    }
-    need_eval = co_receive_opponent_move(w, opp, choice, board, h0.z, depth);
-    if (!need_eval) {
-      if (w.defer_handover) {
-        /* Lock-step scheduling only: games are independent, so the new mover's first
-         * searches may as well run in the next step.  Without this, the few games that
-         * change turns in a step run up to twice the simulations of the others and every
-         * launch waits for them.  The game's own sequence of operations is unchanged. */
-        w.gc.resume = 1;
-        return 0;
-      }
-      need_eval = !co_mc_do_iteration(w, opp, (const float *)0, (const float *)0);
-    }
-  }
-  return 0;
-}
-
 /* Tournament matches (match.h, match.cpp): the two sides search with their own settings */
 CO_DEV void co_use_player(CoWave &w, int p) {
   if (!w.pc) return;
@@ -1160,19 +1093,45 @@ CO_DEV int co_nth_move(const uint32_t lm[3], int k) {
   return -1;
 }
 
-/* Match::chooseMoveAndContinue, match.cpp:207-251 (+ chooseMove :192-205, endGame :163-190).
- * gc.pos_* is Match::root_; a random player (players_[i] == nullptr) has no tree.  Returns
- * "game over". */
-CO_DEV int co_match_choose_move_and_continue(CoWave &w) {
-  int need_eval = 0;
-  while (!need_eval) {
-    if (w.gc.error) return 0;
+/* One step of a game:
+ *   self-play   SelfPlayer::doIteration (selfplayer.cpp:115-122) + chooseMoveAndContinue
+ *               (:246-291; chooseMove :234-244, endGame :206-232),
+ *   tournament  Match::doIteration (match.cpp:67-79) + chooseMoveAndContinue (:207-251; chooseMove
+ *               :192-205, endGame :163-190); gc.pos_* is Match::root_, a random side
+ *               (players_[i] == nullptr) has no tree.
+ * The reference's mutual recursion doIteration -> chooseMoveAndContinue -> doIteration is
+ * written as ONE loop so that the kernel holds a single copy of the search, of the move choice
+ * and of the hand-over: inlined along the call chain they were repeated up to seven times
+ * (250 KB of instructions in front of a 64 KB instruction cache).  Returns "game over". */
+CO_DEV int co_game_step(CoWave &w, const float *eval, const float *probs) {
+  const float *ev = eval, *pr = probs;
+  if (w.gc.resume) {
+    /* continuation of a deferred hand-over: selfplayer.cpp:287-288 */
+    w.gc.resume = 0;
+    ev = pr = (const float *)0;
+  }
+  int skip_iteration = w.pc && w.pc[w.gc.to_play].random; /* match.cpp:68-70 */
+  int fresh_root = 0;
+  for (;;) {
+    if (!skip_iteration) {
+      int done = co_mc_do_iteration(w, w.me, ev, pr);
+      if (w.gc.error) return 0;
+      /* `return players_[to_play_]->doIteration()` after createRoot (selfplayer.cpp:281-283,
+       * match.cpp:236-239): the new root asks for its evaluation, so this is "not over" */
+      if (fresh_root) return done;
+      if (!done) return 0;
+    }
+    skip_iteration = 0;
+    ev = pr = (const float *)0;
+    /* ---- chooseMoveAndContinue, one ply per pass of the loop */
+    unsigned long long t0 = CO_CLK();
     int p = w.gc.to_play;
-    uint64_t board = (uint64_t)w.gc.pos_lo | ((uint64_t)w.gc.pos_hi << 32);
-    uint32_t meta = w.gc.pos_meta;
-    int choice;
-    int terminal, tres;
-    if (w.pc[p].random) {
+    int choice, terminal, tres, depth;
+    uint64_t board;
+    uint32_t meta;
+    if (w.pc && w.pc[p].random) {
+      board = (uint64_t)w.gc.pos_lo | ((uint64_t)w.gc.pos_hi << 32);
+      meta = w.gc.pos_meta;
       uint32_t lm[3];
       co_legal_moves(board, meta, lm);
       int n = co_popc32(lm[0]) + co_popc32(lm[1]) + co_popc32(lm[2]);
@@ -1181,30 +1140,51 @@ CO_DEV int co_match_choose_move_and_continue(CoWave &w) {
       co_trace_push(w, choice);
       w.gc.plies++;
       co_do_move(&board, &meta, choice);
-      uint32_t lm2[3];
-      int lines = co_legal_moves(board, meta, lm2);
-      terminal = (lm2[0] | lm2[1] | lm2[2]) == 0u;
+      int lines = co_legal_moves(board, meta, lm);
+      terminal = (lm[0] | lm[1] | lm[2]) == 0u;
       tres = lines ? CO_RESULT_LOSS : CO_RESULT_DRAW;
+      depth = w.gc.plies; /* root_->depth() */
     } else {
-      choice = co_choose_move(w, w.me, (float *)0);
+      CoTree &me = w.me;
+      if (!w.pc) {
+        uint4 rs = co_load_unit(me.A, co_load_unit(me.A, me.tc.root + 1).x);
+        if (co_res_known(co_slot_result(rs)) && w.gc.mate_turn == 0) w.gc.mate_turn = w.gc.n_samples + 1;
+      }
+      float *sample = (float *)0;
+      if (!w.testing) {
+        if (w.gc.n_samples >= CO_MAX_PLIES) {
+          w.gc.error |= CO_ERR_TOO_MANY_PLIES;
+          return 0;
+        }
+        sample = w.samples + (size_t)w.gc.n_samples * CO_SAMPLE_FLOATS;
+      }
+      choice = co_choose_move(w, me, sample);
       if (w.gc.error) return 0;
+      if (!w.testing) w.gc.n_samples++;
       co_trace_push(w, choice);
       w.gc.plies++;
-      co_do_move(&board, &meta, choice);
-      uint4 nrs = co_load_unit(w.me.A, co_load_unit(w.me.A, w.me.tc.root + 1).x);
+      /* new root of the mover = the position on the board */
+      uint4 h0 = co_load_unit(me.A, me.tc.root);
+      uint4 nrs = co_load_unit(me.A, co_load_unit(me.A, me.tc.root + 1).x);
       tres = co_slot_result(nrs);
       terminal = co_res_terminal(tres);
+      board = (uint64_t)h0.x | ((uint64_t)h0.y << 32);
+      meta = h0.z;
+      depth = (int)CO_META_DEPTH(h0.z);
     }
-    w.gc.pos_lo = (uint32_t)board;
-    w.gc.pos_hi = (uint32_t)(board >> 32);
-    w.gc.pos_meta = meta;
-    int depth = w.gc.plies; /* root_->depth() */
+    if (w.pc) {
+      w.gc.pos_lo = (uint32_t)board;
+      w.gc.pos_hi = (uint32_t)(board >> 32);
+      w.gc.pos_meta = meta & 0x7FFFFu; /* reserves and side to move */
+    }
+    CO_PROF_ADD(w, 2, CO_CLK() - t0);
     if (terminal) {
       if (tres == CO_RESULT_DRAW) w.gc.result = CO_RESULT_DRAW;
       else if (p == 1) w.gc.result = CO_RESULT_LOSS;
       else w.gc.result = CO_RESULT_WIN;
       return 1;
     }
+    /* hand over: the opponent becomes the player to move */
     w.gc.to_play = 1 - p;
     {
       CoTree tmp = w.me;
@@ -1212,48 +1192,31 @@ CO_DEV int co_match_choose_move_and_continue(CoWave &w) {
       w.opp = tmp;
     }
     co_use_player(w, 1 - p);
-    if (w.pc[1 - p].random) continue;
-    CoTree &me = w.me;
-    if (me.tc.root == CO_NONE) {
-      int res;
-      uint32_t b = co_create_node(w, me, board, meta, depth, CO_NONE, CO_NONE, &res);
-      if (b == CO_NONE) return 0;
-      me.tc.root = b;
-      return co_mc_do_iteration(w, me, (const float *)0, (const float *)0);
+    if (w.pc && w.pc[1 - p].random) {
+      skip_iteration = 1;
+      continue;
     }
-    need_eval = co_receive_opponent_move(w, me, choice, board, meta, depth);
-    if (!need_eval) need_eval = !co_mc_do_iteration(w, me, (const float *)0, (const float *)0);
+    CoTree &nm = w.me; /* the new player to move */
+    if (nm.tc.root == CO_NONE) {
+      /* first move of the second player: createRoot + doIteration */
+      int res;
+      uint32_t b = co_create_node(w, nm, board, meta, depth, CO_NONE, CO_NONE, &res);
+      if (b == CO_NONE) return 0;
+      nm.tc.root = b;
+      fresh_root = 1;
+      continue;
+    }
+    if (co_receive_opponent_move(w, nm, choice, board, meta, depth)) return 0; /* needs an evaluation */
+    if (w.defer_handover) {
+      /* Lock-step scheduling only: games are independent, so the new mover's first searches
+       * may as well run in the next step.  Without this, the few games that change turns in
+       * a step run up to twice the simulations of the others and every launch waits for
+       * them.  The game's own sequence of operations is unchanged. */
+      w.gc.resume = 1;
+      return 0;
+    }
+    /* else: `need_eval = !doIteration()` -- search on; a finished turn chooses again */
   }
-  return 0;
-}
-
-/* Match::doIteration, match.cpp:67-79 */
-CO_DEV int co_match_do_iteration(CoWave &w, const float *eval, const float *probs) {
-  if (w.pc[w.gc.to_play].random) return co_match_choose_move_and_continue(w);
-  int done = co_mc_do_iteration(w, w.me, eval, probs);
-  if (w.gc.error) return 0;
-  if (done) return co_match_choose_move_and_continue(w);
-  return 0;
-}
-
-/* SelfPlayer::doIteration, selfplayer.cpp:115-122 */
-CO_DEV int co_sp_do_iteration(CoWave &w, const float *eval, const float *probs) {
-  int done;
-  if (w.gc.resume) {
-    /* continuation of a deferred hand-over: selfplayer.cpp:287-288 */
-    w.gc.resume = 0;
-    done = co_mc_do_iteration(w, w.me, (const float *)0, (const float *)0);
-  } else {
-    done = co_mc_do_iteration(w, w.me, eval, probs);
-  }
-  if (w.gc.error) return 0;
-  if (done) {
-    unsigned long long t0 = CO_CLK();
-    int r = co_choose_move_and_continue(w);
-    CO_PROF_ADD(w, 2, CO_CLK() - t0);
-    return r;
-  }
-  return 0;
 }
 
 /* Trainer::doIteration for game g (trainer.cpp:164-236): the body of the
@@ -1312,8 +1275,7 @@ CO_DEV void co_mcts_step_wave(const EngineParams &P, int g) {
   unsigned long long t_real0 = __builtin_amdgcn_s_memrealtime();
 #endif
   int off = P.fused_pack ? gc.row_off : P.read_offset ? P.read_offset[g] : P.req_offset[g];
-  int done = w.pc ? co_match_do_iteration(w, P.nn_eval + off, P.nn_probs + (size_t)off * CO_NUM_MOVES)
-                  : co_sp_do_iteration(w, P.nn_eval + off, P.nn_probs + (size_t)off * CO_NUM_MOVES);
+  int done = co_game_step(w, P.nn_eval + off, P.nn_probs + (size_t)off * CO_NUM_MOVES);
   if (done) w.gc.done = 1;
   if (P.fused_pack && !w.gc.done && !w.gc.error) {
     /* Trainer::writeRequests fused into the step: reserve rows of the compact batch
