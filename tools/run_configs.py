@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from corintho_ai_amd import NET_MLP12X100, NET_RESCNN4_X3, Tourney, Trainer, nets  # noqa: E402
 
-which = sys.argv[1:] or ["cfg1", "cfg4", "cfg5", "tourney"]
+which = sys.argv[1:] or ["cfg1", "cfg4", "cfg5", "tourney", "compat"]
 net_kind = NET_RESCNN4_X3
 w0, w1 = nets.init_rescnn4(0), nets.init_rescnn4(1)
 
@@ -83,3 +83,35 @@ def run_tourney(n_matches=1024):
 
 if "tourney" in which:
     run_tourney()
+
+
+def run_compat(G=4096, S=400):
+    """the reference protocol (compat mode): request rows come back to the host every iteration,
+    the caller evaluates them (here: on the same GPU through ca_trainer_net_forward, i.e. another
+    host round trip) and hands evaluations in -- the PCIe-inclusive rate of DESIGN.md section 6"""
+    import numpy as np
+
+    t = Trainer(G, "", 12345, S, 16, 1.0, 0.25, 0, 1, False, stagger=False)
+    t.set_net(net_kind, w0)
+    cap = G * 16
+    evals = np.zeros(cap, np.float32)
+    probs = np.zeros((cap, 96), np.float32)
+    gs = np.zeros((cap, 70), np.float32)
+    t0 = time.perf_counter()
+    iters = 0
+    while not t.doIteration(evals, probs, -1):
+        n = t.num_requests(-1)
+        t.writeRequests(gs, -1)
+        e, p = t.net_forward(gs[:n])
+        evals[:n] = e
+        probs[:n] = p
+        iters += 1
+    dt = time.perf_counter() - t0
+    print(json.dumps({"config": "compat: %d games x %d sims, host-driven protocol, network via net_forward" % (G, S),
+                      "games": G, "sims": S, "net": "rescnn4x3", "seconds": dt, "games_per_s": G / dt, "iterations": iters}),
+          flush=True)
+    t.close()
+
+
+if "compat" in which:
+    run_compat()
