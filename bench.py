@@ -256,7 +256,7 @@ def main():
                         "algorithmic": "%.0f B/simulation x %d simulations" % (BYTES_PER_SIM, totals["searches"]),
                         "avg_launch_ms": totals["mcts_ms"] / max(totals["mcts_launches"], 1)}
         roofline["streams"] = npools
-        if npools > 1 and not args.no_unshared:
+        if npools > 1 and not args.no_unshared and world == 1:
             # The timed region runs the games as `npools` pools on separate streams, so the durations
             # above are those of kernels SHARING the GPU with the other pool's kernels (their sum
             # exceeds the wall time).  One more generation with a single pool gives the same kernel's
