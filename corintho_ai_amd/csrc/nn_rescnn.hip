@@ -368,8 +368,10 @@ __global__ __launch_bounds__(256, 2) void co_k_rescnn_forward(RcParams P) {
 #define RC3_CONV_CHUNK 4096 /* u32: 4 k-steps ... = 16 KB */
 #define RC3_TRUNK_WORDS (9 * RC3_STEM_CHUNK + 72 * RC3_CONV_CHUNK)
 /* head weights staged once per workgroup behind the two trunk groups and the head features:
- * 1x1 fragments (2048 words), policy dense (6144), value dense 1 (2048), value dense 2 (1024) */
-#define RC3_HEAD_WORDS (2048 + 6144 + 2048 + 1024)
+ * 1x1 fragments (2048 words), policy dense (6144), value dense 1 (2048), value dense 2 (1024),
+ * epilogue constants of the nine convolutions (1728, padded) */
+#define RC3_EPI_WORDS 1792 /* 9 convolutions x (bias, BN scale, BN shift)[64], padded to whole 256-word pieces */
+#define RC3_HEAD_WORDS (2048 + 6144 + 2048 + 1024 + RC3_EPI_WORDS)
 #define RC3_LDS_BYTES (2 * 3 * RC3_CONV_CHUNK * 4 + 8 * RC_NB * 96 * 4 + RC3_HEAD_WORDS * 4)
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -627,18 +629,19 @@ __global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_x3(Rc3Params Q) {
   int ch = 0;
   rc3_conv3x3<1>(acc, ph, pl, ch, Q.wtrunk, lds_w, wave, lane, okL, okR);
   RC3_STAMP(1)
-  rc3_epilogue<false>(x, acc, x, P.epi, h);
+  const float *lds_epi = reinterpret_cast<const float *>(lds_head + 2048 + 6144 + 2048 + 1024);
+  rc3_epilogue<false>(x, acc, x, lds_epi, h);
   rc3_pack(ph, pl, x);
   RC3_STAMP(2)
   for (int b = 0; b < 4; ++b) {
     rc3_conv3x3<4>(acc, ph, pl, ch, Q.wtrunk, lds_w, wave, lane, okL, okR);
     RC3_STAMP(3)
-    rc3_epilogue<false>(y, acc, x, P.epi + (size_t)(1 + 2 * b) * 192, h);
+    rc3_epilogue<false>(y, acc, x, lds_epi + (1 + 2 * b) * 192, h);
     rc3_pack(ph, pl, y);
     RC3_STAMP(2)
     rc3_conv3x3<4>(acc, ph, pl, ch, Q.wtrunk, lds_w, wave, lane, okL, okR);
     RC3_STAMP(3)
-    rc3_epilogue<true>(x, acc, x, P.epi + (size_t)(2 + 2 * b) * 192, h);
+    rc3_epilogue<true>(x, acc, x, lds_epi + (2 + 2 * b) * 192, h);
     rc3_pack(ph, pl, x);
     RC3_STAMP(2)
   }
@@ -886,6 +889,7 @@ struct ResCnnX3Net : ResCnnNet {
     rt_d2d(d_whead3 + 2048, P.wpol, 6144 * 4, s); /* the dense weights in the base class's MFMA order */
     rt_d2d(d_whead3 + 2048 + 6144, P.wv1, 2048 * 4, s);
     rt_d2d(d_whead3 + 2048 + 6144 + 2048, P.wv2, 1024 * 4, s);
+    rt_d2d(d_whead3 + 2048 + 6144 + 2048 + 1024, P.epi, (size_t)RC_NUM_CONVS * 192 * 4, s);
     rt_sync(s);
   }
   ~ResCnnX3Net() override {
