@@ -431,18 +431,60 @@ __device__ __forceinline__ uint32_t rc3_tap(uint32_t v, bool okL, bool okR) {
   return s;
 }
 
+/* The four packed words of one B operand shifted to tap (dy, dx).  For dx != 0 the shift and
+ * the zeroing of the lanes whose source pixel lies in the neighbouring board row are ONE
+ * instruction, v_cndmask_b32 with a DPP source: D = vcc ? 0 : row_shift(v) with vcc = the wrap
+ * lanes (x = 0 for dx = -1, x = 3 for dx = +1; a constant lane pattern).  As two instructions
+ * (v_mov_b32_dpp + v_cndmask_b32_e64) the B-operand preparation took 2.7 vector issues per MFMA
+ * and, with two waves per SIMD, left the issue port nearly full.  The trailing s_nop 1 covers
+ * the VALU-write -> MFMA-read wait states that the compiler cannot see into the asm for. */
+#define RC3_CNDMASK_DPP4(CTRL)                                                                          \
+  asm("s_mov_b64 vcc, %[m]\n\t"                                                                         \
+      "v_cndmask_b32_dpp %[o0], %[i0], %[z], vcc " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"   \
+      "v_cndmask_b32_dpp %[o1], %[i1], %[z], vcc " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"   \
+      "v_cndmask_b32_dpp %[o2], %[i2], %[z], vcc " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"   \
+      "v_cndmask_b32_dpp %[o3], %[i3], %[z], vcc " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"   \
+      "s_nop 1"                                                                                         \
+      : [o0] "=&v"(o0), [o1] "=&v"(o1), [o2] "=&v"(o2), [o3] "=&v"(o3)                                  \
+      : [i0] "v"(in[0]), [i1] "v"(in[1]), [i2] "v"(in[2]), [i3] "v"(in[3]), [z] "v"(zero), [m] "s"(wrap) \
+      : "vcc")
+
+template <int TAP>
+__device__ __forceinline__ u32x4 rc3_tap4(const uint32_t (&in)[4], uint32_t zero) {
+  constexpr int dy = TAP / 3 - 1, dx = TAP % 3 - 1;
+  u32x4 out;
+  if constexpr (dx == 0) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) out[m] = rc3_row_shift<4 * dy>(in[m]);
+  } else {
+    const unsigned long long wrap = dx < 0 ? 0x1111111111111111ull : 0x8888888888888888ull;
+    uint32_t o0, o1, o2, o3;
+    if constexpr (4 * dy + dx == -5) RC3_CNDMASK_DPP4("row_shr:5");
+    if constexpr (4 * dy + dx == -3) RC3_CNDMASK_DPP4("row_shr:3");
+    if constexpr (4 * dy + dx == -1) RC3_CNDMASK_DPP4("row_shr:1");
+    if constexpr (4 * dy + dx == 1) RC3_CNDMASK_DPP4("row_shl:1");
+    if constexpr (4 * dy + dx == 3) RC3_CNDMASK_DPP4("row_shl:3");
+    if constexpr (4 * dy + dx == 5) RC3_CNDMASK_DPP4("row_shl:5");
+    out[0] = o0;
+    out[1] = o1;
+    out[2] = o2;
+    out[3] = o3;
+  }
+  return out;
+}
+
 /* tap as a value: after full unrolling every call site has a constant tap and folds to one case */
-__device__ __forceinline__ uint32_t rc3_tap_sel(uint32_t v, int tap, bool okL, bool okR) {
+__device__ __forceinline__ u32x4 rc3_tap4_sel(const uint32_t (&in)[4], int tap, uint32_t zero) {
   switch (tap) {
-    case 0: return rc3_tap<0>(v, okL, okR);
-    case 1: return rc3_tap<1>(v, okL, okR);
-    case 2: return rc3_tap<2>(v, okL, okR);
-    case 3: return rc3_tap<3>(v, okL, okR);
-    case 4: return rc3_tap<4>(v, okL, okR);
-    case 5: return rc3_tap<5>(v, okL, okR);
-    case 6: return rc3_tap<6>(v, okL, okR);
-    case 7: return rc3_tap<7>(v, okL, okR);
-    default: return rc3_tap<8>(v, okL, okR);
+    case 0: return rc3_tap4<0>(in, zero);
+    case 1: return rc3_tap4<1>(in, zero);
+    case 2: return rc3_tap4<2>(in, zero);
+    case 3: return rc3_tap4<3>(in, zero);
+    case 4: return rc3_tap4<4>(in, zero);
+    case 5: return rc3_tap4<5>(in, zero);
+    case 6: return rc3_tap4<6>(in, zero);
+    case 7: return rc3_tap4<7>(in, zero);
+    default: return rc3_tap4<8>(in, zero);
   }
 }
 
@@ -456,6 +498,8 @@ __device__ __forceinline__ void rc3_conv_group(f32x16 (&acc)[RC3_NP][2], const u
                                                bool okL, bool okR) {
   constexpr int tw = CS == 1 ? RC3_STEM_CHUNK : RC3_CONV_CHUNK;
   constexpr int N = 3 * CS;
+  uint32_t zero;
+  asm("v_mov_b32 %0, 0" : "=v"(zero)); /* a zero the compiler keeps in a VGPR (second cndmask source) */
   u32x4 ah[2][2], al[2][2];
 #pragma unroll
   for (int to = 0; to < 2; ++to) {
@@ -477,12 +521,8 @@ __device__ __forceinline__ void rc3_conv_group(f32x16 (&acc)[RC3_NP][2], const u
     }
 #pragma unroll
     for (int np = 0; np < RC3_NP; ++np) {
-      u32x4 bh, bl;
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        bh[m] = rc3_tap_sel(ph[np][s][m], 3 * G + tg, okL, okR);
-        bl[m] = rc3_tap_sel(pl[np][s][m], 3 * G + tg, okL, okR);
-      }
+      const u32x4 bh = rc3_tap4_sel(ph[np][s], 3 * G + tg, zero);
+      const u32x4 bl = rc3_tap4_sel(pl[np][s], 3 * G + tg, zero);
       const bf16x8 Bh = __builtin_bit_cast(bf16x8, bh), Bl = __builtin_bit_cast(bf16x8, bl);
 #pragma unroll
       for (int to = 0; to < 2; ++to)
