@@ -107,6 +107,7 @@ def cpu_baseline(args, weights, net_name="mlp12x100"):
         pass
     t = O.Trainer(G, seed=12345, max_searches=args.sims, searches_per_eval=args.spe, c_puct=args.c_puct,
                   epsilon=args.epsilon, num_threads=cores)
+    t.set_stagger(False)  # as the GPU run
     nn_time = [0.0]
 
     if net_name == "rescnn4":
@@ -126,6 +127,23 @@ def cpu_baseline(args, weights, net_name="mlp12x100"):
     t0 = time.perf_counter()
     H.play_generation(t, G, args.spe, net)
     dt = time.perf_counter() - t0
+    # the search alone on a larger sample (enough games to keep every thread busy), with a
+    # zero-cost stand-in network: the upper bound of the CPU path whatever the inference costs
+    G2 = 16 * G
+    t2 = O.Trainer(G2, seed=12345, max_searches=args.sims, searches_per_eval=args.spe, c_puct=args.c_puct,
+                   epsilon=args.epsilon, num_threads=cores)
+    t2.set_stagger(False)
+    nn2 = [0.0]
+
+    def fake(states):
+        t1 = time.perf_counter()
+        out = H.uniform_net(states)
+        nn2[0] += time.perf_counter() - t1
+        return out
+
+    t0 = time.perf_counter()
+    H.play_generation(t2, G2, args.spe, fake)
+    dt2 = time.perf_counter() - t0 - nn2[0]
     return {
         "value": G / dt,
         "unit": "games/s",
@@ -134,7 +152,8 @@ def cpu_baseline(args, weights, net_name="mlp12x100"):
         "sample": "%d games x %d sims/move, spe %d, oracle/ (OpenMP, %d threads) + fp32 %s on the host (%s); "
                   "%.1f s total, %.1f s of it network" % (G, args.sims, args.spe, cores, net_name,
                                                           "torch CPU" if net_name == "rescnn4" else "numpy", dt, nn_time[0]),
-        "mcts_only_games_per_s": G / max(dt - nn_time[0], 1e-9),
+        "mcts_only_games_per_s": G2 / max(dt2, 1e-9),
+        "mcts_only_sample": "%d games, uniform stand-in network (its cost excluded), %.1f s" % (G2, dt2),
     }
 
 
