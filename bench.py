@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--spe", type=int, default=16)
     ap.add_argument("--c-puct", type=float, default=1.0)
     ap.add_argument("--epsilon", type=float, default=0.25)
-    ap.add_argument("--net", default="rescnn4x3", choices=["mlp12x100", "rescnn4", "rescnn4x3"],
+    ap.add_argument("--net", default="rescnn4x3", choices=["mlp12x100", "mlp12x100x3", "rescnn4", "rescnn4x3"],
                     help="rescnn4x3 (default) = the 4-block residual CNN BASELINE.json configs[1] names, convolutions at "
                          "bf16x3 split precision (within 2e-5 of fp32); rescnn4 = the same network on fp32 MFMA; "
                          "mlp12x100 = the reference's own net")
@@ -176,17 +176,17 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    from corintho_ai_amd import NET_MLP12X100, NET_RESCNN4, NET_RESCNN4_X3, Trainer, nets
+    from corintho_ai_amd import NET_MLP12X100, NET_MLP12X100_X3, NET_RESCNN4, NET_RESCNN4_X3, Trainer, nets
 
     G = args.games
-    if args.net == "mlp12x100":
+    if args.net in ("mlp12x100", "mlp12x100x3"):
         if args.tflite:
             from corintho_ai_amd.tflite_import import mlp12x100_from_tflite
 
             weights = mlp12x100_from_tflite(args.tflite)
         else:
             weights = nets.init_mlp12x100(0)
-        kind = NET_MLP12X100
+        kind = NET_MLP12X100_X3 if args.net == "mlp12x100x3" else NET_MLP12X100
         flop_per_row = 2.0 * (70 * 100 + 11 * 100 * 100 + 100 + 100 * 96)
     else:
         weights = nets.init_rescnn4(0)
@@ -258,13 +258,13 @@ def main():
         # dominant kernel = the family with more device time on rank 0
         if nn_s >= mcts_s:
             achieved = totals["nn_rows"] * flop_per_row / max(nn_s, 1e-12) / 1e12
-            peak = BF16_MFMA_PEAK_TFLOPS if args.net == "rescnn4x3" else FP32_MFMA_PEAK_TFLOPS
-            kname = {"mlp12x100": "co_k_mlp_forward", "rescnn4": "co_k_rescnn_forward",
+            peak = BF16_MFMA_PEAK_TFLOPS if args.net.endswith("x3") else FP32_MFMA_PEAK_TFLOPS
+            kname = {"mlp12x100": "co_k_mlp_forward", "mlp12x100x3": "co_k_mlp_forward_x3", "rescnn4": "co_k_rescnn_forward",
                      "rescnn4x3": "co_k_rescnn_forward_x3"}[args.net]
             roofline = {"kernel": kname,
                         "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                         "frac": achieved / peak, "traffic": measured_traffic(kname, args, npools),
-                        "issued_frac": (3.0 if args.net == "rescnn4x3" else 1.0) * achieved / peak,
+                        "issued_frac": (3.0 if args.net.endswith("x3") else 1.0) * achieved / peak,
                         "algorithmic": "%.1f KFLOP/row x %d rows" % (flop_per_row / 1e3, totals["nn_rows"]),
                         "avg_launch_ms": totals["nn_ms"] / max(totals["nn_launches"], 1)}
         else:
@@ -312,7 +312,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "bf16x3" if args.net == "rescnn4x3" else "f32",
+            "dtype": "bf16x3" if args.net.endswith("x3") else "f32",
             "data": "synthetic",
             "config": {
                 "workload": "%d parallel self-play games per GPU, %d sims/move, %d searches/eval, %s (random init, seed 0), "
@@ -344,6 +344,8 @@ def main():
                 ("rescnn4_bf16x3", NET_RESCNN4_X3, None, nets.rescnn4_flop_per_row(), BF16_MFMA_PEAK_TFLOPS),
                 ("mlp12x100_fp32", NET_MLP12X100, "mlp", 2.0 * (70 * 100 + 11 * 100 * 100 + 100 + 100 * 96),
                  FP32_MFMA_PEAK_TFLOPS),
+                ("mlp12x100_bf16x3", NET_MLP12X100_X3, "mlp", 2.0 * (70 * 100 + 11 * 100 * 100 + 100 + 100 * 96),
+                 BF16_MFMA_PEAK_TFLOPS),
             ):
                 if vkind == kind:
                     continue
@@ -361,7 +363,7 @@ def main():
                                   "device_ms": {"mcts": st["mcts_ms"], "network": st["nn_ms"], "pack": st["pack_ms"]}}
             out["detail"]["variants"] = variants
         if world == 1 and args.cpu_games > 0:
-            out["cpu_baseline"] = cpu_baseline(args, weights, "mlp12x100" if args.net == "mlp12x100" else "rescnn4")
+            out["cpu_baseline"] = cpu_baseline(args, weights, "mlp12x100" if args.net.startswith("mlp12x100") else "rescnn4")
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()

@@ -17,6 +17,7 @@
 #define CO_NET_MLP12X100 1
 #define CO_NET_RESCNN4 2
 #define CO_NET_RESCNN4_X3 3 /* same network and weights, convolutions at bf16x3 split precision */
+#define CO_NET_MLP12X100_X3 4 /* mlp12x100, same weights, dense layers at bf16x3 split precision */
 
 /* mlp12x100 flat weight layout (float32), matching Keras get_weights() order of
  * wrapper.py:256-271:

@@ -26,6 +26,7 @@ NUM_SYMMETRIES = 8
 NET_MLP12X100 = 1
 NET_RESCNN4 = 2
 NET_RESCNN4_X3 = 3
+NET_MLP12X100_X3 = 4
 
 
 def _f32(a, what):

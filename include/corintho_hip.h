@@ -105,6 +105,7 @@ int ca_trainer_do_iteration(ca_trainer *t, const float *evaluations, const float
 #define CA_NET_RESCNN4 2   /* the north-star 4-block residual CNN, fp32 MFMA */
 #define CA_NET_RESCNN4_X3 3 /* the same network and weights; 3x3 convolutions at bf16x3 split precision
                               (bf16 MFMA, fp32 accumulate; within 2e-5 of the fp32 result) */
+#define CA_NET_MLP12X100_X3 4 /* the reference architecture and weights; dense layers at bf16x3 split precision */
 /* slot 0 = best model (training, and arena `to_play == 1`), slot 1 = new model (arena
  * `to_play == 0`), as get_predictions chooses them (main.pyx:70-83) */
 int ca_trainer_set_net(ca_trainer *t, int slot, int kind, const float *weights, size_t n_floats);

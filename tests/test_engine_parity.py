@@ -356,6 +356,40 @@ def test_mlp_matches_float32_restatement(engine):
 
 
 @pytest.mark.gpu
+def test_mlp_bf16x3_within_tolerance_of_float32():
+    """the reference network with its dense layers at bf16x3 split precision (and BatchNorm folded
+    into the next layer): within the 1e-4 contract of the numpy restatement, batch independent,
+    and a fused generation replays on the oracle"""
+    from corintho_ai_amd import NET_MLP12X100_X3
+
+    t = make_trainer("hip", 64, "", 1, 50, 16, 1.0, 0.25, 0, 1, False)
+    rng = np.random.default_rng(21)
+    n = 1000
+    states = np.zeros((n, 70), np.float32)
+    states[:, :64] = rng.integers(0, 2, (n, 64))
+    states[:, 64:] = rng.integers(0, 5, (n, 6)) * 0.25
+    for seed, noise in ((0, False), (1, True), (7, True)):
+        w = nets.init_mlp12x100(seed=seed, bn_noise=noise)
+        t.set_net(NET_MLP12X100_X3, w)
+        ev, pr = t.net_forward(states)
+        ev0, pr0 = nets.mlp12x100_forward_np(w, states)
+        assert np.max(np.abs(ev - ev0)) < 1e-4, np.max(np.abs(ev - ev0))
+        assert np.max(np.abs(pr - pr0)) < 1e-4, np.max(np.abs(pr - pr0))
+        assert np.all(np.abs(pr.sum(axis=1) - 1) < 1e-5)
+        ev1, pr1 = t.net_forward(states[130:131])
+        assert ev1[0] == ev[130] and np.array_equal(pr1[0], pr[130])
+    G, S_, spe = 24, 40, 8
+    f = make_trainer("hip", G, "", 77, S_, spe, 1.0, 0.25, 0, 1, False, stagger=False)
+    f.set_net(NET_MLP12X100_X3, nets.init_mlp12x100(seed=2, bn_noise=True))
+    assert f.run()
+    o = O.Trainer(G, seed=77, max_searches=S_, searches_per_eval=spe)
+    o.set_stagger(False)
+    H.play_generation(o, G, spe, lambda s: f.net_forward(s))
+    for x, y in zip(H.get_samples(f), H.get_samples(o)):
+        assert x.tobytes() == y.tobytes()
+
+
+@pytest.mark.gpu
 def test_rescnn4_matches_float32_restatement():
     """north-star network: policy/value within 1e-4 (fp32) of the torch-CPU restatement
     of the specification in corintho_ai_amd/nets.py; rows independent of their batch"""

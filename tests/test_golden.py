@@ -87,13 +87,14 @@ def test_selfplay_golden(engine, case):
 def _net_cases():
     """(engine, vector name, network kind): the MLP on every engine, the residual CNN kernels
     (which have no emulation build) on the GPU"""
-    from corintho_ai_amd import NET_MLP12X100, NET_RESCNN4, NET_RESCNN4_X3
+    from corintho_ai_amd import NET_MLP12X100, NET_MLP12X100_X3, NET_RESCNN4, NET_RESCNN4_X3
 
     gpu = pytest.mark.gpu
     out = []
     for name in ("mlp_seed0", "mlp_seed1_noise"):
         out.append(pytest.param("emu", name, NET_MLP12X100, id="emu-" + name))
         out.append(pytest.param("hip", name, NET_MLP12X100, id="hip-" + name, marks=gpu))
+        out.append(pytest.param("hip", name, NET_MLP12X100_X3, id="hip-bf16x3-" + name, marks=gpu))
     for name in ("rescnn4_seed0", "rescnn4_seed3_noise"):
         out.append(pytest.param("hip", name, NET_RESCNN4, id="hip-fp32-" + name, marks=gpu))
         out.append(pytest.param("hip", name, NET_RESCNN4_X3, id="hip-bf16x3-" + name, marks=gpu))
