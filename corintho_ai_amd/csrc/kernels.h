@@ -209,8 +209,16 @@ CO_KERNEL co_k_fp_probe(const float *in, int n, float *out) {
       float v_sqrt = (float)((double)c_puct * co_sqrt_f64((double)visits));
       float prob = p9 * denom;
       float pv = prob * v_sqrt;
-      double a = -1.0 * (double)eval / (double)cv;
-      double b = (double)pv / ((double)cv + 1.0);
+      /* the search's own quotient routine where it applies (integer counts up to 2^15) */
+      int icv = (int)cv;
+      double a, b;
+      if ((float)icv == cv && icv >= 1 && icv < 32768) {
+        a = co_div_small(-(double)eval, cv);
+        b = co_div_small((double)pv, cv + 1.0f);
+      } else {
+        a = -1.0 * (double)eval / (double)cv;
+        b = (double)pv / ((double)cv + 1.0);
+      }
       float one_minus = (float)1 - eps;
       float *o = out + (size_t)i * 8;
       o[0] = v_sqrt;

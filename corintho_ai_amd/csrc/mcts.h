@@ -587,6 +587,33 @@ CO_DEV void co_propagate_terminal(CoTree &t, const uint32_t *path_block, const u
   }
 }
 
+/* x / d for a float x and an integer d in [1, 2^15] as the correctly rounded double quotient --
+ * what the reference's double division gives (trainmc.cpp:565-568) -- without the full IEEE
+ * division sequence (two v_div_scale, v_rcp_f64, seven fma, v_div_fmas, v_div_fixup; the two
+ * quotients and the square root of a PUCT scan were ~45 double-rate instructions per level and
+ * the largest single cost of a simulation).  r = 1/d to double precision from the float
+ * reciprocal and two Newton steps; q0 = RN(x r); e = x - d q0 is exact (d has 16 bits and x is
+ * a multiple of ulp(q0)); q = RN(q0 + e r) = RN(x/d (1 + 2^-51 ulp)).  x/d is either a double
+ * itself or at least ulp/(2 d) >= 2^-17 ulp away from every rounding boundary, so q = RN(x/d).
+ * (A zero quotient may differ in sign; pv >= +0 makes the PUCT sum the same.)  The seed only has
+ * to be good to ~20 bits, so the emulation build's 1.0f / d and v_rcp_f32 give the same q. */
+CO_DEV double co_div_small(double x, float df) {
+#ifdef CO_EMU
+  float rf = 1.0f / df;
+#else
+  float rf = __builtin_amdgcn_rcpf(df);
+#endif
+  double d = (double)df;
+  double r = (double)rf;
+  double e = __builtin_fma(-d, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-d, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  double q0 = x * r;
+  double rem = __builtin_fma(-d, q0, x);
+  return __builtin_fma(rem, r, q0);
+}
+
 /* Register copy of the root's header and stat slot, kept across the simulations
  * of one step so that a simulation starts without any dependent load. */
 struct CoRoot {
@@ -651,9 +678,9 @@ CO_DEV void co_search(CoWave &w, CoTree &t, CoRoot &rc) {
           int drawn = (r == CO_RESULT_DRAW) | (r == CO_DEDUCED_DRAW);
           int searchable = ((r == CO_RESULT_NONE) | drawn) & !((s.w >> 8) & 1u);
           int vis = co_slot_visits(s);
-          float cv = (float)(vis > 0 ? vis : 1);
-          double a = -1.0 * (double)co_u2f(s.y) / (double)cv;
-          double b = (double)pv / ((double)cv + 1.0);
+          float cv = (float)(vis > 0 ? vis : 1); /* 1 .. 32767 */
+          double a = co_div_small(-(double)co_u2f(s.y), cv);
+          double b = co_div_small((double)pv, cv + 1.0f);
           float uv = (float)(a + b);
           float uc = drawn ? pv : uv;           /* visited child (trainmc.cpp:561-569) */
           uc = searchable ? uc : CO_NEG_INF;
