@@ -22,7 +22,7 @@
 // epilogue is ReLU + the hi/lo split.  tanh and the 96-way softmax are fused into the last
 // layer.  Fixed k order, no batch-dependent tiling: a row's result does not depend on its batch.
 //
-// Geometry: 128 threads... no: 256 threads = 4 waves x 32 rows = 128 rows per workgroup, one
+// Geometry: 256 threads = 4 waves x 32 rows = 128 rows per workgroup, one
 // workgroup per CU (2 x 58 KB of LDS); K = 112 (7 steps) for the hidden layers, 80 (5 steps) for
 // the input layer, whose operands are exact in bf16 (0/1 and k/4) and need no lo product.
 #include <hip/hip_runtime.h>
