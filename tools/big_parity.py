@@ -2,7 +2,7 @@
 """One-off parity run at the bench's full size: a fused generation on the GPU, then EVERY game
 replayed on the CPU oracle (fed by the same device network through ca_trainer_net_forward) and
 compared bit for bit: sample tensors (state, policy, outcome), score, mate length.
-usage: big_parity.py [games] [sims] [net: mlp12x100|rescnn4x3]"""
+usage: big_parity.py [games] [sims] [net: mlp12x100|mlp12x100x3|rescnn4x3] [seed]"""
 import os
 import sys
 import time
@@ -18,15 +18,16 @@ from tests import harness as H  # noqa: E402
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 net = sys.argv[3] if len(sys.argv) > 3 else "rescnn4x3"
-kind, w = (NET_MLP12X100, nets.init_mlp12x100(0)) if net == "mlp12x100" else (NET_RESCNN4_X3, nets.init_rescnn4(0))
+seed = int(sys.argv[4]) if len(sys.argv) > 4 else 12345
+kind, w = ((4 if net.endswith("x3") else NET_MLP12X100), nets.init_mlp12x100(0)) if net.startswith("mlp12x100") else (NET_RESCNN4_X3, nets.init_rescnn4(0))
 spe = 16
-t = Trainer(G, "", 12345, S, spe, 1.0, 0.25, 0, 1, False, stagger=False)
+t = Trainer(G, "", seed, S, spe, 1.0, 0.25, 0, 1, False, stagger=False)
 t.set_net(kind, w)
 t0 = time.perf_counter()
 assert t.run()
 t_gpu = time.perf_counter() - t0
 sp, oc = t.export_samples()
-o = O.Trainer(G, seed=12345, max_searches=S, searches_per_eval=spe, num_threads=int(os.environ.get("CORINTHO_CPU_THREADS", "16")))
+o = O.Trainer(G, seed=seed, max_searches=S, searches_per_eval=spe, num_threads=int(os.environ.get("CORINTHO_CPU_THREADS", "16")))
 o.set_stagger(False)
 t0 = time.perf_counter()
 r = H.play_generation(o, G, spe, lambda st: t.net_forward(st))
@@ -36,8 +37,8 @@ n = t.num_samples()
 ok = (ogs.shape[0] == n * 8 and ogs[0::8].tobytes() == sp[:, :70].tobytes() and opr[0::8].tobytes() == sp[:, 70:].tobytes()
       and oev[0::8].tobytes() == oc.tobytes() and o.score() == t.score() and o.avg_mate_length() == t.avg_mate_length())
 st = t.stats()
-print("%d games x %d sims/move, %s, seed 12345: GPU generation %.2f s; oracle replay of all games %.1f s (%d host iterations)"
-      % (G, S, net, t_gpu, t_cpu, r["iterations"]))
+print("%d games x %d sims/move, %s, seed %d: GPU generation %.2f s; oracle replay of all games %.1f s (%d host iterations)"
+      % (G, S, net, seed, t_gpu, t_cpu, r["iterations"]))
 print("plies %d, simulations %d, leaf evaluations %d, samples %d, score %.6f" % (st["plies"], st["searches"], st["evals"], n, t.score()))
 print("BIT-EXACT: every (state[70], policy[96], outcome) row, score and mate length agree" if ok else "MISMATCH")
 sys.exit(0 if ok else 1)
