@@ -330,6 +330,7 @@ CO_DEV void co_receive_batch(CoWave &w, CoTree &t, int k0, int nb, const float *
   WAVE_SHARED(float, tn, CO_RB * CO_RS + 4);  /* noise */
   WAVE_SHARED(uint8_t, tm, CO_RB * CO_RS + 3); /* move ids */
   unsigned long long tA = CO_CLK();
+  (void)tA; /* only read by profiling builds */
   /* ---- A */
   LV(uint32_t, leafv);
   LV(int, nv);
