@@ -537,3 +537,15 @@ def test_full_size_generation_properties():
     assert ogs[0::8].tobytes() == sp_all[:m, :70].tobytes()
     assert opr[0::8].tobytes() == sp_all[:m, 70:].tobytes()
     assert oev[0::8].tobytes() == oc_all[:m].tobytes()
+
+
+@pytest.mark.parametrize("engine", ENGINES)
+def test_arena_overflow_is_reported_by_the_fused_loop(engine):
+    """a tree that outgrows its arena stops that game with an error; the device loop must end
+    and raise (not spin, not drop the error) -- for one pool and for several"""
+    w = nets.init_mlp12x100(seed=0)
+    for pools in (1, 2):
+        t = make_trainer(engine, 6, "", 1, 64, 8, 1.0, 0.25, 0, 1, False, arena_units=300, stagger=False, pools=pools)
+        t.set_net(1, w)
+        with pytest.raises(_lib.EngineError, match="arena"):
+            t.run()
