@@ -161,3 +161,76 @@ def test_pairing_files_are_read_like_the_reference_driver(tmp_path):
     players, matches = read_pairings(tmp_path / "players.txt", tmp_path / "matches.txt")
     assert players == [(0, 0, 1600, 16, 1.0, 0.25, False), (1, 4, 800, 8, 1.5, 0.1, False), (2, -1, 0, 0, 1.0, 0.25, True)]
     assert matches == [(0, 1, False), (2, 0, True)]
+
+
+def _few_searches_tourney(factory):
+    """tests/cpp/tourney_test.cpp:30-69 (TourneyTest.FewSearches): six searching players with their
+    own model ids (2, 3, 4 simulations per move; 1 or all of them per evaluation), a random player
+    with id 0, every ordered pairing"""
+    t = factory()
+    counter = 1
+    for max_searches in (2, 3, 4):
+        for spe in (1, max_searches):
+            t.addPlayer(counter, counter, max_searches, spe, 1.0, 0.25, False)
+            counter += 1
+    t.addPlayer(0, 0, 1, 1, 0.0, 0.0, True)
+    n = 0
+    for i in range(counter):
+        for j in range(counter):
+            if i != j:
+                t.addMatch(i, j, False)
+                n += 1
+    return t, counter, n
+
+
+@pytest.mark.parametrize("engine", ENGINES)
+def test_reference_tourney_few_searches(engine):
+    nets_by_model = {m: (lambda s, m=m: H.hash_net(s, 100 + m)) for m in range(1, 7)}
+    e, counter, n = _few_searches_tourney(lambda: Tourney(1, "", trace=True, _cdll=cdll(engine)))
+    o, _, _ = _few_searches_tourney(lambda: O.Tourney(1, "", trace=True))
+    assert n == 42 and e.num_matches() == 42
+    # model id 0 belongs to the random player: no requests, but its matches move (tourney_test.cpp:52-66)
+    ra = H.play_tourney(e, list(range(counter)), nets_by_model, 4 * 12, record=True)
+    rb = H.play_tourney(o, list(range(counter)), nets_by_model, 4 * 12, record=True)
+    assert e.all_done() and o.all_done()
+    assert [(a[0], a[1].tobytes()) for a in ra["log"]] == [(b[0], b[1].tobytes()) for b in rb["log"]]
+    for m, rows in ra["log"]:
+        assert np.all((rows >= 0.0) & (rows <= 1.0))
+    for i in range(n):
+        assert np.array_equal(e.trace(i), o.trace(i)), "match %d" % i
+        assert e.match_score(i) == o.match_score(i)
+
+
+@pytest.mark.parametrize("engine", ENGINES)
+@pytest.mark.parametrize("max_searches,spe", [(2, 1), (2, 2), (5, 3), (9, 9), (16, 1), (16, 16)])
+@pytest.mark.parametrize("random_id", [0, 1, 2])
+def test_reference_match_few_searches(engine, max_searches, spe, random_id):
+    """tests/cpp/match_test.cpp:28-76 (MatchTest.FewSearches): one match, either side (or neither)
+    random; between iterations the side to move has 1..searches_per_eval requests with rows in [0, 1]"""
+    def build(factory):
+        t = factory()
+        t.addPlayer(0, 0, max_searches, spe, 1.0, 0.25, random_id == 0)
+        t.addPlayer(1, 1, max_searches, spe, 1.0, 0.25, random_id == 1)
+        t.addMatch(0, 1, False)
+        return t
+
+    e = build(lambda: Tourney(1, "", trace=True, _cdll=cdll(engine)))
+    o = build(lambda: O.Tourney(1, "", trace=True))
+    evals = np.zeros(spe, np.float32)
+    probs = np.zeros((spe, 96), np.float32)
+    gs = np.zeros((spe, 70), np.float32)
+    for t in (e, o):
+        guard = 0
+        while not t.all_done():
+            for mid in (0, 1):
+                n = t.num_requests(mid)
+                assert 0 <= n <= spe
+                if n:
+                    t.writeRequests(gs, mid)
+                    assert np.all((gs[:n] >= 0.0) & (gs[:n] <= 1.0))
+                    evals[:n], probs[:n] = H.hash_net(gs[:n], 5 + mid)
+                t.doIteration(evals, probs, mid)
+            guard += 1
+            assert guard < 100000
+    assert np.array_equal(e.trace(0), o.trace(0))
+    assert e.match_score(0) == o.match_score(0)
