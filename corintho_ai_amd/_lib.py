@@ -53,6 +53,10 @@ class CaStats(C.Structure):
         ("nn_launches", C.c_int64),
         ("nn_rows", C.c_int64),
         ("pools", C.c_int64),
+        ("timed_launches", C.c_int64),
+        ("nn_timed_rows", C.c_int64),
+        ("mcts_timed_ms", C.c_double),
+        ("nn_timed_ms", C.c_double),
     ]
 
 

@@ -91,9 +91,10 @@ struct Pool {
   int lo, n, row_base;
   bool finished;
   int idle;
-  rt_event_t ev[2][CO_POOL_POLL * 3]; /* per window parity: start / after search / after network */
+  rt_event_t ev[2][3];      /* per window parity: start / after search / after network of the TIMED iteration */
   rt_event_t polled[2];
-  int launched[2];          /* iterations recorded in ev[parity] */
+  int launched[2];          /* iterations queued in the window of that parity */
+  int timed[2];             /* the window's last iteration carries the events */
   unsigned long long *word; /* pinned: counter word copied at the end of window parity 0 / 1 */
 };
 
@@ -121,6 +122,9 @@ struct ca_trainer {
   std::unique_ptr<CoNet> nets[2];
   double mcts_ms = 0, nn_ms = 0, pack_ms = 0;
   int64_t mcts_launches = 0, nn_launches = 0, nn_rows = 0;
+  /* fused training: the launches that carried timing events (one per pool and window) */
+  double mcts_timed_ms = 0, nn_timed_ms = 0;
+  int64_t timed_launches = 0, nn_timed_rows = 0;
 
   /* tournament mode (ca_tourney): per-match players, per-match seeds, the reference's read offsets */
   bool tourney = false;
@@ -235,6 +239,8 @@ struct ca_trainer {
     host_games_valid = false;
     mcts_ms = nn_ms = pack_ms = 0;
     mcts_launches = nn_launches = nn_rows = 0;
+    mcts_timed_ms = nn_timed_ms = 0;
+    timed_launches = nn_timed_rows = 0;
   }
 
   void fill_params(uint32_t cap, int total) {
@@ -561,6 +567,7 @@ struct ca_trainer {
       q.finished = false;
       q.idle = 0;
       q.launched[0] = q.launched[1] = 0;
+      q.timed[0] = q.timed[1] = 0;
     }
     rt_sync(stream);
     P.to_play = -1;
@@ -579,12 +586,17 @@ struct ca_trainer {
     auto collect = [&](Pool &q, int parity) {
       if (!q.launched[parity]) return;
       rt_event_sync(q.polled[parity]);
-      for (int k = 0; k < q.launched[parity]; ++k) {
-        mcts_ms += rt_event_elapsed_ms(q.ev[parity][k * 3], q.ev[parity][k * 3 + 1]);
-        nn_ms += rt_event_elapsed_ms(q.ev[parity][k * 3 + 1], q.ev[parity][k * 3 + 2]);
+      unsigned long long c = q.word[parity];
+      if (q.timed[parity]) {
+        /* one iteration per window is timed (three event records per launch pair cost 1-4 % of
+         * the wall time); its batch size is the counter word just read */
+        mcts_timed_ms += rt_event_elapsed_ms(q.ev[parity][0], q.ev[parity][1]);
+        nn_timed_ms += rt_event_elapsed_ms(q.ev[parity][1], q.ev[parity][2]);
+        nn_timed_rows += (int64_t)(c & 0xFFFFFFFFull);
+        ++timed_launches;
+        q.timed[parity] = 0;
       }
       q.launched[parity] = 0;
-      unsigned long long c = q.word[parity];
       q.finished = (c >> 32) == 0;
       if (!q.finished && (c & 0xFFFFFFFFull) == 0) {
         if (++q.idle > 16) failure = "No requests during training"; /* main.pyx:161-163 */
@@ -603,14 +615,18 @@ struct ca_trainer {
         pp.pool_n = q.n;
         pp.pool_row_base = q.row_base;
         pp.pack_counter = pack_counter.p + 2 * p;
-        rt_event_t *e = &q.ev[parity][in_window * 3];
-        rt_event_record(e[0], q.st);
+        const bool timed = in_window == poll - 1 || (max_iterations > 0 && it + 1 == max_iterations);
+        rt_event_t *e = q.ev[parity];
+        if (timed) rt_event_record(e[0], q.st);
         RT_LAUNCH(co_k_mcts_step, q.n, CO_WAVE, q.st, pp);
-        rt_event_record(e[1], q.st);
+        if (timed) rt_event_record(e[1], q.st);
         const int32_t *d_rows = (const int32_t *)(pack_counter.p + 2 * p + (trainer_iteration & 1));
         nets[0]->forward(nn_in.p + (size_t)q.row_base * CO_STATE_STRIDE, q.n * spe, d_rows, nn_eval.p + q.row_base,
                          nn_probs.p + (size_t)q.row_base * CO_NUM_MOVES, q.st);
-        rt_event_record(e[2], q.st);
+        if (timed) {
+          rt_event_record(e[2], q.st);
+          q.timed[parity] = 1;
+        }
         q.launched[parity] = in_window + 1;
         ++mcts_launches;
         ++nn_launches;
@@ -649,6 +665,11 @@ struct ca_trainer {
     P.pack_counter = pack_counter.p;
     host_games_valid = false;
     scan_valid = false;
+    if (timed_launches > 0) {
+      /* device time by kernel family, estimated from the timed launches */
+      mcts_ms = mcts_timed_ms * (double)mcts_launches / (double)timed_launches;
+      nn_ms = nn_timed_ms * (double)nn_launches / (double)timed_launches;
+    }
     if (!failure.empty()) throw EngineError(CA_ERR_ENGINE, failure);
     pack(-1); /* refresh the done flag and the batch description */
     check_errors();
@@ -1138,6 +1159,10 @@ extern "C" int ca_trainer_stats(ca_trainer *t, ca_stats *out) {
     out->nn_launches = t->nn_launches;
     out->nn_rows = t->nn_rows;
     out->pools = t->pools.empty() ? 1 : (int64_t)t->pools.size();
+    out->timed_launches = t->timed_launches;
+    out->nn_timed_rows = t->nn_timed_rows;
+    out->mcts_timed_ms = t->mcts_timed_ms;
+    out->nn_timed_ms = t->nn_timed_ms;
   })
 }
 

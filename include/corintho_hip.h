@@ -145,6 +145,12 @@ typedef struct ca_stats {
   int64_t mcts_launches, nn_launches;
   int64_t nn_rows;       /* rows evaluated by the network kernels */
   int64_t pools;         /* pools the last ca_trainer_run used (1 in arena mode) */
+  /* fused training times one iteration per pool and window of 8 with HIP events (mcts_ms / nn_ms
+   * above are then estimates: timed sums scaled by launches / timed launches); exact figures of
+   * the timed launches: */
+  int64_t timed_launches; /* search + network launch pairs that carried events */
+  int64_t nn_timed_rows;  /* batch rows of those network launches */
+  double mcts_timed_ms, nn_timed_ms;
 } ca_stats;
 int ca_trainer_stats(ca_trainer *t, ca_stats *out);
 /* per-game: {to_play, done, result, n_samples, n_pending, error, mate_turn, plies} */
