@@ -362,8 +362,11 @@ __global__ __launch_bounds__(256, 2) void co_k_rescnn_forward(RcParams P) {
  * Bias, BatchNorm, residual adds and the heads stay in fp32.
  * Geometry: 512 threads = 8 waves (two per SIMD), 2 position pairs per wave, 32 positions
  * per workgroup. */
-#define RC3_NP 2 /* position pairs per wave */
-#define RC3_POS_PER_WG 32
+/* NP = position pairs per wave: 2 in the throughput kernel (32 positions per workgroup), 1 in the
+ * small-batch kernel (16 per workgroup: half the MFMA work behind the same weight stream, so a
+ * batch that fits one round of workgroups comes back sooner -- the thinning tail of a generation
+ * runs hundreds of such iterations, each as long as its slowest kernel) */
+#define RC3_SMALL_ROWS 4096 /* batches up to this size take the small-batch kernel: <= 256 workgroups */
 #define RC3_STEM_CHUNK 1024 /* u32: 1 k-step x 2 out tiles x {hi,lo} x 64 lanes x 4 */
 #define RC3_CONV_CHUNK 4096 /* u32: 4 k-steps ... = 16 KB */
 #define RC3_TRUNK_WORDS (9 * RC3_STEM_CHUNK + 72 * RC3_CONV_CHUNK)
@@ -492,9 +495,9 @@ __device__ __forceinline__ u32x4 rc3_tap4_sel(const uint32_t (&in)[4], int tap, 
  * word m = channels (reg 8a + 2m, 8a + 2m + 1) of tile T.  The weight fragments of step i + 1
  * (also across the tap boundary) are requested from LDS before the MFMAs of step i issue (two
  * register sets), so the LDS latency is paid once per group. */
-template <int CS, int G>
-__device__ __forceinline__ void rc3_conv_group(f32x16 (&acc)[RC3_NP][2], const uint32_t (&ph)[RC3_NP][4][4],
-                                               const uint32_t (&pl)[RC3_NP][4][4], const uint32_t *wg, int lane,
+template <int CS, int G, int NP>
+__device__ __forceinline__ void rc3_conv_group(f32x16 (&acc)[NP][2], const uint32_t (&ph)[NP][4][4],
+                                               const uint32_t (&pl)[NP][4][4], const uint32_t *wg, int lane,
                                                bool okL, bool okR) {
   constexpr int tw = CS == 1 ? RC3_STEM_CHUNK : RC3_CONV_CHUNK;
   constexpr int N = 3 * CS;
@@ -520,7 +523,7 @@ __device__ __forceinline__ void rc3_conv_group(f32x16 (&acc)[RC3_NP][2], const u
       }
     }
 #pragma unroll
-    for (int np = 0; np < RC3_NP; ++np) {
+    for (int np = 0; np < NP; ++np) {
       const u32x4 bh = rc3_tap4_sel(ph[np][s], 3 * G + tg, zero);
       const u32x4 bl = rc3_tap4_sel(pl[np][s], 3 * G + tg, zero);
       const bf16x8 Bh = __builtin_bit_cast(bf16x8, bh), Bl = __builtin_bit_cast(bf16x8, bl);
@@ -537,12 +540,12 @@ __device__ __forceinline__ void rc3_conv_group(f32x16 (&acc)[RC3_NP][2], const u
   }
 }
 
-template <int CS>
-__device__ __forceinline__ void rc3_conv3x3(f32x16 (&acc)[RC3_NP][2], const uint32_t (&ph)[RC3_NP][4][4],
-                                            const uint32_t (&pl)[RC3_NP][4][4], int &ch, const uint32_t *wtrunk,
+template <int CS, int NP>
+__device__ __forceinline__ void rc3_conv3x3(f32x16 (&acc)[NP][2], const uint32_t (&ph)[NP][4][4],
+                                            const uint32_t (&pl)[NP][4][4], int &ch, const uint32_t *wtrunk,
                                             uint32_t *lds_w, int wave, int lane, bool okL, bool okR) {
 #pragma unroll
-  for (int np = 0; np < RC3_NP; ++np)
+  for (int np = 0; np < NP; ++np)
 #pragma unroll
     for (int to = 0; to < 2; ++to)
 #pragma unroll
@@ -552,7 +555,7 @@ __device__ __forceinline__ void rc3_conv3x3(f32x16 (&acc)[RC3_NP][2], const uint
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                         \
     __syncthreads();                                                                         \
     if (ch + 1 < RC3_NUM_GROUPS) rc3_stage(wtrunk, lds_w + ((ch + 1) & 1) * RC3_GROUP_WORDS, ch + 1, wave, lane); \
-    rc3_conv_group<CS, G>(acc, ph, pl, lds_w + (ch & 1) * RC3_GROUP_WORDS, lane, okL, okR);  \
+    rc3_conv_group<CS, G, NP>(acc, ph, pl, lds_w + (ch & 1) * RC3_GROUP_WORDS, lane, okL, okR);  \
     ++ch;                                                                                    \
   }
   RC3_GROUP(0) RC3_GROUP(1) RC3_GROUP(2)
@@ -560,10 +563,11 @@ __device__ __forceinline__ void rc3_conv3x3(f32x16 (&acc)[RC3_NP][2], const uint
 }
 
 /* fp32 tile values -> the packed hi/lo operands of the next convolution */
-__device__ __forceinline__ void rc3_pack(uint32_t (&ph)[RC3_NP][4][4], uint32_t (&pl)[RC3_NP][4][4],
-                                         const float (&v)[RC3_NP][2][16]) {
+template <int NP>
+__device__ __forceinline__ void rc3_pack(uint32_t (&ph)[NP][4][4], uint32_t (&pl)[NP][4][4],
+                                         const float (&v)[NP][2][16]) {
 #pragma unroll
-  for (int np = 0; np < RC3_NP; ++np)
+  for (int np = 0; np < NP; ++np)
 #pragma unroll
     for (int T = 0; T < 2; ++T)
 #pragma unroll
@@ -575,9 +579,9 @@ __device__ __forceinline__ void rc3_pack(uint32_t (&ph)[RC3_NP][4][4], uint32_t 
 
 /* conv bias -> BatchNorm affine (-> + skip) -> ReLU; register 4g + i of tile T is channel
  * 32T + 8g + 4h + i */
-template <bool ADD_SKIP>
-__device__ __forceinline__ void rc3_epilogue(float (&out)[RC3_NP][2][16], const f32x16 (&acc)[RC3_NP][2],
-                                             const float (&skip)[RC3_NP][2][16], const float *epi, int h) {
+template <bool ADD_SKIP, int NP>
+__device__ __forceinline__ void rc3_epilogue(float (&out)[NP][2][16], const f32x16 (&acc)[NP][2],
+                                             const float (&skip)[NP][2][16], const float *epi, int h) {
 #pragma unroll
   for (int T = 0; T < 2; ++T)
 #pragma unroll
@@ -593,7 +597,7 @@ __device__ __forceinline__ void rc3_epilogue(float (&out)[RC3_NP][2][16], const 
 #pragma unroll
       for (int i = 0; i < 4; ++i) cb[i] = __builtin_fmaf(aa[i], bb[i], cc[i]);
 #pragma unroll
-      for (int np = 0; np < RC3_NP; ++np)
+      for (int np = 0; np < NP; ++np)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           /* a (acc + bias) + c as one fma on the folded shift cb = a bias + c */
@@ -621,13 +625,15 @@ extern "C" int ca_net_prof(unsigned long long out[8]) {
 #define RC3_STAMP(slot)
 #endif
 
-__global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_x3(Rc3Params Q) {
+template <int NP>
+__global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_x3_t(Rc3Params Q) {
   const RcParams &P = Q.base;
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[]; /* 2 weight groups + head features */
   uint32_t *lds_w = lds_dyn;
   float(*lds_feat)[RC_NB][96] = reinterpret_cast<float(*)[RC_NB][96]>(lds_dyn + 2 * RC3_GROUP_WORDS);
   const int rows = *P.d_rows;
-  const int row0 = blockIdx.x * RC3_POS_PER_WG;
+  if ((rows <= RC3_SMALL_ROWS) != (NP == 1)) return; /* the other kernel takes this batch */
+  const int row0 = blockIdx.x * (16 * NP);
   if (row0 >= rows) return;
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, h = lane >> 5, p2 = (lane >> 4) & 1, c = lane & 15;
@@ -645,10 +651,10 @@ __global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_x3(Rc3Params Q) {
 
   /* input planes: register 4g + i of tile 0 = channel 8g + 4h + i:
    * g 0: h 0 the cell's board bits, h 1 reserves 0..3; g 1: h 0 reserves 4..5 (+ padding), h 1 zeros */
-  float x[RC3_NP][2][16];
+  float x[NP][2][16];
 #pragma unroll
-  for (int np = 0; np < RC3_NP; ++np) {
-    const int pos = row0 + wave * 4 + np * 2 + p2;
+  for (int np = 0; np < NP; ++np) {
+    const int pos = row0 + wave * (2 * NP) + np * 2 + p2;
 #pragma unroll
     for (int T = 0; T < 2; ++T)
 #pragma unroll
@@ -661,33 +667,33 @@ __global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_x3(Rc3Params Q) {
       x[np][0][4] = v1.x; x[np][0][5] = v1.y; x[np][0][6] = v1.z; x[np][0][7] = v1.w;
     }
   }
-  uint32_t ph[RC3_NP][4][4], pl[RC3_NP][4][4];
-  rc3_pack(ph, pl, x);
+  uint32_t ph[NP][4][4], pl[NP][4][4];
+  rc3_pack<NP>(ph, pl, x);
   RC3_STAMP(0)
-  f32x16 acc[RC3_NP][2];
-  float y[RC3_NP][2][16];
+  f32x16 acc[NP][2];
+  float y[NP][2][16];
   int ch = 0;
-  rc3_conv3x3<1>(acc, ph, pl, ch, Q.wtrunk, lds_w, wave, lane, okL, okR);
+  rc3_conv3x3<1, NP>(acc, ph, pl, ch, Q.wtrunk, lds_w, wave, lane, okL, okR);
   RC3_STAMP(1)
   const float *lds_epi = reinterpret_cast<const float *>(lds_head + 2048 + 6144 + 2048 + 1024);
-  rc3_epilogue<false>(x, acc, x, lds_epi, h);
-  rc3_pack(ph, pl, x);
+  rc3_epilogue<false, NP>(x, acc, x, lds_epi, h);
+  rc3_pack<NP>(ph, pl, x);
   RC3_STAMP(2)
   for (int b = 0; b < 4; ++b) {
-    rc3_conv3x3<4>(acc, ph, pl, ch, Q.wtrunk, lds_w, wave, lane, okL, okR);
+    rc3_conv3x3<4, NP>(acc, ph, pl, ch, Q.wtrunk, lds_w, wave, lane, okL, okR);
     RC3_STAMP(3)
-    rc3_epilogue<false>(y, acc, x, lds_epi + (1 + 2 * b) * 192, h);
-    rc3_pack(ph, pl, y);
+    rc3_epilogue<false, NP>(y, acc, x, lds_epi + (1 + 2 * b) * 192, h);
+    rc3_pack<NP>(ph, pl, y);
     RC3_STAMP(2)
-    rc3_conv3x3<4>(acc, ph, pl, ch, Q.wtrunk, lds_w, wave, lane, okL, okR);
+    rc3_conv3x3<4, NP>(acc, ph, pl, ch, Q.wtrunk, lds_w, wave, lane, okL, okR);
     RC3_STAMP(3)
-    rc3_epilogue<true>(x, acc, x, lds_epi + (2 + 2 * b) * 192, h);
-    rc3_pack(ph, pl, x);
+    rc3_epilogue<true, NP>(x, acc, x, lds_epi + (2 + 2 * b) * 192, h);
+    rc3_pack<NP>(ph, pl, x);
     RC3_STAMP(2)
   }
   /* heads: the two 1x1 convolutions as one more split-precision step on the operands packed
    * after the last block (no tap shift); output rows 0..3 policy planes (h 0), 4..5 value (h 1) */
-  float *feat_w = &lds_feat[wave][0][0];
+  float *feat_w = &lds_feat[0][0][0] + wave * (2 * NP) * 96; /* this wave's positions, workgroup order */
   u32x4 hh[4], hl[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
@@ -695,7 +701,7 @@ __global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_x3(Rc3Params Q) {
     hl[s] = *reinterpret_cast<const u32x4 *>(lds_head + ((s * 2 + 1) * 64 + lane) * 4);
   }
 #pragma unroll
-  for (int np = 0; np < RC3_NP; ++np) {
+  for (int np = 0; np < NP; ++np) {
     f32x16 h1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) h1[i] = 0.0f;
@@ -730,11 +736,12 @@ __global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_x3(Rc3Params Q) {
   }
   RC3_STAMP(4)
   __syncthreads();
-  /* 32 positions = two column tiles: waves 0, 1 run their policy heads, waves 2, 3 their value heads */
+  /* 16 NP positions = NP column tiles: waves 0 (, 1) run their policy heads, waves 2 (, 3) their
+   * value heads */
   const float *lds_dense = reinterpret_cast<const float *>(lds_head + 2048);
-  if (wave < 2)
+  if (wave < NP)
     rc_dense_policy(P, lds_dense, &lds_feat[0][0][0] + wave * 16 * 96, rows, row0 + wave * 16, lane);
-  else if (wave < 4)
+  else if (wave >= 2 && wave < 2 + NP)
     rc_dense_value(P, lds_dense + 6144, lds_dense + 6144 + 2048, &lds_feat[0][0][0] + (wave - 2) * 16 * 96, rows,
                    row0 + (wave - 2) * 16, lane);
   RC3_STAMP(5)
@@ -745,6 +752,11 @@ __global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_x3(Rc3Params Q) {
   }
 #endif
 }
+
+/* <2>: throughput kernel, batches of more than RC3_SMALL_ROWS rows, 32 positions per workgroup;
+ * <1>: small-batch kernel, up to RC3_SMALL_ROWS rows, 16 positions per workgroup, one round */
+#define co_k_rescnn_forward_x3 co_k_rescnn_forward_x3_t<2>
+#define co_k_rescnn_forward_x3_small co_k_rescnn_forward_x3_t<1>
 
 /* ------------------------------------------------------------------ host */
 struct ResCnnNet : CoNet {
@@ -924,6 +936,8 @@ struct ResCnnX3Net : ResCnnNet {
     rt_h2d(d_trunk3, tr.data(), tr.size() * 4, s);
     RT_CHECK(hipFuncSetAttribute((const void *)co_k_rescnn_forward_x3, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  RC3_LDS_BYTES));
+    RT_CHECK(hipFuncSetAttribute((const void *)co_k_rescnn_forward_x3_small, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 RC3_LDS_BYTES));
     rt_malloc((void **)&d_whead3, (size_t)RC3_HEAD_WORDS * 4);
     rt_h2d(d_whead3, wh3.data(), wh3.size() * 4, s);
     rt_d2d(d_whead3 + 2048, P.wpol, 6144 * 4, s); /* the dense weights in the base class's MFMA order */
@@ -939,7 +953,7 @@ struct ResCnnX3Net : ResCnnNet {
   int kind() const override { return CO_NET_RESCNN4_X3; }
   void forward(const float *d_in, int32_t rows_cap, const int32_t *d_rows, float *d_eval, float *d_probs,
                rt_stream_t s) override {
-    int grid = (rows_cap + RC3_POS_PER_WG - 1) / RC3_POS_PER_WG;
+    int grid = (rows_cap + 31) / 32;
     if (grid < 1) return;
     Rc3Params q;
     q.base = P;
@@ -949,7 +963,11 @@ struct ResCnnX3Net : ResCnnNet {
     q.base.probs = d_probs;
     q.wtrunk = d_trunk3;
     q.whead3 = d_whead3;
-    hipLaunchKernelGGL(co_k_rescnn_forward_x3, dim3(grid), dim3(512), RC3_LDS_BYTES, s, q);
+    /* both kernels are queued; the row count on the device decides which one works (the other's
+     * workgroups return at once).  Batches that can exceed RC3_SMALL_ROWS need the throughput kernel. */
+    const int small_rows = rows_cap < RC3_SMALL_ROWS ? rows_cap : RC3_SMALL_ROWS;
+    hipLaunchKernelGGL(co_k_rescnn_forward_x3_small, dim3((small_rows + 15) / 16), dim3(512), RC3_LDS_BYTES, s, q);
+    if (rows_cap > RC3_SMALL_ROWS) hipLaunchKernelGGL(co_k_rescnn_forward_x3, dim3(grid), dim3(512), RC3_LDS_BYTES, s, q);
     RT_CHECK(hipGetLastError());
   }
 };
