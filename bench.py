@@ -60,13 +60,17 @@ def parse():
 
 def measured_traffic(kernel, args, npools):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
-    (profiles/r01_e_pmc.json; PMC counters cannot be collected from inside an un-profiled run).
+    (profiles/r01_f_pmc.json; PMC counters cannot be collected from inside an un-profiled run).
     Only valid for the workload those passes were taken on (the default one); otherwise null."""
     if (args.games, args.sims, args.spe, args.net, npools) != (4096, 400, 16, "rescnn4x3", 2):
         return None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_e_pmc.json")) as f:
-            return json.load(f)["kernels"][kernel]["traffic_bytes_per_launch"]
+        with open(os.path.join(ROOT, "profiles", "r01_f_pmc.json")) as f:
+            k = json.load(f)["kernels"]
+            t = k[kernel]["traffic_bytes_per_launch"]
+            if kernel + "_small" in k:  # the network launch queues both instances of the kernel; one of them works
+                t += k[kernel + "_small"]["traffic_bytes_per_launch"]
+            return t
     except Exception:
         return None
 

@@ -16,6 +16,14 @@ SRC = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "gpurun_out")
 DST = sys.argv[4] if len(sys.argv) > 4 else os.path.join(ROOT, "profiles")
 
 
+def kname(name):
+    """kernel name as the docs use it: no signature, the two instances of the residual-CNN template
+    under their macro names"""
+    n = name.split("(")[0].replace("void ", "").strip()
+    return n.replace("co_k_rescnn_forward_x3_t<2>", "co_k_rescnn_forward_x3").replace("co_k_rescnn_forward_x3_t<1>",
+                                                                                     "co_k_rescnn_forward_x3_small")
+
+
 def db_of(kind):
     f = glob.glob(os.path.join(SRC, "prof_%s_%s" % (tag, kind), "**", "*.db"), recursive=True)
     return sqlite3.connect(f[0]) if f else None
@@ -27,7 +35,7 @@ def counters(db):
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
     disp = collections.defaultdict(set)
     for k, did, c, v in db.execute("select %s, dispatch_id, counter_name, value from counters_collection" % kcol):
-        k = k.split("(")[0]
+        k = kname(k)
         acc[k][c] += v
         disp[(k, c)].add(did)
     return {k: {c: (acc[k][c] / max(len(disp[(k, c)]), 1), len(disp[(k, c)])) for c in acc[k]} for k in acc}
@@ -37,7 +45,7 @@ lines = ["# %s: kernel statistics (rocprofv3 --kernel-trace --stats), MI355X gfx
          "Command: `%s`" % cmd, "", "| kernel | calls | total (us) | average (us) | share % |", "|---|---:|---:|---:|---:|"]
 db = db_of("stats")
 for name, calls, total, avg, pct in db.execute("select name, total_calls, total_duration, average, percentage from top_kernels"):
-    lines.append("| `%s` | %d | %.1f | %.3f | %.2f |" % (name.split("(")[0], calls, total, avg, pct))
+    lines.append("| `%s` | %d | %.1f | %.3f | %.2f |" % (kname(name), calls, total, avg, pct))
 pmc = {"tag": tag, "command": cmd,
        "note": "rocprofv3 --pmc passes, one counter group per pass with --kernel-trace only. FETCH_SIZE / WRITE_SIZE "
                "are in KB (rocprofv3 units); HBM traffic per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 bytes "
