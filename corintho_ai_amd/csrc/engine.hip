@@ -871,12 +871,16 @@ struct ca_tourney {
         ++p.iterations;
       }
       ++rounds;
-      p.P.to_play = ids.front();
-      RT_LAUNCH(co_k_scan, 1, CO_WAVE, p.stream, p.P); /* refresh the all-done flag */
-      int32_t d = 0;
-      rt_d2h(&d, p.all_done.p, 4, p.stream);
-      rt_sync(p.stream);
-      done = d != 0;
+      /* the host looks at the all-done flag every eighth round only (a round that finds every match
+       * finished launches kernels that return at once), so the queue never runs dry in between */
+      if ((rounds & 7) == 0 || (max_rounds > 0 && rounds >= max_rounds)) {
+        p.P.to_play = ids.front();
+        RT_LAUNCH(co_k_scan, 1, CO_WAVE, p.stream, p.P); /* refresh the all-done flag */
+        int32_t d = 0;
+        rt_d2h(&d, p.all_done.p, 4, p.stream);
+        rt_sync(p.stream);
+        done = d != 0;
+      }
     }
     p.scan_valid = false;
     p.host_games_valid = false;
