@@ -131,6 +131,7 @@ struct ca_trainer {
   std::vector<PlayerCfg> host_pcfg; /* [2G] */
   std::vector<uint32_t> match_seeds; /* [G] */
   DevBuf<PlayerCfg> pcfg;
+  DevBuf<int32_t> arena_state; /* fused arena: see EngineParams::arena_state */
   DevBuf<int32_t> read_offset;
   bool scan_valid = false;
 
@@ -186,6 +187,7 @@ struct ca_trainer {
     all_done.alloc(1);
     row_counter.alloc(1);
     pack_counter.alloc(2 * CO_MAX_POOLS);
+    arena_state.alloc(8);
     if (tourney) {
       pcfg.alloc(host_pcfg.size());
       rt_h2d(pcfg.p, host_pcfg.data(), host_pcfg.size() * sizeof(PlayerCfg), stream);
@@ -230,6 +232,7 @@ struct ca_trainer {
     rt_h2d(trees.p, ht.data(), ht.size() * sizeof(TreeCtl), stream);
     rt_memset(row_counter.p, 0, 8, stream);
     rt_memset(pack_counter.p, 0, 16 * CO_MAX_POOLS, stream);
+    rt_memset(arena_state.p, 0, 32, stream);
     rt_sync(stream);
     iterations = 0;
     trainer_iteration = 0;
@@ -260,6 +263,8 @@ struct ca_trainer {
     P.trace_on = cfg.trace;
     P.pcfg = tourney ? pcfg.p : nullptr;
     P.read_offset = tourney ? read_offset.p : nullptr;
+    P.arena_state = nullptr;
+    P.scan_phase = 0;
     P.games = games.p;
     P.trees = trees.p;
     P.arena = arena.p;
@@ -687,59 +692,73 @@ struct ca_trainer {
       if (npools > G) npools = G;
       return run_pools(max_iterations, npools);
     }
-    /* arena (main.pyx:142-168 with is_testing): one model is served per iteration and the
-     * host flips the model when the batch comes back empty, so every iteration is polled;
-     * requests are packed by K4 in game order (the reference's request order) */
+    /* arena (main.pyx:142-168 with is_testing): one model is served per iteration and hands over
+     * when its batch comes back empty.  The model to move lives on the device (arena_state, kept
+     * by the two scans of an iteration), both networks are queued every iteration and the idle
+     * one finds a row count of zero, so the host only looks every eighth iteration.  Requests
+     * are packed by K4 in game order (the reference's request order). */
+    const int poll = 8;
     std::vector<rt_event_t> ev(4);
     for (auto &e : ev) rt_event_create(&e);
-    int to_play = 0;
-    if (iterations == 0) rt_memset(req_offset.p, 0, ((size_t)G + 1) * 4, stream);
+    P.arena_state = arena_state.p;
     P.row_counter = row_counter.p;
     P.fused_pack = 0;
     P.defer_handover = 0;
+    P.to_play = 0;
     int64_t it = 0;
-    int idle_flips = 0;
+    int32_t st[5] = {0, 0, 0, 0, 0};
+    std::string failure;
     while (!finished && (max_iterations <= 0 || it < max_iterations)) {
-      P.to_play = to_play;
+      const bool timed = (it % poll) == poll - 1 || (max_iterations > 0 && it + 1 == max_iterations);
       P.iteration = trainer_iteration;
-      if (iterations > 0) RT_LAUNCH(co_k_scan, 1, CO_WAVE, stream, P); /* offsets at entry (trainer.cpp:208-215) */
-      rt_event_record(ev[0], stream);
+      P.scan_phase = 0;
+      RT_LAUNCH(co_k_scan, 1, CO_WAVE, stream, P); /* offsets at entry (trainer.cpp:208-215) */
+      if (timed) rt_event_record(ev[0], stream);
       RT_LAUNCH(co_k_mcts_step, G, CO_WAVE, stream, P);
-      rt_event_record(ev[1], stream);
+      if (timed) rt_event_record(ev[1], stream);
+      P.scan_phase = 1;
       RT_LAUNCH(co_k_scan, 1, CO_WAVE, stream, P);
       RT_LAUNCH(co_k_compact, G, CO_WAVE, stream, P);
-      rt_event_record(ev[2], stream);
-      int slot = to_play == 0 ? 1 : 0; /* get_predictions, main.pyx:74-81 */
-      nets[slot]->forward(nn_in.p, G * spe, req_offset.p + G, nn_eval.p, nn_probs.p, stream);
-      rt_event_record(ev[3], stream);
+      if (timed) rt_event_record(ev[2], stream);
+      for (int slot = 0; slot < 2; ++slot) /* get_predictions, main.pyx:74-81 */
+        nets[slot]->forward(nn_in.p, G * spe, arena_state.p + 3 + slot, nn_eval.p, nn_probs.p, stream);
+      if (timed) rt_event_record(ev[3], stream);
       ++iterations;
       ++it;
       ++mcts_launches;
       ++nn_launches;
-      int32_t tot_done[2];
-      rt_d2h(&tot_done[0], req_offset.p + G, 4, stream);
-      rt_d2h(&tot_done[1], all_done.p, 4, stream);
-      rt_sync(stream);
-      finished = tot_done[1] != 0;
-      mcts_ms += rt_event_elapsed_ms(ev[0], ev[1]);
-      pack_ms += rt_event_elapsed_ms(ev[1], ev[2]);
-      nn_ms += rt_event_elapsed_ms(ev[2], ev[3]);
-      if (!finished) {
-        /* main.pyx:150-154: flip the model when it has no request */
-        if (tot_done[0] == 0) {
-          to_play = 1 - to_play;
-          if (++idle_flips > 4) throw EngineError(CA_ERR_ENGINE, "arena: no model has requests");
-        } else {
-          idle_flips = 0;
+      if (timed) {
+        int32_t d = 0;
+        rt_d2h(&d, all_done.p, 4, stream);
+        rt_d2h(st, arena_state.p, sizeof st, stream);
+        rt_sync(stream);
+        finished = d != 0;
+        mcts_timed_ms += rt_event_elapsed_ms(ev[0], ev[1]);
+        nn_timed_ms += rt_event_elapsed_ms(ev[2], ev[3]);
+        pack_ms += rt_event_elapsed_ms(ev[1], ev[2]) * poll;
+        nn_timed_rows += st[3] + st[4];
+        ++timed_launches;
+        if (!finished && st[1] > 4) {
+          failure = "arena: no model has requests";
+          break;
         }
       }
     }
     rt_sync(stream);
     for (auto &e : ev) rt_event_destroy(e);
+    rt_d2h(st, arena_state.p, sizeof st, stream);
+    rt_sync(stream);
+    P.arena_state = nullptr;
+    P.scan_phase = 0;
     P.row_counter = nullptr;
     host_games_valid = false;
     scan_valid = false;
-    pack(to_play); /* refresh the done flag and the batch description */
+    if (timed_launches > 0) {
+      mcts_ms = mcts_timed_ms * (double)mcts_launches / (double)timed_launches;
+      nn_ms = nn_timed_ms * (double)nn_launches / (double)timed_launches;
+    }
+    if (!failure.empty()) throw EngineError(CA_ERR_ENGINE, failure);
+    pack(st[0]); /* refresh the done flag and the batch description */
     check_errors();
     unsigned long long rows = 0;
     rt_d2h(&rows, row_counter.p, 8, stream);

@@ -115,6 +115,13 @@ struct EngineParams {
    * offset table of Tourney::doIteration (tourney.cpp:55-62) */
   const PlayerCfg *pcfg;
   int32_t *read_offset;
+  /* fused arena (Trainer test mode with both networks on the device): the model to move lives on
+   * the device so that the host need not look at every iteration (main.pyx:150-154 flips it when
+   * its batch comes back empty).  [0] model of this iteration, [1] consecutive empty batches,
+   * [2] model of the next iteration (committed by the next entry scan), [3], [4] batch rows for
+   * network slot 0 / 1 (the idle network's count is 0).  Null: `to_play` is the host's. */
+  int32_t *arena_state;
+  int32_t scan_phase; /* co_k_scan: 0 = offsets at entry of an iteration, 1 = batch after the search */
   /* pool */
   GameCtl *games;
   TreeCtl *trees;

@@ -17,17 +17,19 @@ CO_KERNEL co_k_mcts_step(EngineParams P) {
   if (CO_BLOCK_IDX < P.pool_n && g < P.num_games) co_mcts_step_wave(P, g);
 }
 
-/* is game g part of the batch of model `to_play` (trainer.cpp:42-46, 84-98)? */
-CO_DEV int co_game_active(const EngineParams &P, int g, const GameCtl &gc) {
+/* is game g part of the batch of model `tp` (trainer.cpp:42-46, 84-98)? */
+CO_DEV int co_game_active(const EngineParams &P, int g, const GameCtl &gc, int tp) {
   if (gc.done) return 0;
-  if (P.pcfg) return P.pcfg[2 * g + gc.to_play].model_id == P.to_play; /* tourney.cpp:26, 46, 66 */
-  if (P.to_play == 0 || P.to_play == 1) return gc.to_play == (P.to_play + gc.parity) % 2;
+  if (P.pcfg) return P.pcfg[2 * g + gc.to_play].model_id == tp; /* tourney.cpp:26, 46, 66 */
+  if (tp == 0 || tp == 1) return gc.to_play == (tp + gc.parity) % 2;
   return 1;
 }
 
 /* single wavefront: lane l owns a contiguous chunk of games */
 CO_KERNEL co_k_scan(EngineParams P) {
   int G = P.num_games;
+  /* fused arena: the entry scan works for the model staged by the previous iteration */
+  const int tp = P.arena_state ? P.arena_state[P.scan_phase == 0 ? 2 : 0] : P.to_play;
   int chunk = (G + CO_WAVE - 1) / CO_WAVE;
   LV(int, csum);
   LV(int, nd);
@@ -37,7 +39,7 @@ CO_KERNEL co_k_scan(EngineParams P) {
       int g = lane * chunk + i;
       if (g < G) {
         GameCtl gc = P.games[g];
-        if (co_game_active(P, g, gc)) s += gc.n_pending;
+        if (co_game_active(P, g, gc, tp)) s += gc.n_pending;
         notdone += !gc.done;
       }
     }
@@ -66,7 +68,7 @@ CO_KERNEL co_k_scan(EngineParams P) {
       if (g < G) {
         GameCtl gc = P.games[g];
         P.req_offset[g] = s;
-        if (co_game_active(P, g, gc)) s += gc.n_pending;
+        if (co_game_active(P, g, gc, tp)) s += gc.n_pending;
       }
     }
     if (lane == 0 && P.read_offset) {
@@ -75,14 +77,30 @@ CO_KERNEL co_k_scan(EngineParams P) {
       int offset = 0;
       P.read_offset[0] = 0;
       for (int i = 1; i < G; ++i) {
-        if (co_game_active(P, i, P.games[i])) offset += P.games[i - 1].n_pending;
+        if (co_game_active(P, i, P.games[i], tp)) offset += P.games[i - 1].n_pending;
         P.read_offset[i] = offset;
       }
     }
     if (lane == 0) {
       P.req_offset[G] = run;
       P.all_done[0] = not_done == 0;
-      if (P.row_counter) P.row_counter[0] += (unsigned long long)run;
+      if (P.row_counter && (!P.arena_state || P.scan_phase == 1)) P.row_counter[0] += (unsigned long long)run;
+      if (P.arena_state) {
+        if (P.scan_phase == 0) {
+          P.arena_state[0] = tp; /* commit: the search, the compaction and the network of this iteration see it */
+        } else {
+          P.arena_state[3 + (tp == 0 ? 1 : 0)] = run; /* get_predictions, main.pyx:74-81: slot 1 serves model 0 */
+          P.arena_state[3 + (tp == 0 ? 0 : 1)] = 0;
+          /* main.pyx:150-154: a model without requests hands over to the other one */
+          if (not_done != 0 && run == 0) {
+            P.arena_state[2] = 1 - tp;
+            P.arena_state[1] += 1;
+          } else {
+            P.arena_state[2] = tp;
+            P.arena_state[1] = 0;
+          }
+        }
+      }
     }
   }
 }
@@ -91,7 +109,7 @@ CO_KERNEL co_k_compact(EngineParams P) {
   int g = CO_BLOCK_IDX;
   if (g >= P.num_games) return;
   GameCtl gc = P.games[g];
-  if (!co_game_active(P, g, gc)) return;
+  if (!co_game_active(P, g, gc, P.arena_state ? P.arena_state[0] : P.to_play)) return;
   int n = gc.n_pending;
   const float *src = P.req + (size_t)g * P.searches_per_eval * CO_STATE_STRIDE;
   float *dst = P.nn_in + (size_t)P.req_offset[g] * CO_STATE_STRIDE;

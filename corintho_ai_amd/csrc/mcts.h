@@ -1257,10 +1257,11 @@ CO_DEV void co_mcts_step_wave(const EngineParams &P, int g) {
   }
   GameCtl gc = P.games[g];
   if (gc.done || gc.error) return;
+  const int tp = P.arena_state ? P.arena_state[0] : P.to_play;
   if (P.pcfg) {
-    if (P.pcfg[2 * g + gc.to_play].model_id != P.to_play) return; /* tourney.cpp:66 */
-  } else if (P.to_play == 0 || P.to_play == 1) {
-    if (gc.to_play != (P.to_play + gc.parity) % 2) return;
+    if (P.pcfg[2 * g + gc.to_play].model_id != tp) return; /* tourney.cpp:66 */
+  } else if (tp == 0 || tp == 1) {
+    if (gc.to_play != (tp + gc.parity) % 2) return;
   } else if (P.stagger_div > 0) {
     if ((P.game_base + g) / P.stagger_div > P.iteration) {
       if (P.fused_pack) co_atomic_add_u64(P.pack_counter + (P.iteration & 1), 1ull << 32); /* still running */
