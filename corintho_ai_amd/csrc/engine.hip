@@ -91,6 +91,7 @@ struct Pool {
   int lo, n, row_base;
   bool finished;
   int idle;
+  int running; /* games of the pool still running at its last poll */
   rt_event_t ev[2][3];      /* per window parity: start / after search / after network of the TIMED iteration */
   rt_event_t polled[2];
   int launched[2];          /* iterations queued in the window of that parity */
@@ -570,6 +571,7 @@ struct ca_trainer {
     }
     for (auto &q : pools) {
       q.finished = false;
+      q.running = q.n;
       q.idle = 0;
       q.launched[0] = q.launched[1] = 0;
       q.timed[0] = q.timed[1] = 0;
@@ -592,6 +594,7 @@ struct ca_trainer {
       if (!q.launched[parity]) return;
       rt_event_sync(q.polled[parity]);
       unsigned long long c = q.word[parity];
+      q.running = (int)(c >> 32);
       if (q.timed[parity]) {
         /* one iteration per window is timed (three event records per launch pair cost 1-4 % of
          * the wall time); its batch size is the counter word just read */
@@ -616,6 +619,12 @@ struct ca_trainer {
         if (q.finished) continue;
         EngineParams pp = P;
         pp.iteration = trainer_iteration;
+        /* Deferring the new mover's first searches to the next step (mcts.h co_game_step) balances
+         * the waves of a full launch but costs the game one more iteration per ply; once the pool
+         * has thinned out, an iteration is as long as its slowest wave anyway and the number of
+         * iterations of the longest game is what the generation waits for.  Per-game results do
+         * not depend on the choice. */
+        pp.defer_handover = q.running * 2 > q.n ? 1 : 0;
         pp.pool_lo = q.lo;
         pp.pool_n = q.n;
         pp.pool_row_base = q.row_base;
