@@ -95,6 +95,8 @@ struct Pool {
   rt_event_t ev[2][3];      /* per window parity: start / after search / after network of the TIMED iteration */
   rt_event_t polled[2];
   int launched[2];          /* iterations queued in the window of that parity */
+  int word_iter[2];         /* Trainer::searches_done_ of the iteration whose counter word was copied */
+  int first_start;          /* iteration at which the stagger releases the pool's first game (trainer.cpp:184-186) */
   int timed[2];             /* the window's last iteration carries the events */
   unsigned long long *word; /* pinned: counter word copied at the end of window parity 0 / 1 */
 };
@@ -575,6 +577,8 @@ struct ca_trainer {
       q.idle = 0;
       q.launched[0] = q.launched[1] = 0;
       q.timed[0] = q.timed[1] = 0;
+      q.word_iter[0] = q.word_iter[1] = 0;
+      q.first_start = P.stagger_div > 0 ? (P.game_base + q.lo) / P.stagger_div : 0;
     }
     rt_sync(stream);
     P.to_play = -1;
@@ -607,7 +611,10 @@ struct ca_trainer {
       q.launched[parity] = 0;
       q.finished = (c >> 32) == 0;
       if (!q.finished && (c & 0xFFFFFFFFull) == 0) {
-        if (++q.idle > 16) failure = "No requests during training"; /* main.pyx:161-163 */
+        /* main.pyx:161-163 raises when NO game has a request.  A pool whose first game the
+         * staggered start (trainer.cpp:184-186) has not released yet has running games and no
+         * rows by construction: that is not the reference's error condition */
+        if (q.word_iter[parity] > q.first_start && ++q.idle > 16) failure = "No requests during training";
       } else {
         q.idle = 0;
       }
@@ -654,6 +661,7 @@ struct ca_trainer {
         for (auto &q : pools) {
           if (q.finished) continue;
           rt_d2h(&q.word[parity], pack_counter.p + 2 * (&q - &pools[0]) + counter_slot, 8, q.st);
+          q.word_iter[parity] = trainer_iteration - 1;
           rt_event_record(q.polled[parity], q.st);
         }
         all_finished = true;

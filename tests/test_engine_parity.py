@@ -333,6 +333,26 @@ def test_fused_pools_do_not_change_any_game(engine):
 
 
 @pytest.mark.parametrize("engine", ENGINES)
+@pytest.mark.parametrize("pools,base,total", [(2, 0, 300), (1, 150, 300), (2, 150, 450)])
+def test_fused_staggered_start_with_late_pools(engine, pools, base, total):
+    """The staggered start (trainer.cpp:184-186) releases game i at iteration i / max(G / S, 1): a
+    pool (or a shard with game_base > 0) whose first game starts after more than 17 host polls
+    (136 iterations) has running games and no request rows until then.  That is not the
+    "No requests during training" condition of main.pyx:161-163 (which looks at ALL games)."""
+    G = total - base if pools == 1 else 300
+    S_, spe = total, 16  # stagger_div = max(total / S, 1) = 1
+    w = nets.init_mlp12x100(seed=0)
+    t = make_trainer(engine, G, "", 3, S_, spe, 1.0, 0.25, 0, 1, False, pools=pools, game_base=base,
+                     total_games=base + G)
+    t.set_net(1, w)
+    first_late = base + (G // 2 if pools == 2 else 0)  # release iteration of the last pool's first game
+    assert first_late > 136
+    assert not t.run(max_iterations=first_late + S_ // spe + 8)  # the old idle count raised after ~136 iterations
+    info = t.game_info(G // 2 if pools == 2 else 0)
+    assert info["error"] == 0 and info["plies"] >= 1  # that game was released and has moved
+
+
+@pytest.mark.parametrize("engine", ENGINES)
 def test_mlp_matches_float32_restatement(engine):
     """policy/value within 1e-4 (fp32) of the numpy restatement of wrapper.py:256-271"""
     G, spe = 64, 16
