@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libcorintho_hip.so")
-SOURCES = ["engine.hip", "nn_mlp.hip", "nn_mlp_x3.hip", "nn_rescnn.hip"]
+SOURCES = ["engine.hip", "nn_mlp.hip", "nn_mlp_split.hip", "nn_rescnn.hip"]
 FLAGS = [
     "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-ffp-contract=off",
     "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall", "-Wno-unused-function",

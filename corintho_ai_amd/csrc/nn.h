@@ -18,6 +18,10 @@
 #define CO_NET_RESCNN4 2
 #define CO_NET_RESCNN4_X3 3 /* same network and weights, convolutions at bf16x3 split precision */
 #define CO_NET_MLP12X100_X3 4 /* mlp12x100, same weights, dense layers at bf16x3 split precision */
+/* float32-equivalent arithmetic on the bf16 matrix pipe: both operands as three bf16 terms (their sum is the
+ * float32 value), six MFMA products -- everything down to 2^-24 of a product is kept (nn_rescnn.hip) */
+#define CO_NET_RESCNN4_X6 5
+#define CO_NET_MLP12X100_X6 6
 
 /* mlp12x100 flat weight layout (float32), matching Keras get_weights() order of
  * wrapper.py:256-271:

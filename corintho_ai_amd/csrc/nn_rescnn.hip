@@ -32,6 +32,7 @@
 #include <vector>
 
 #include "engine_defs.h"
+#include "lds_dma.h"
 #include "nn.h"
 
 #define RC_NB 4
@@ -343,12 +344,21 @@ __global__ __launch_bounds__(256, 2) void co_k_rescnn_forward(RcParams P) {
 }
 
 /* ======================================================================
- * bf16x3 variant (CA_NET_RESCNN4_X3): same network, same weights, same register-resident
- * structure, but every 3x3 convolution runs on the bf16 matrix pipe at split precision:
- * x = hi + lo with hi = bf16(x), lo = bf16(x - hi) (16 mantissa bits kept), and
- *   x * w  ~=  hi_x*hi_w + hi_x*lo_w + lo_x*hi_w      (fp32 accumulation in the MFMA)
- * Three bf16 MFMAs replace eight fp32 ones: 5.3x the fp32 matrix rate.  Measured against
- * the float32 restatement the value differs by < 2e-5 and the policy by < 1e-6 (contract 1e-4).
+ * Split-precision variants (CO_NET_RESCNN4_X3: NT = 2 terms, CO_NET_RESCNN4_X6: NT = 3 terms):
+ * same network, same weights, same register-resident structure, but every 3x3 convolution runs
+ * on the bf16 matrix pipe with both operands written as a sum of NT bf16 values,
+ *   x = x0 + x1 (+ x2),  x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1),
+ * and the product expanded into the terms w_i x_j with i + j <= NT - 1 (fp32 accumulation in the
+ * MFMA):
+ *   NT = 2 ("bf16x3"): 16 significand bits kept, 3 MFMAs; dropped terms ~2^-16 |x w|.  Within
+ *           2e-5 of the float32 restatement -- narrower than the reference's float32 arithmetic.
+ *   NT = 3 ("bf16x6"): x0 + x1 + x2 IS the float32 value (3 x 8 = 24 significand bits, the
+ *           remainders are exact), 6 MFMAs; the dropped terms w1 x2, w2 x1, w2 x2 are <= 2^-24
+ *           |x w| each -- the size of ONE float32 rounding of the product, and there are fewer
+ *           accumulator roundings than in the fp32 MFMA chain (one per 16 products instead of one
+ *           per product).  Measured against a float64 restatement the error is that of K6 (fp32
+ *           MFMA) or smaller (tests/test_net_precision.py): float32-equivalent arithmetic at 16/6 =
+ *           2.7x the fp32 matrix rate.
  *
  * v_mfma_f32_32x32x16_bf16 (an MFMA of this shape occupies the SIMD's issue port for 8 of
  * its 32 cycles; the 16x16x32 shape for 8 of 16, which left too little room for the DPP
@@ -360,22 +370,33 @@ __global__ __launch_bounds__(256, 2) void co_k_rescnn_forward(RcParams P) {
  * layer is the operand layout of the next, and the tap shift is the same DPP row shift
  * (a row of 16 lanes = one position), now on packed pairs.
  * Bias, BatchNorm, residual adds and the heads stay in fp32.
- * Geometry: 512 threads = 8 waves (two per SIMD), 2 position pairs per wave, 32 positions
- * per workgroup. */
-/* NP = position pairs per wave: 2 in the throughput kernel (32 positions per workgroup), 1 in the
- * small-batch kernel (16 per workgroup: half the MFMA work behind the same weight stream, so a
+ * Geometry: 512 threads = 8 waves (two per SIMD), NP position pairs per wave. */
+/* NP = position pairs per wave.  NT = 2: 2 in the throughput kernel (32 positions per workgroup), 1 in
+ * the small-batch kernel (16 per workgroup: half the MFMA work behind the same weight stream, so a
  * batch that fits one round of workgroups comes back sooner -- the thinning tail of a generation
- * runs hundreds of such iterations, each as long as its slowest kernel) */
-#define RC3_SMALL_ROWS 4096 /* batches up to this size take the small-batch kernel: <= 256 workgroups */
-#define RC3_STEM_CHUNK 1024 /* u32: 1 k-step x 2 out tiles x {hi,lo} x 64 lanes x 4 */
-#define RC3_CONV_CHUNK 4096 /* u32: 4 k-steps ... = 16 KB */
-#define RC3_TRUNK_WORDS (9 * RC3_STEM_CHUNK + 72 * RC3_CONV_CHUNK)
-/* head weights staged once per workgroup behind the two trunk groups and the head features:
- * 1x1 fragments (2048 words), policy dense (6144), value dense 1 (2048), value dense 2 (1024),
- * epilogue constants of the nine convolutions (1728, padded) */
+ * runs hundreds of such iterations, each as long as its slowest kernel).  NT = 3: 1 (three packed
+ * operand sets + three weight fragment sets leave no registers for a second pair at two waves per
+ * SIMD; the MFMA work per weight byte is that of NT = 2, NP = 2 again). */
+#define RC3_SMALL_ROWS 4096 /* NT = 2: batches up to this size take the small-batch kernel: <= 256 workgroups */
+#define RCS_STEM_CHUNK(NT) (512 * (NT))  /* u32: 1 k-step x 2 out tiles x NT terms x 64 lanes x 4 */
+#define RCS_CONV_CHUNK(NT) (2048 * (NT)) /* u32: 4 k-steps ... = 8 KB per term */
+#define RCS_TRUNK_WORDS(NT) (9 * RCS_STEM_CHUNK(NT) + 72 * RCS_CONV_CHUNK(NT))
 #define RC3_EPI_WORDS 1792 /* 9 convolutions x (bias, BN scale, BN shift)[64], padded to whole 256-word pieces */
-#define RC3_HEAD_WORDS (2048 + 6144 + 2048 + 1024 + RC3_EPI_WORDS)
-#define RC3_LDS_BYTES (2 * 3 * RC3_CONV_CHUNK * 4 + 8 * RC_NB * 96 * 4 + RC3_HEAD_WORDS * 4)
+/* head weights: 1x1 fragments (4 steps x NT terms x 64 lanes x 4 words), then the fp32 dense weights in
+ * MFMA order: policy dense (6144), value dense 1 (2048), value dense 2 (1024) */
+#define RCS_FRAG1_WORDS(NT) (4 * (NT) * 256)
+#define RCS_DENSE_WORDS (6144 + 2048 + 1024)
+#define RCS_HEAD_WORDS(NT) (RCS_FRAG1_WORDS(NT) + RCS_DENSE_WORDS)
+/* weights stream through LDS in groups of three taps (one kernel row): 27 groups, group
+ * gi < 3 belongs to the stem */
+#define RC3_NUM_GROUPS 27
+#define RCS_GROUP_WORDS(NT) (3 * RCS_CONV_CHUNK(NT)) /* 48 KB / 72 KB */
+#define RCS_FEAT_WORDS(NP) (8 * 2 * (NP) * 96)
+/* LDS: [2 weight groups][head features][epilogue constants][NT = 2: head weights].  With three terms
+ * the head weights do not fit beside two 72 KB groups: they are staged into the idle group buffer
+ * while the last group computes. */
+#define RCS_LDS_WORDS(NT, NP) \
+  (2 * RCS_GROUP_WORDS(NT) + RCS_FEAT_WORDS(NP) + RC3_EPI_WORDS + ((NT) == 2 ? RCS_HEAD_WORDS(NT) : 0))
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -385,37 +406,43 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct Rc3Params {
   RcParams base;          /* dense heads + epilogue parameters, in/out pointers */
-  const uint32_t *wtrunk; /* RC3_TRUNK_WORDS, bf16 hi/lo fragments */
-  const uint32_t *whead3; /* RC3_HEAD_WORDS: [4 steps][hi, lo][64 lanes][4 words] 1x1 head convs in fragment order,
+  const uint32_t *wtrunk; /* RCS_TRUNK_WORDS, bf16 term fragments */
+  const uint32_t *whead3; /* RCS_HEAD_WORDS: [4 steps][NT terms][64 lanes][4 words] 1x1 head convs in fragment order,
                            * then the fp32 dense weights wpol, wv1, wv2 as in RcParams */
+  const uint32_t *epi3;   /* RC3_EPI_WORDS: RcParams::epi, padded */
 };
 
-/* weights stream through LDS in groups of three taps (one kernel row): 27 groups, group
- * gi < 3 belongs to the stem */
-#define RC3_NUM_GROUPS 27
-#define RC3_GROUP_WORDS (3 * RC3_CONV_CHUNK) /* 48 KB */
-__device__ __forceinline__ const uint32_t *rc3_chunk_ptr(const uint32_t *wtrunk, int gi) {
-  return gi < 3 ? wtrunk + gi * 3 * RC3_STEM_CHUNK : wtrunk + 9 * RC3_STEM_CHUNK + (gi - 3) * 3 * RC3_CONV_CHUNK;
+template <int NT>
+__device__ __forceinline__ const uint32_t *rcs_group_ptr(const uint32_t *wtrunk, int gi) {
+  return gi < 3 ? wtrunk + gi * 3 * RCS_STEM_CHUNK(NT) : wtrunk + 9 * RCS_STEM_CHUNK(NT) + (gi - 3) * 3 * RCS_CONV_CHUNK(NT);
 }
 
-__device__ __forceinline__ void rc3_stage(const uint32_t *wtrunk, uint32_t *lds_buf, int gi, int wave, int lane) {
-  const uint32_t *src = rc3_chunk_ptr(wtrunk, gi);
-  const int pieces = gi < 3 ? 3 * RC3_STEM_CHUNK / 256 : 3 * RC3_CONV_CHUNK / 256;
-  for (int p = wave; p < pieces; p += 8) {
-    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + p * 256 + lane * 4),
-                                     (void __attribute__((address_space(3))) *)(lds_buf + p * 256), 16, 0, 0);
-  }
+/* LDS-DMA of `words` (a multiple of 256) by the eight waves of the workgroup (lds_dma.h: the waits
+ * are the kernel's own) */
+__device__ __forceinline__ void rcs_stage_words(const uint32_t *src, uint32_t lds_addr, int words, int wave, int lane) {
+  const int pieces = words / 256;
+  for (int p = wave; p < pieces; p += 8) co_lds_dma_1k(src + p * 256 + lane * 4, lds_addr + (uint32_t)p * 1024u);
 }
 
-/* (a, b) -> packed bf16 pair of the values and packed bf16 pair of the remainders */
-__device__ __forceinline__ void rc3_split(float a, float b, uint32_t &hi, uint32_t &lo) {
+template <int NT>
+__device__ __forceinline__ void rcs_stage(const uint32_t *wtrunk, uint32_t lds_addr, int gi, int wave, int lane) {
+  rcs_stage_words(rcs_group_ptr<NT>(wtrunk, gi), lds_addr, gi < 3 ? 3 * RCS_STEM_CHUNK(NT) : 3 * RCS_CONV_CHUNK(NT), wave, lane);
+}
+
+/* (a, b) -> NT packed bf16 pairs: the values rounded to bf16, then the successive remainders (each
+ * remainder is exact in float32, so with NT = 3 the three terms add up to the float32 value) */
+template <int NT>
+__device__ __forceinline__ void rcs_split(float a, float b, uint32_t (&t)[NT]) {
   f32x2 v = {a, b};
-  bf16x2 h = __builtin_convertvector(v, bf16x2);
-  f32x2 hf = __builtin_convertvector(h, f32x2);
-  f32x2 rem = {a - hf.x, b - hf.y};
-  bf16x2 l = __builtin_convertvector(rem, bf16x2);
-  hi = __builtin_bit_cast(uint32_t, h);
-  lo = __builtin_bit_cast(uint32_t, l);
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    bf16x2 hb = __builtin_convertvector(v, bf16x2);
+    t[i] = __builtin_bit_cast(uint32_t, hb);
+    if (i + 1 < NT) {
+      f32x2 hf = __builtin_convertvector(hb, f32x2);
+      v = (f32x2){v.x - hf.x, v.y - hf.y};
+    }
+  }
 }
 
 template <int S>
@@ -423,15 +450,6 @@ __device__ __forceinline__ uint32_t rc3_row_shift(uint32_t v) {
   if (S == 0) return v;
   constexpr int ctrl = S > 0 ? (0x100 + S) : (0x110 - S);
   return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, ctrl, 0xF, 0xF, true);
-}
-
-template <int TAP>
-__device__ __forceinline__ uint32_t rc3_tap(uint32_t v, bool okL, bool okR) {
-  constexpr int dy = TAP / 3 - 1, dx = TAP % 3 - 1;
-  uint32_t s = rc3_row_shift<4 * dy + dx>(v);
-  if (dx == -1) s = okL ? s : 0u;
-  if (dx == 1) s = okR ? s : 0u;
-  return s;
 }
 
 /* The four packed words of one B operand shifted to tap (dy, dx).  For dx != 0 the shift and
@@ -491,24 +509,23 @@ __device__ __forceinline__ u32x4 rc3_tap4_sel(const uint32_t (&in)[4], int tap, 
   }
 }
 
-/* One staged group = taps 3G .. 3G + 2, CS K steps each.  ph/pl[np][s][m]: K step s = 2T + a,
+/* One staged group = taps 3G .. 3G + 2, CS K steps each.  p[t][np][s][m]: term t, K step s = 2T + a,
  * word m = channels (reg 8a + 2m, 8a + 2m + 1) of tile T.  The weight fragments of step i + 1
  * (also across the tap boundary) are requested from LDS before the MFMAs of step i issue (two
- * register sets), so the LDS latency is paid once per group. */
-template <int CS, int G, int NP>
-__device__ __forceinline__ void rc3_conv_group(f32x16 (&acc)[NP][2], const uint32_t (&ph)[NP][4][4],
-                                               const uint32_t (&pl)[NP][4][4], const uint32_t *wg, int lane,
-                                               bool okL, bool okR) {
-  constexpr int tw = CS == 1 ? RC3_STEM_CHUNK : RC3_CONV_CHUNK;
+ * register sets), so the LDS latency is paid once per group.  Products w_i x_j, i + j <= NT - 1,
+ * largest first. */
+template <int CS, int G, int NP, int NT>
+__device__ __forceinline__ void rcs_conv_group(f32x16 (&acc)[NP][2], const uint32_t (&p)[NT][NP][4][4], const uint32_t *wg,
+                                               int lane) {
+  constexpr int tw = CS == 1 ? RCS_STEM_CHUNK(NT) : RCS_CONV_CHUNK(NT);
   constexpr int N = 3 * CS;
   uint32_t zero;
   asm("v_mov_b32 %0, 0" : "=v"(zero)); /* a zero the compiler keeps in a VGPR (second cndmask source) */
-  u32x4 ah[2][2], al[2][2];
+  u32x4 a[2][NT][2];
 #pragma unroll
-  for (int to = 0; to < 2; ++to) {
-    ah[0][to] = *reinterpret_cast<const u32x4 *>(wg + (((0 * 2 + to) * 2 + 0) * 64 + lane) * 4);
-    al[0][to] = *reinterpret_cast<const u32x4 *>(wg + (((0 * 2 + to) * 2 + 1) * 64 + lane) * 4);
-  }
+  for (int to = 0; to < 2; ++to)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) a[0][t][to] = *reinterpret_cast<const u32x4 *>(wg + (((0 * 2 + to) * NT + t) * 64 + lane) * 4);
 #pragma unroll
   for (int idx = 0; idx < N; ++idx) {
     const int cur = idx & 1, nxt = cur ^ 1;
@@ -517,55 +534,55 @@ __device__ __forceinline__ void rc3_conv_group(f32x16 (&acc)[NP][2], const uint3
       const int tg1 = (idx + 1) / CS, s1 = (idx + 1) % CS;
       const uint32_t *w1 = wg + tg1 * tw;
 #pragma unroll
-      for (int to = 0; to < 2; ++to) {
-        ah[nxt][to] = *reinterpret_cast<const u32x4 *>(w1 + (((s1 * 2 + to) * 2 + 0) * 64 + lane) * 4);
-        al[nxt][to] = *reinterpret_cast<const u32x4 *>(w1 + (((s1 * 2 + to) * 2 + 1) * 64 + lane) * 4);
-      }
+      for (int to = 0; to < 2; ++to)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          a[nxt][t][to] = *reinterpret_cast<const u32x4 *>(w1 + (((s1 * 2 + to) * NT + t) * 64 + lane) * 4);
     }
 #pragma unroll
     for (int np = 0; np < NP; ++np) {
-      const u32x4 bh = rc3_tap4_sel(ph[np][s], 3 * G + tg, zero);
-      const u32x4 bl = rc3_tap4_sel(pl[np][s], 3 * G + tg, zero);
-      const bf16x8 Bh = __builtin_bit_cast(bf16x8, bh), Bl = __builtin_bit_cast(bf16x8, bl);
+      bf16x8 B[NT];
 #pragma unroll
-      for (int to = 0; to < 2; ++to)
-        acc[np][to] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[cur][to]), Bh, acc[np][to], 0, 0, 0);
+      for (int t = 0; t < NT; ++t) B[t] = __builtin_bit_cast(bf16x8, rc3_tap4_sel(p[t][np][s], 3 * G + tg, zero));
 #pragma unroll
-      for (int to = 0; to < 2; ++to)
-        acc[np][to] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[cur][to]), Bl, acc[np][to], 0, 0, 0);
+      for (int sum = 0; sum < NT; ++sum)
 #pragma unroll
-      for (int to = 0; to < 2; ++to)
-        acc[np][to] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[cur][to]), Bh, acc[np][to], 0, 0, 0);
+        for (int i = 0; i <= sum; ++i)
+#pragma unroll
+          for (int to = 0; to < 2; ++to)
+            acc[np][to] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[cur][i][to]), B[sum - i],
+                                                                  acc[np][to], 0, 0, 0);
     }
   }
 }
 
-template <int CS, int NP>
-__device__ __forceinline__ void rc3_conv3x3(f32x16 (&acc)[NP][2], const uint32_t (&ph)[NP][4][4],
-                                            const uint32_t (&pl)[NP][4][4], int &ch, const uint32_t *wtrunk,
-                                            uint32_t *lds_w, int wave, int lane, bool okL, bool okR) {
+template <int CS, int NP, int NT>
+__device__ __forceinline__ void rcs_conv3x3(f32x16 (&acc)[NP][2], const uint32_t (&p)[NT][NP][4][4], int &ch,
+                                            const Rc3Params &Q, uint32_t *lds_w, uint32_t lds_w_addr, int wave, int lane) {
 #pragma unroll
   for (int np = 0; np < NP; ++np)
 #pragma unroll
     for (int to = 0; to < 2; ++to)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[np][to][i] = 0.0f;
-#define RC3_GROUP(G)                                                                         \
-  {                                                                                          \
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                         \
-    __syncthreads();                                                                         \
-    if (ch + 1 < RC3_NUM_GROUPS) rc3_stage(wtrunk, lds_w + ((ch + 1) & 1) * RC3_GROUP_WORDS, ch + 1, wave, lane); \
-    rc3_conv_group<CS, G, NP>(acc, ph, pl, lds_w + (ch & 1) * RC3_GROUP_WORDS, lane, okL, okR);  \
-    ++ch;                                                                                    \
+#define RC3_GROUP(G)                                                                                              \
+  {                                                                                                               \
+    CO_WAIT_VMCNT(0); /* group ch has landed (requested one group ago) */                                         \
+    co_wg_barrier();  /* ... for every wave, and everyone has left the other buffer */                            \
+    if (ch + 1 < RC3_NUM_GROUPS)                                                                                  \
+      rcs_stage<NT>(Q.wtrunk, lds_w_addr + (uint32_t)((ch + 1) & 1) * (RCS_GROUP_WORDS(NT) * 4u), ch + 1, wave, lane); \
+    else if (NT != 2) /* the head weights ride in the buffer the last group leaves idle */                        \
+      rcs_stage_words(Q.whead3, lds_w_addr + (uint32_t)((ch + 1) & 1) * (RCS_GROUP_WORDS(NT) * 4u), RCS_HEAD_WORDS(NT), wave, lane); \
+    rcs_conv_group<CS, G, NP, NT>(acc, p, lds_w + (ch & 1) * RCS_GROUP_WORDS(NT), lane);                          \
+    ++ch;                                                                                                         \
   }
   RC3_GROUP(0) RC3_GROUP(1) RC3_GROUP(2)
 #undef RC3_GROUP
 }
 
-/* fp32 tile values -> the packed hi/lo operands of the next convolution */
-template <int NP>
-__device__ __forceinline__ void rc3_pack(uint32_t (&ph)[NP][4][4], uint32_t (&pl)[NP][4][4],
-                                         const float (&v)[NP][2][16]) {
+/* fp32 tile values -> the packed operands of the next convolution */
+template <int NP, int NT>
+__device__ __forceinline__ void rcs_pack(uint32_t (&p)[NT][NP][4][4], const float (&v)[NP][2][16]) {
 #pragma unroll
   for (int np = 0; np < NP; ++np)
 #pragma unroll
@@ -573,8 +590,12 @@ __device__ __forceinline__ void rc3_pack(uint32_t (&ph)[NP][4][4], uint32_t (&pl
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
-          rc3_split(v[np][T][8 * a + 2 * m], v[np][T][8 * a + 2 * m + 1], ph[np][2 * T + a][m], pl[np][2 * T + a][m]);
+        for (int m = 0; m < 4; ++m) {
+          uint32_t t[NT];
+          rcs_split<NT>(v[np][T][8 * a + 2 * m], v[np][T][8 * a + 2 * m + 1], t);
+#pragma unroll
+          for (int i = 0; i < NT; ++i) p[i][np][2 * T + a][m] = t[i];
+        }
 }
 
 /* conv bias -> BatchNorm affine (-> + skip) -> ReLU; register 4g + i of tile T is channel
@@ -625,29 +646,26 @@ extern "C" int ca_net_prof(unsigned long long out[8]) {
 #define RC3_STAMP(slot)
 #endif
 
-template <int NP>
-__global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_x3_t(Rc3Params Q) {
+template <int NP, int NT>
+__global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_split_t(Rc3Params Q) {
   const RcParams &P = Q.base;
-  extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[]; /* 2 weight groups + head features */
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
   uint32_t *lds_w = lds_dyn;
-  float(*lds_feat)[RC_NB][96] = reinterpret_cast<float(*)[RC_NB][96]>(lds_dyn + 2 * RC3_GROUP_WORDS);
+  float *lds_feat = reinterpret_cast<float *>(lds_dyn + 2 * RCS_GROUP_WORDS(NT));
   const int rows = *P.d_rows;
-  if ((rows <= RC3_SMALL_ROWS) != (NP == 1)) return; /* the other kernel takes this batch */
+  if (NT == 2 && (rows <= RC3_SMALL_ROWS) != (NP == 1)) return; /* the other kernel takes this batch */
   const int row0 = blockIdx.x * (16 * NP);
   if (row0 >= rows) return;
   const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63, h = lane >> 5, p2 = (lane >> 4) & 1, c = lane & 15;
-  const bool okL = (c & 3) != 0, okR = (c & 3) != 3;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, h = lane >> 5, p2 = (lane >> 4) & 1, c = lane & 15;
 #ifdef CO_PROF
   unsigned long long stamp_ = __builtin_readcyclecounter();
   const unsigned long long start_ = stamp_;
 #endif
-  rc3_stage(Q.wtrunk, lds_w, 0, wave, lane);
-  /* the head weights ride along with the first group (the wait before the first MFMA covers them) */
-  uint32_t *lds_head = lds_dyn + 2 * RC3_GROUP_WORDS + 8 * RC_NB * 96;
-  for (int p = wave; p < RC3_HEAD_WORDS / 256; p += 8)
-    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(Q.whead3 + p * 256 + lane * 4),
-                                     (void __attribute__((address_space(3))) *)(lds_head + p * 256), 16, 0, 0);
+  const uint32_t lds_w_addr = co_lds_addr(lds_dyn);
+  uint32_t *lds_epi_w = lds_dyn + 2 * RCS_GROUP_WORDS(NT) + RCS_FEAT_WORDS(NP);
+  const uint32_t lds_epi_addr = lds_w_addr + (2 * RCS_GROUP_WORDS(NT) + RCS_FEAT_WORDS(NP)) * 4u;
+  const uint32_t *lds_head = NT == 2 ? lds_epi_w + RC3_EPI_WORDS : lds_w + (RC3_NUM_GROUPS & 1) * RCS_GROUP_WORDS(NT);
 
   /* input planes: register 4g + i of tile 0 = channel 8g + 4h + i:
    * g 0: h 0 the cell's board bits, h 1 reserves 0..3; g 1: h 0 reserves 4..5 (+ padding), h 1 zeros */
@@ -667,39 +685,49 @@ __global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_x3_t(Rc3Params Q) 
       x[np][0][4] = v1.x; x[np][0][5] = v1.y; x[np][0][6] = v1.z; x[np][0][7] = v1.w;
     }
   }
-  uint32_t ph[NP][4][4], pl[NP][4][4];
-  rc3_pack<NP>(ph, pl, x);
+  uint32_t pk[NT][NP][4][4];
+  rcs_pack<NP, NT>(pk, x);
+  /* weight stream, requested behind the input loads (vmcnt retires in issue order): group 0, the
+   * epilogue constants and, with two terms, the head weights (the wait before the first MFMA
+   * covers them) */
+  rcs_stage<NT>(Q.wtrunk, lds_w_addr, 0, wave, lane);
+  rcs_stage_words(Q.epi3, lds_epi_addr, RC3_EPI_WORDS, wave, lane);
+  if (NT == 2) rcs_stage_words(Q.whead3, lds_epi_addr + RC3_EPI_WORDS * 4u, RCS_HEAD_WORDS(NT), wave, lane);
   RC3_STAMP(0)
   f32x16 acc[NP][2];
   float y[NP][2][16];
   int ch = 0;
-  rc3_conv3x3<1, NP>(acc, ph, pl, ch, Q.wtrunk, lds_w, wave, lane, okL, okR);
+  rcs_conv3x3<1, NP, NT>(acc, pk, ch, Q, lds_w, lds_w_addr, wave, lane);
   RC3_STAMP(1)
-  const float *lds_epi = reinterpret_cast<const float *>(lds_head + 2048 + 6144 + 2048 + 1024);
+  const float *lds_epi = reinterpret_cast<const float *>(lds_epi_w);
   rc3_epilogue<false, NP>(x, acc, x, lds_epi, h);
-  rc3_pack<NP>(ph, pl, x);
+  rcs_pack<NP, NT>(pk, x);
   RC3_STAMP(2)
   for (int b = 0; b < 4; ++b) {
-    rc3_conv3x3<4, NP>(acc, ph, pl, ch, Q.wtrunk, lds_w, wave, lane, okL, okR);
+    rcs_conv3x3<4, NP, NT>(acc, pk, ch, Q, lds_w, lds_w_addr, wave, lane);
     RC3_STAMP(3)
     rc3_epilogue<false, NP>(y, acc, x, lds_epi + (1 + 2 * b) * 192, h);
-    rc3_pack<NP>(ph, pl, y);
+    rcs_pack<NP, NT>(pk, y);
     RC3_STAMP(2)
-    rc3_conv3x3<4, NP>(acc, ph, pl, ch, Q.wtrunk, lds_w, wave, lane, okL, okR);
+    rcs_conv3x3<4, NP, NT>(acc, pk, ch, Q, lds_w, lds_w_addr, wave, lane);
     RC3_STAMP(3)
     rc3_epilogue<true, NP>(x, acc, x, lds_epi + (2 + 2 * b) * 192, h);
-    rc3_pack<NP>(ph, pl, x);
+    rcs_pack<NP, NT>(pk, x);
     RC3_STAMP(2)
+  }
+  if (NT != 2) {
+    /* the head weights were requested behind the last group */
+    CO_WAIT_VMCNT(0);
+    co_wg_barrier();
   }
   /* heads: the two 1x1 convolutions as one more split-precision step on the operands packed
    * after the last block (no tap shift); output rows 0..3 policy planes (h 0), 4..5 value (h 1) */
-  float *feat_w = &lds_feat[0][0][0] + wave * (2 * NP) * 96; /* this wave's positions, workgroup order */
-  u32x4 hh[4], hl[4];
+  float *feat_w = lds_feat + wave * (2 * NP) * 96; /* this wave's positions, workgroup order */
+  u32x4 hw[NT][4];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    hh[s] = *reinterpret_cast<const u32x4 *>(lds_head + ((s * 2 + 0) * 64 + lane) * 4);
-    hl[s] = *reinterpret_cast<const u32x4 *>(lds_head + ((s * 2 + 1) * 64 + lane) * 4);
-  }
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) hw[t][s] = *reinterpret_cast<const u32x4 *>(lds_head + ((s * NT + t) * 64 + lane) * 4);
 #pragma unroll
   for (int np = 0; np < NP; ++np) {
     f32x16 h1;
@@ -707,16 +735,19 @@ __global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_x3_t(Rc3Params Q) 
     for (int i = 0; i < 16; ++i) h1[i] = 0.0f;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      u32x4 bh, bl;
+      bf16x8 B[NT];
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        bh[m] = ph[np][s][m];
-        bl[m] = pl[np][s][m];
+      for (int t = 0; t < NT; ++t) {
+        u32x4 bw;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) bw[m] = pk[t][np][s][m];
+        B[t] = __builtin_bit_cast(bf16x8, bw);
       }
-      const bf16x8 Bh = __builtin_bit_cast(bf16x8, bh), Bl = __builtin_bit_cast(bf16x8, bl);
-      h1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, hh[s]), Bh, h1, 0, 0, 0);
-      h1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, hh[s]), Bl, h1, 0, 0, 0);
-      h1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, hl[s]), Bh, h1, 0, 0, 0);
+#pragma unroll
+      for (int sum = 0; sum < NT; ++sum)
+#pragma unroll
+        for (int i = 0; i <= sum; ++i)
+          h1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, hw[i][s]), B[sum - i], h1, 0, 0, 0);
     }
     const float4 b4 = *reinterpret_cast<const float4 *>(P.head_epi + 4 * h);
     const float4 a4 = *reinterpret_cast<const float4 *>(P.head_epi + 16 + 4 * h);
@@ -738,11 +769,11 @@ __global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_x3_t(Rc3Params Q) 
   __syncthreads();
   /* 16 NP positions = NP column tiles: waves 0 (, 1) run their policy heads, waves 2 (, 3) their
    * value heads */
-  const float *lds_dense = reinterpret_cast<const float *>(lds_head + 2048);
+  const float *lds_dense = reinterpret_cast<const float *>(lds_head + RCS_FRAG1_WORDS(NT));
   if (wave < NP)
-    rc_dense_policy(P, lds_dense, &lds_feat[0][0][0] + wave * 16 * 96, rows, row0 + wave * 16, lane);
+    rc_dense_policy(P, lds_dense, lds_feat + wave * 16 * 96, rows, row0 + wave * 16, lane);
   else if (wave >= 2 && wave < 2 + NP)
-    rc_dense_value(P, lds_dense + 6144, lds_dense + 6144 + 2048, &lds_feat[0][0][0] + (wave - 2) * 16 * 96, rows,
+    rc_dense_value(P, lds_dense + 6144, lds_dense + 6144 + 2048, lds_feat + (wave - 2) * 16 * 96, rows,
                    row0 + (wave - 2) * 16, lane);
   RC3_STAMP(5)
 #ifdef CO_PROF
@@ -753,10 +784,12 @@ __global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_x3_t(Rc3Params Q) 
 #endif
 }
 
-/* <2>: throughput kernel, batches of more than RC3_SMALL_ROWS rows, 32 positions per workgroup;
- * <1>: small-batch kernel, up to RC3_SMALL_ROWS rows, 16 positions per workgroup, one round */
-#define co_k_rescnn_forward_x3 co_k_rescnn_forward_x3_t<2>
-#define co_k_rescnn_forward_x3_small co_k_rescnn_forward_x3_t<1>
+/* NT = 2  <2>: throughput kernel, batches of more than RC3_SMALL_ROWS rows, 32 positions per workgroup;
+ *         <1>: small-batch kernel, up to RC3_SMALL_ROWS rows, 16 positions per workgroup, one round
+ * NT = 3  <1> only */
+#define co_k_rescnn_forward_x3 co_k_rescnn_forward_split_t<2, 2>
+#define co_k_rescnn_forward_x3_small co_k_rescnn_forward_split_t<1, 2>
+#define co_k_rescnn_forward_x6 co_k_rescnn_forward_split_t<1, 3>
 
 /* ------------------------------------------------------------------ host */
 struct ResCnnNet : CoNet {
@@ -880,18 +913,30 @@ static inline float rc_bf16_to_f(uint16_t h) {
   memcpy(&f, &u, 4);
   return f;
 }
+/* v -> nt bf16 terms: bf16(v), bf16 of the remainder, ... (the device's rcs_split) */
+static inline void rc_bf16_terms(float v, int nt, uint16_t *t) {
+  for (int i = 0; i < nt; ++i) {
+    t[i] = rc_bf16_rne(v);
+    v = v - rc_bf16_to_f(t[i]);
+  }
+}
 
-struct ResCnnX3Net : ResCnnNet {
+/* the split-precision kernels: NT = 2 (bf16x3) or 3 (bf16x6, float32-equivalent) */
+struct ResCnnSplitNet : ResCnnNet {
+  int nt;
   uint32_t *d_trunk3 = nullptr;
   uint32_t *d_whead3 = nullptr;
-  ResCnnX3Net(const float *w, size_t max_rows, rt_stream_t s) : ResCnnNet(w, max_rows, s) {
-    std::vector<uint32_t> tr(RC3_TRUNK_WORDS, 0u);
+  uint32_t *d_epi3 = nullptr;
+  ResCnnSplitNet(const float *w, size_t max_rows, rt_stream_t s, int nterms) : ResCnnNet(w, max_rows, s), nt(nterms) {
+    const size_t stem_chunk = (size_t)512 * nt, conv_chunk = (size_t)2048 * nt;
+    std::vector<uint32_t> tr(9 * stem_chunk + 72 * conv_chunk, 0u);
     const float *p = w;
     size_t off = 0;
+    uint16_t tv[3];
     for (int cv = 0; cv < RC_NUM_CONVS; ++cv) {
       const int cin = cv == 0 ? 10 : 64;
       const int cs = cv == 0 ? 1 : 4;
-      const size_t chunk = cv == 0 ? RC3_STEM_CHUNK : RC3_CONV_CHUNK;
+      const size_t chunk = cv == 0 ? stem_chunk : conv_chunk;
       const float *K = p;
       for (int tap = 0; tap < 9; ++tap)
         for (int st = 0; st < cs; ++st)
@@ -904,21 +949,21 @@ struct ResCnnX3Net : ResCnnNet {
                   int ci = 32 * T + 4 * h + 8 * (2 * a + (j >> 2)) + (j & 3);
                   int co = 32 * to + i;
                   float v = ci < cin ? K[((size_t)tap * cin + ci) * 64 + co] : 0.0f;
-                  uint16_t hi = rc_bf16_rne(v);
-                  uint16_t lo = rc_bf16_rne(v - rc_bf16_to_f(hi));
+                  rc_bf16_terms(v, nt, tv);
                   size_t lane = 32 * h + i;
-                  size_t wh = off + (size_t)tap * chunk + ((((size_t)st * 2 + to) * 2 + 0) * 64 + lane) * 4 + j / 2;
-                  size_t wl = off + (size_t)tap * chunk + ((((size_t)st * 2 + to) * 2 + 1) * 64 + lane) * 4 + j / 2;
-                  tr[wh] |= (uint32_t)hi << (16 * (j & 1));
-                  tr[wl] |= (uint32_t)lo << (16 * (j & 1));
+                  for (int t = 0; t < nt; ++t) {
+                    size_t wd = off + (size_t)tap * chunk + ((((size_t)st * 2 + to) * nt + t) * 64 + lane) * 4 + j / 2;
+                    tr[wd] |= (uint32_t)tv[t] << (16 * (j & 1));
+                  }
                 }
       off += 9 * chunk;
       p += (size_t)9 * cin * 64 + 5 * 64;
     }
-    /* 1x1 head convolutions as hi/lo fragments of one more K loop (same k-slot order as the
+    /* 1x1 head convolutions as term fragments of one more K loop (same k-slot order as the
      * trunk): output row i = 0..3 policy planes, 4..5 value planes, the rest zero */
     const float *pk = p, *vk = pk + 64 * 4 + 4 * 5 + 64 * 96 + 96;
-    std::vector<uint32_t> wh3(4 * 2 * 64 * 4, 0u);
+    const size_t frag1 = (size_t)4 * nt * 256, head_words = frag1 + 6144 + 2048 + 1024;
+    std::vector<uint32_t> wh3(frag1, 0u);
     for (int st = 0; st < 4; ++st)
       for (int h = 0; h < 2; ++h)
         for (int i = 0; i < 32; ++i)
@@ -926,35 +971,40 @@ struct ResCnnX3Net : ResCnnNet {
             int T = st >> 1, a = st & 1;
             int k = 32 * T + 4 * h + 8 * (2 * a + (j >> 2)) + (j & 3);
             float v = i < 4 ? pk[k * 4 + i] : i < 6 ? vk[k * 2 + (i - 4)] : 0.0f;
-            uint16_t hi = rc_bf16_rne(v);
-            uint16_t lo = rc_bf16_rne(v - rc_bf16_to_f(hi));
+            rc_bf16_terms(v, nt, tv);
             size_t lane = 32 * h + i;
-            wh3[(((size_t)st * 2 + 0) * 64 + lane) * 4 + j / 2] |= (uint32_t)hi << (16 * (j & 1));
-            wh3[(((size_t)st * 2 + 1) * 64 + lane) * 4 + j / 2] |= (uint32_t)lo << (16 * (j & 1));
+            for (int t = 0; t < nt; ++t)
+              wh3[(((size_t)st * nt + t) * 64 + lane) * 4 + j / 2] |= (uint32_t)tv[t] << (16 * (j & 1));
           }
     rt_malloc((void **)&d_trunk3, tr.size() * 4);
     rt_h2d(d_trunk3, tr.data(), tr.size() * 4, s);
-    RT_CHECK(hipFuncSetAttribute((const void *)co_k_rescnn_forward_x3, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 RC3_LDS_BYTES));
-    RT_CHECK(hipFuncSetAttribute((const void *)co_k_rescnn_forward_x3_small, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 RC3_LDS_BYTES));
-    rt_malloc((void **)&d_whead3, (size_t)RC3_HEAD_WORDS * 4);
+    rt_malloc((void **)&d_whead3, head_words * 4);
     rt_h2d(d_whead3, wh3.data(), wh3.size() * 4, s);
-    rt_d2d(d_whead3 + 2048, P.wpol, 6144 * 4, s); /* the dense weights in the base class's MFMA order */
-    rt_d2d(d_whead3 + 2048 + 6144, P.wv1, 2048 * 4, s);
-    rt_d2d(d_whead3 + 2048 + 6144 + 2048, P.wv2, 1024 * 4, s);
-    rt_d2d(d_whead3 + 2048 + 6144 + 2048 + 1024, P.epi, (size_t)RC_NUM_CONVS * 192 * 4, s);
+    rt_d2d(d_whead3 + frag1, P.wpol, 6144 * 4, s); /* the dense weights in the base class's MFMA order */
+    rt_d2d(d_whead3 + frag1 + 6144, P.wv1, 2048 * 4, s);
+    rt_d2d(d_whead3 + frag1 + 6144 + 2048, P.wv2, 1024 * 4, s);
+    rt_malloc((void **)&d_epi3, (size_t)RC3_EPI_WORDS * 4); /* zero-filled: the padding is staged too */
+    rt_d2d(d_epi3, P.epi, (size_t)RC_NUM_CONVS * 192 * 4, s);
+    if (nt == 2) {
+      RT_CHECK(hipFuncSetAttribute((const void *)co_k_rescnn_forward_x3, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   RCS_LDS_WORDS(2, 2) * 4));
+      RT_CHECK(hipFuncSetAttribute((const void *)co_k_rescnn_forward_x3_small, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   RCS_LDS_WORDS(2, 1) * 4));
+    } else {
+      RT_CHECK(hipFuncSetAttribute((const void *)co_k_rescnn_forward_x6, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   RCS_LDS_WORDS(3, 1) * 4));
+    }
     rt_sync(s);
   }
-  ~ResCnnX3Net() override {
+  ~ResCnnSplitNet() override {
     rt_free(d_trunk3);
     rt_free(d_whead3);
+    rt_free(d_epi3);
   }
-  int kind() const override { return CO_NET_RESCNN4_X3; }
+  int kind() const override { return nt == 2 ? CO_NET_RESCNN4_X3 : CO_NET_RESCNN4_X6; }
   void forward(const float *d_in, int32_t rows_cap, const int32_t *d_rows, float *d_eval, float *d_probs,
                rt_stream_t s) override {
-    int grid = (rows_cap + 31) / 32;
-    if (grid < 1) return;
+    if (rows_cap < 1) return;
     Rc3Params q;
     q.base = P;
     q.base.in = d_in;
@@ -963,11 +1013,17 @@ struct ResCnnX3Net : ResCnnNet {
     q.base.probs = d_probs;
     q.wtrunk = d_trunk3;
     q.whead3 = d_whead3;
-    /* both kernels are queued; the row count on the device decides which one works (the other's
-     * workgroups return at once).  Batches that can exceed RC3_SMALL_ROWS need the throughput kernel. */
-    const int small_rows = rows_cap < RC3_SMALL_ROWS ? rows_cap : RC3_SMALL_ROWS;
-    hipLaunchKernelGGL(co_k_rescnn_forward_x3_small, dim3((small_rows + 15) / 16), dim3(512), RC3_LDS_BYTES, s, q);
-    if (rows_cap > RC3_SMALL_ROWS) hipLaunchKernelGGL(co_k_rescnn_forward_x3, dim3(grid), dim3(512), RC3_LDS_BYTES, s, q);
+    q.epi3 = d_epi3;
+    if (nt == 2) {
+      /* both kernels are queued; the row count on the device decides which one works (the other's
+       * workgroups return at once).  Batches that can exceed RC3_SMALL_ROWS need the throughput kernel. */
+      const int small_rows = rows_cap < RC3_SMALL_ROWS ? rows_cap : RC3_SMALL_ROWS;
+      hipLaunchKernelGGL(co_k_rescnn_forward_x3_small, dim3((small_rows + 15) / 16), dim3(512), RCS_LDS_WORDS(2, 1) * 4, s, q);
+      if (rows_cap > RC3_SMALL_ROWS)
+        hipLaunchKernelGGL(co_k_rescnn_forward_x3, dim3((rows_cap + 31) / 32), dim3(512), RCS_LDS_WORDS(2, 2) * 4, s, q);
+    } else {
+      hipLaunchKernelGGL(co_k_rescnn_forward_x6, dim3((rows_cap + 15) / 16), dim3(512), RCS_LDS_WORDS(3, 1) * 4, s, q);
+    }
     RT_CHECK(hipGetLastError());
   }
 };
@@ -977,7 +1033,7 @@ CoNet *co_rescnn_create(const float *weights, size_t n_floats, size_t max_rows, 
   return new ResCnnNet(weights, max_rows, s);
 }
 
-CoNet *co_rescnn_x3_create(const float *weights, size_t n_floats, size_t max_rows, rt_stream_t s) {
-  if (n_floats != (size_t)RC_NUM_WEIGHTS) return nullptr;
-  return new ResCnnX3Net(weights, max_rows, s);
+CoNet *co_rescnn_split_create(const float *weights, size_t n_floats, size_t max_rows, rt_stream_t s, int nterms) {
+  if (n_floats != (size_t)RC_NUM_WEIGHTS || (nterms != 2 && nterms != 3)) return nullptr;
+  return new ResCnnSplitNet(weights, max_rows, s, nterms);
 }

@@ -27,6 +27,8 @@ NET_MLP12X100 = 1
 NET_RESCNN4 = 2
 NET_RESCNN4_X3 = 3
 NET_MLP12X100_X3 = 4
+NET_RESCNN4_X6 = 5    # float32-equivalent: three bf16 terms per operand, six MFMA products
+NET_MLP12X100_X6 = 6
 
 
 def _f32(a, what):

@@ -106,6 +106,12 @@ int ca_trainer_do_iteration(ca_trainer *t, const float *evaluations, const float
 #define CA_NET_RESCNN4_X3 3 /* the same network and weights; 3x3 convolutions at bf16x3 split precision
                               (bf16 MFMA, fp32 accumulate; within 2e-5 of the fp32 result) */
 #define CA_NET_MLP12X100_X3 4 /* the reference architecture and weights; dense layers at bf16x3 split precision */
+/* float32-equivalent arithmetic on the bf16 matrix pipe ("bf16x6"): both operands of every matrix product as
+ * THREE bf16 terms whose sum is the float32 value, the six products down to 2^-16 of the leading one kept (the
+ * dropped ones are below one float32 rounding of the product), fp32 accumulation.  Error against a float64
+ * evaluation = that of the fp32-MFMA kinds 1 and 2 (tests/test_net_precision.py). */
+#define CA_NET_RESCNN4_X6 5
+#define CA_NET_MLP12X100_X6 6
 /* slot 0 = best model (training, and arena `to_play == 1`), slot 1 = new model (arena
  * `to_play == 0`), as get_predictions chooses them (main.pyx:70-83) */
 int ca_trainer_set_net(ca_trainer *t, int slot, int kind, const float *weights, size_t n_floats);

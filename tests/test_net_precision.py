@@ -1,0 +1,108 @@
+"""Precision of the network kernels against a float64 evaluation of the same float32 weights.
+
+The reference evaluates its network in float32 (Keras / TFLite, main.pyx:70-83).  The engine has
+three arithmetic widths per architecture:
+  * fp32 MFMA (kinds 1, 2): a k-ordered float32 fma chain -- float32 by construction;
+  * "bf16x6" (kinds 5, 6): both operands of every product as three bf16 terms whose sum IS the
+    float32 value, six MFMA products (everything above 2^-24 of a product), fp32 accumulation --
+    claimed float32-equivalent;
+  * "bf16x3" (kinds 3, 4): two terms, three products: 16 significand bits, narrower than float32.
+The claim of the second line is tested here: on random-init weights, on weights with BatchNorm
+noise and on trained-scale synthetic weights (kernels x 4, BatchNorm variances 0.1 .. 10, logits
+several units wide), the bf16x6 kernels' error against float64 is no larger than twice the fp32-MFMA
+kernel's own error (it is about equal or smaller: one accumulator rounding per 16 products instead
+of one per product), while bf16x3 sits one to two orders of magnitude above both.
+"""
+import numpy as np
+import pytest
+
+from corintho_ai_amd import (NET_MLP12X100, NET_MLP12X100_X3, NET_MLP12X100_X6, NET_RESCNN4, NET_RESCNN4_X3,
+                             NET_RESCNN4_X6, nets)
+from oracle import oracle as O
+from tests import harness as H
+from tests.engines import make_trainer
+
+pytestmark = pytest.mark.gpu
+
+
+def _states(n, seed):
+    rng = np.random.default_rng(seed)
+    s = np.zeros((n, 70), np.float32)
+    s[:, :64] = rng.integers(0, 2, (n, 64))
+    s[:, 64:] = rng.integers(0, 5, (n, 6)) * 0.25
+    return s
+
+
+def _errors(t, kind, w, states, want):
+    t.set_net(kind, w)
+    ev, pr = t.net_forward(states)
+    return float(np.max(np.abs(ev.astype(np.float64) - want[0]))), float(np.max(np.abs(pr.astype(np.float64) - want[1])))
+
+
+CNN_SETS = [("init", lambda: nets.init_rescnn4(0)), ("bn-noise", lambda: nets.init_rescnn4(3, bn_noise=True)),
+            ("trained-like-0", lambda: nets.trained_like_rescnn4(0)), ("trained-like-1", lambda: nets.trained_like_rescnn4(1))]
+MLP_SETS = [("init", lambda: nets.init_mlp12x100(0)), ("bn-noise", lambda: nets.init_mlp12x100(7, bn_noise=True)),
+            ("trained-like-0", lambda: nets.trained_like_mlp12x100(0)), ("trained-like-1", lambda: nets.trained_like_mlp12x100(1))]
+
+
+def _check(kinds, sets, f64, label, floor):
+    t = make_trainer("hip", 64, "", 1, 50, 16, 1.0, 0.25, 0, 1, False)
+    states = _states(777, 5)
+    rows = []
+    for name, make in sets:
+        w = make()
+        want = f64(w, states)
+        e32 = _errors(t, kinds[0], w, states, want)
+        e6 = _errors(t, kinds[1], w, states, want)
+        e3 = _errors(t, kinds[2], w, states, want)
+        rows.append((name, e32, e6, e3))
+        print("%s %-15s |err| vs float64  value: fp32 %.2e  bf16x6 %.2e  bf16x3 %.2e   policy: fp32 %.2e  bf16x6 %.2e  bf16x3 %.2e"
+              % (label, name, e32[0], e6[0], e3[0], e32[1], e6[1], e3[1]))
+        # float32-equivalence: no worse than twice the fp32-MFMA kernel (floor: a few float32 ulps of
+        # the output, below which the final tanh / softmax roundings decide)
+        assert e6[0] <= 2.0 * e32[0] + floor, (name, e6, e32)
+        assert e6[1] <= 2.0 * e32[1] + floor, (name, e6, e32)
+        # and inside the north-star contract by a wide margin
+        assert e6[0] < 1e-5 and e6[1] < 1e-5
+        assert e3[0] < 1e-4 and e3[1] < 1e-4
+    return rows
+
+
+def test_rescnn4_bf16x6_is_float32_equivalent():
+    _check((NET_RESCNN4, NET_RESCNN4_X6, NET_RESCNN4_X3), CNN_SETS, nets.rescnn4_forward_f64, "rescnn4", 2.4e-7)
+
+
+def test_mlp12x100_bf16x6_is_float32_equivalent():
+    _check((NET_MLP12X100, NET_MLP12X100_X6, NET_MLP12X100_X3), MLP_SETS, nets.mlp12x100_forward_f64, "mlp12x100", 2.4e-7)
+
+
+@pytest.mark.parametrize("kind,make", [(NET_RESCNN4_X6, lambda: nets.trained_like_rescnn4(2)),
+                                       (NET_MLP12X100_X6, lambda: nets.trained_like_mlp12x100(2))],
+                         ids=["rescnn4x6", "mlp12x100x6"])
+def test_bf16x6_rows_do_not_depend_on_their_batch(kind, make):
+    """SURVEY 8e invariant: a row's outputs are a function of the row only (fixed k order, no
+    batch-dependent tiling), for every batch size around the kernels' tile boundaries"""
+    t = make_trainer("hip", 64, "", 1, 50, 16, 1.0, 0.25, 0, 1, False)
+    t.set_net(kind, make())
+    states = _states(1024, 9)
+    ev, pr = t.net_forward(states)
+    assert np.all(np.abs(pr.sum(axis=1) - 1) < 1e-5)
+    for lo, hi in ((0, 1), (5, 6), (0, 15), (0, 16), (0, 17), (100, 131), (100, 228), (0, 129), (300, 1024)):
+        e1, p1 = t.net_forward(states[lo:hi])
+        assert np.array_equal(e1, ev[lo:hi]) and np.array_equal(p1, pr[lo:hi]), (lo, hi)
+
+
+@pytest.mark.parametrize("kind,make", [(NET_RESCNN4_X6, lambda: nets.init_rescnn4(0, bn_noise=True)),
+                                       (NET_MLP12X100_X6, lambda: nets.init_mlp12x100(2, bn_noise=True))],
+                         ids=["rescnn4x6", "mlp12x100x6"])
+def test_fused_bf16x6_generation_replays_on_the_oracle(kind, make):
+    G, S_, spe = 24, 40, 8
+    f = make_trainer("hip", G, "", 33, S_, spe, 1.0, 0.25, 0, 1, False, stagger=False)
+    f.set_net(kind, make())
+    assert f.run()
+    o = O.Trainer(G, seed=33, max_searches=S_, searches_per_eval=spe)
+    o.set_stagger(False)
+    H.play_generation(o, G, spe, lambda s: f.net_forward(s))
+    for x, y in zip(H.get_samples(f), H.get_samples(o)):
+        assert x.tobytes() == y.tobytes()
+    assert f.score() == o.score()

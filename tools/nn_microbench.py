@@ -25,12 +25,12 @@ if flags:
     L = _lib.declare(C.CDLL(out))
 G = (rows + 15) // 16
 t = Trainer(G, "", 1, 50, 16, 1.0, 0.25, 0, 1, False, _cdll=L)
-w = nets.init_mlp12x100(0) if kind in (1, 4) else nets.init_rescnn4(0)
+w = nets.init_mlp12x100(0) if kind in (1, 4, 6) else nets.init_rescnn4(0)
 t.set_net(kind, w)
 rng = np.random.default_rng(0)
 s = np.zeros((rows, 70), np.float32)
 s[:, :64] = rng.integers(0, 2, (rows, 64))
 s[:, 64:] = rng.integers(0, 5, (rows, 6)) * 0.25
 ms = t.net_bench(s, reps=20)
-flop = (nets.rescnn4_flop_per_row() if kind not in (1, 4) else 253400.0) * rows
+flop = (nets.rescnn4_flop_per_row() if kind not in (1, 4, 6) else 253400.0) * rows
 print("kind %d rows %d flags %s: %.3f ms per launch, %.1f TFLOP/s algorithmic" % (kind, rows, flags, ms, flop / ms / 1e9))
