@@ -1126,15 +1126,29 @@ struct co_trainer {
   int max_searches, searches_per_eval, num_threads;
   int searches_done;
   int stagger;
+  /* a SLICE of a larger Trainer (test convenience, no reference counterpart): games
+   * [game_base, game_base + num_games) of a Trainer of total_games games -- seeds, parity, colour in
+   * score() and the stagger rule follow the GLOBAL game index, so the slice plays exactly the games
+   * the full Trainer would (games are independent, trainer.cpp:243-255) */
+  int game_base, total_games;
   co_mt19937 generator;
 };
 
 /* ref: trainer.cpp:18-37, 238-256 */
 co_trainer *co_trainer_create(int num_games, int seed, int max_searches, int searches_per_eval, float c_puct,
                               float epsilon, int num_threads, int testing) {
-  if (num_games <= 0 || max_searches <= 0 || searches_per_eval <= 0) return NULL;
+  return co_trainer_create_slice(num_games, 0, num_games, seed, max_searches, searches_per_eval, c_puct, epsilon,
+                                 num_threads, testing);
+}
+
+co_trainer *co_trainer_create_slice(int total_games, int first, int num_games, int seed, int max_searches,
+                                    int searches_per_eval, float c_puct, float epsilon, int num_threads, int testing) {
+  if (num_games <= 0 || max_searches <= 0 || searches_per_eval <= 0 || first < 0 || first + num_games > total_games)
+    return NULL;
   co_trainer *t = (co_trainer *)calloc(1, sizeof *t);
   t->num_games = num_games;
+  t->game_base = first;
+  t->total_games = total_games;
   t->max_searches = max_searches;
   t->searches_per_eval = searches_per_eval;
   t->num_threads = num_threads > 0 ? num_threads : 1;
@@ -1142,8 +1156,10 @@ co_trainer *co_trainer_create(int num_games, int seed, int max_searches, int sea
   mt_seed(&t->generator, (uint32_t)seed);
   t->games = (selfplayer_t *)calloc((size_t)num_games, sizeof(selfplayer_t));
   t->is_done = (uint8_t *)calloc((size_t)num_games, 1);
+  for (int i = 0; i < first; ++i) (void)mt_next(&t->generator); /* the seeds of the games before the slice */
   for (int i = 0; i < num_games; ++i)
-    sp_init(&t->games[i], mt_next(&t->generator), max_searches, searches_per_eval, c_puct, epsilon, testing, i % 2);
+    sp_init(&t->games[i], mt_next(&t->generator), max_searches, searches_per_eval, c_puct, epsilon, testing,
+            (first + i) % 2);
   return t;
 }
 
@@ -1179,9 +1195,39 @@ int co_trainer_num_samples(const co_trainer *t) {
 /* ref: trainer.cpp:59-68 */
 float co_trainer_score(const co_trainer *t) {
   float score = 0;
-  for (int i = 0; i < t->num_games; i += 2) score += sp_score(&t->games[i]);
-  for (int i = 1; i < t->num_games; i += 2) score = (float)((double)score + (1.0 - (double)sp_score(&t->games[i])));
+  const int b = t->game_base & 1; /* local index of the first game with an even global index */
+  for (int i = b; i < t->num_games; i += 2) score += sp_score(&t->games[i]);
+  for (int i = 1 - b; i < t->num_games; i += 2) score = (float)((double)score + (1.0 - (double)sp_score(&t->games[i])));
   return score / (float)(size_t)t->num_games;
+}
+
+/* ref: trainer.cpp:115-162.  `file << float` prints like "%g". */
+int co_trainer_write_scores(const co_trainer *t, const char *filename) {
+  size_t n = (size_t)t->num_games;
+  float *scores = (float *)calloc(n ? n : 1, sizeof(float));
+  for (size_t i = 0; i < n; i += 2) scores[i] = sp_score(&t->games[i]);
+  for (size_t i = 1; i < n; i += 2) scores[i] = (float)(1.0 - (double)sp_score(&t->games[i]));
+  FILE *f = fopen(filename, "w");
+  if (!f) {
+    free(scores);
+    return 0;
+  }
+  static const char *who[2] = {"First", "Second"};
+  for (int side = 0; side < 2; ++side) {
+    int32_t wins = 0, draws = 0;
+    for (size_t i = (size_t)side; i < n; i += 2) {
+      if (scores[i] == 1.0) ++wins;
+      else if (scores[i] == 0.5) ++draws;
+    }
+    size_t half = n / 2;
+    fprintf(f, "%s player wins: %d / %zu = %g\n", who[side], wins, half, (double)((float)wins / (float)half));
+    fprintf(f, "%s player draws: %d / %zu = %g\n", who[side], draws, half, (double)((float)draws / (float)half));
+    fprintf(f, "%s player losses: %zu / %zu = %g\n", who[side], half - (size_t)wins - (size_t)draws, half,
+            (double)((float)(half - (size_t)wins - (size_t)draws) / (float)half));
+  }
+  fclose(f);
+  free(scores);
+  return 1;
 }
 
 /* ref: trainer.cpp:70-77 */
@@ -1226,7 +1272,7 @@ int co_trainer_do_iteration(co_trainer *t, const float *eval, const float *probs
       offset += sp_num_requests(&t->games[i - 1]);
       offsets[i] = offset;
     }
-    size_t div = (size_t)G / (size_t)t->max_searches;
+    size_t div = (size_t)t->total_games / (size_t)t->max_searches;
     if (div < 1) div = 1;
 #ifdef _OPENMP
     omp_set_num_threads(t->num_threads);
@@ -1234,7 +1280,7 @@ int co_trainer_do_iteration(co_trainer *t, const float *eval, const float *probs
 #pragma omp parallel for schedule(dynamic, 1)
     for (int i = 0; i < G; ++i) {
       if (!t->is_done[i]) {
-        if (!t->stagger || (size_t)i / div <= (size_t)t->searches_done) {
+        if (!t->stagger || (size_t)(t->game_base + i) / div <= (size_t)t->searches_done) {
           int done = sp_do_iteration(&t->games[i], eval + offsets[i], probs + (size_t)CO_NUM_MOVES * offsets[i]);
           if (done) t->is_done[i] = 1;
         }

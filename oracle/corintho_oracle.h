@@ -64,6 +64,11 @@ typedef struct co_trainer co_trainer;
 co_trainer *co_trainer_create(int num_games, int seed, int max_searches,
                               int searches_per_eval, float c_puct,
                               float epsilon, int num_threads, int testing);
+/* games [first, first + num_games) of a Trainer of total_games games: same seeds (drawn in global
+ * index order, trainer.cpp:243-255), parity, colours and stagger rule as the full Trainer -- the
+ * slice the multi-GPU tests replay a shard on */
+co_trainer *co_trainer_create_slice(int total_games, int first, int num_games, int seed, int max_searches,
+                                    int searches_per_eval, float c_puct, float epsilon, int num_threads, int testing);
 void co_trainer_destroy(co_trainer *t);
 int co_trainer_num_requests(const co_trainer *t, int to_play);
 int co_trainer_num_samples(const co_trainer *t);
@@ -71,6 +76,8 @@ float co_trainer_score(const co_trainer *t);
 float co_trainer_avg_mate_length(const co_trainer *t);
 void co_trainer_write_requests(const co_trainer *t, float *game_states,
                                int to_play);
+/* Trainer::writeScores, trainer.cpp:115-162; returns 0 if the file cannot be opened */
+int co_trainer_write_scores(const co_trainer *t, const char *filename);
 void co_trainer_write_samples(const co_trainer *t, float *game_states,
                               float *eval_samples, float *prob_samples);
 int co_trainer_do_iteration(co_trainer *t, const float *eval,

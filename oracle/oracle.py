@@ -59,6 +59,11 @@ def lib():
     L.co_mt_destroy.argtypes = [C.c_void_p]
     L.co_trainer_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int]
     L.co_trainer_create.restype = C.c_void_p
+    L.co_trainer_create_slice.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int,
+                                          C.c_int]
+    L.co_trainer_create_slice.restype = C.c_void_p
+    L.co_trainer_write_scores.argtypes = [C.c_void_p, C.c_char_p]
+    L.co_trainer_write_scores.restype = C.c_int
     L.co_trainer_destroy.argtypes = [C.c_void_p]
     L.co_trainer_num_requests.argtypes = [C.c_void_p, C.c_int]
     L.co_trainer_num_requests.restype = C.c_int
@@ -221,11 +226,13 @@ class Trainer:
     """Same surface as the reference Trainer (trainer.h:22-53, main.pyx:17-38)."""
 
     def __init__(self, num_games, log_folder="", seed=0, max_searches=1600, searches_per_eval=16, c_puct=1.0,
-                 epsilon=0.25, num_logged=0, num_threads=1, testing=False):
+                 epsilon=0.25, num_logged=0, num_threads=1, testing=False, *, game_base=0, total_games=0):
+        """game_base / total_games: games [game_base, game_base + num_games) of a Trainer of total_games
+        games (co_trainer_create_slice), for replaying one shard of a sharded generation"""
         self.num_games = num_games
         self.searches_per_eval = searches_per_eval
-        self._t = lib().co_trainer_create(num_games, seed, max_searches, searches_per_eval, c_puct, epsilon,
-                                          num_threads, int(bool(testing)))
+        self._t = lib().co_trainer_create_slice(total_games or num_games, game_base, num_games, seed, max_searches,
+                                                searches_per_eval, c_puct, epsilon, num_threads, int(bool(testing)))
         if not self._t:
             raise ValueError("bad Trainer arguments")
 
@@ -254,6 +261,10 @@ class Trainer:
 
     def writeRequests(self, game_states, to_play=-1):
         lib().co_trainer_write_requests(self._t, _f32(game_states), to_play)
+
+    def writeScores(self, filename):
+        if not lib().co_trainer_write_scores(self._t, filename.encode() if isinstance(filename, str) else filename):
+            raise OSError("cannot open %r" % filename)
 
     def writeSamples(self, game_states, eval_samples, prob_samples):
         lib().co_trainer_write_samples(self._t, _f32(game_states), _f32(eval_samples), _f32(prob_samples))

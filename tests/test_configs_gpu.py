@@ -1,0 +1,126 @@
+"""BASELINE.json configs 3, 4 and 5 at FULL size on one MI355X (configs[1] is
+tests/test_engine_parity.py::test_full_size_generation_properties).  Too big for the oracle as a
+whole, so each is checked through size-independent properties plus an oracle replay of its first
+32 games, fed by the same device network, bit for bit.
+
+  cfg3  32 768 games sharded over 8 GPUs: ONE shard of it on this GPU -- rank 7 of 8, games
+        [28 672, 32 768), seeds / parity / colours on the global index (trainer.cpp:243-255)
+  cfg4  4096 games, 1600 sims/move, Dirichlet noise 0.25 (toml/train.toml:2-18: the reference's
+        production setting): deep trees, the search-tree arena's high-water mark
+  cfg5  arena: 1024 two-model games, testing = true, 400 sims/move, fused on the device
+"""
+import numpy as np
+import pytest
+
+from corintho_ai_amd import NET_RESCNN4_X6, nets
+from oracle import oracle as O
+from tests import harness as H
+from tests.engines import make_trainer
+
+pytestmark = pytest.mark.gpu
+
+NREPLAY = 32
+
+
+def _replay_first_games(t, G_total, base, sims, spe, seed, n=NREPLAY, eps=0.25):
+    """games [base, base + n) on the CPU oracle (a slice of a Trainer of G_total games), evaluated by
+    the device network of trainer `t`; -> the oracle trainer"""
+    o = O.Trainer(n, seed=seed, max_searches=sims, searches_per_eval=spe, epsilon=eps, num_threads=16, game_base=base,
+                  total_games=G_total)
+    o.set_stagger(False)
+    H.play_generation(o, n, spe, lambda st: t.net_forward(st))
+    return o
+
+
+def _check_training_generation(t, G):
+    infos = [t.game_info(g) for g in range(0, G, 61)]
+    assert all(i["done"] == 1 and i["error"] == 0 and 0 < i["n_samples"] <= 40 for i in infos)
+    gs, ev, pr = H.get_samples(t)
+    n = t.num_samples()
+    assert gs.shape == (n * 8, 70) and 12 * G < n < 24 * G
+    H.check_sample_properties(gs, ev, pr)
+    assert 0.0 <= t.score() <= 1.0
+    return gs, ev, pr
+
+
+def test_cfg3_one_shard_of_the_32768_game_generation():
+    G, TOTAL, BASE, S_, spe, seed = 4096, 32768, 28672, 400, 16, 12345
+    w = nets.init_rescnn4(0)
+    t = make_trainer("hip", G, "", seed, S_, spe, 1.0, 0.25, 0, 1, False, stagger=False, game_base=BASE, total_games=TOTAL)
+    t.set_net(NET_RESCNN4_X6, w)
+    assert t.run()
+    _check_training_generation(t, G)
+    sp_all, oc_all = t.export_samples()
+    counts = [t.game_info(g)["n_samples"] for g in range(NREPLAY)]
+    m = sum(counts)
+    o = _replay_first_games(t, TOTAL, BASE, S_, spe, seed)
+    ogs, oev, opr = H.get_samples(o)
+    assert ogs.shape[0] == m * 8
+    assert ogs[0::8].tobytes() == sp_all[:m, :70].tobytes()
+    assert opr[0::8].tobytes() == sp_all[:m, 70:].tobytes()
+    assert oev[0::8].tobytes() == oc_all[:m].tobytes()
+    for g in range(NREPLAY):
+        assert t.game_info(g)["result"] == o.game_result(g)
+    # the shard's seeds are those of the global indices: the same 32 local games of shard 0 differ
+    t0 = make_trainer("hip", NREPLAY, "", seed, S_, spe, 1.0, 0.25, 0, 1, False, stagger=False, game_base=0, total_games=TOTAL)
+    t0.set_net(NET_RESCNN4_X6, w)
+    assert t0.run()
+    assert t0.export_samples()[0].tobytes() != sp_all[:m].tobytes()
+
+
+def test_cfg4_1600_simulations_with_dirichlet_noise():
+    G, S_, spe, seed = 4096, 1600, 16, 12345
+    w = nets.init_rescnn4(0)
+    t = make_trainer("hip", G, "", seed, S_, spe, 1.0, 0.25, 0, 1, False, stagger=False)
+    t.set_net(NET_RESCNN4_X6, w)
+    assert t.run()
+    _check_training_generation(t, G)
+    st = t.stats()
+    # deep-tree stress: the arena's high-water mark stays below the default capacity
+    # ((1600 * 14 + 64) * 40 units per tree, engine.hip init) -- an overflow would have raised
+    cap = (S_ * 14 + 64) * 40
+    assert 0 < st["peak_arena_units"] < cap, st["peak_arena_units"]
+    assert st["searches"] > G * S_ * 8  # ~18 plies per game; tree reuse and solved roots make a ply cheaper than 1600 new simulations
+    sp_all, oc_all = t.export_samples()
+    m = sum(t.game_info(g)["n_samples"] for g in range(NREPLAY))
+    o = _replay_first_games(t, G, 0, S_, spe, seed)
+    ogs, oev, opr = H.get_samples(o)
+    assert ogs.shape[0] == m * 8
+    assert ogs[0::8].tobytes() == sp_all[:m, :70].tobytes()
+    assert opr[0::8].tobytes() == sp_all[:m, 70:].tobytes()
+    assert oev[0::8].tobytes() == oc_all[:m].tobytes()
+    print("cfg4: peak arena units per tree %d of %d; %.1f plies, %.0f evaluations per game"
+          % (st["peak_arena_units"], cap, st["plies"] / G, st["evals"] / G))
+
+
+def test_cfg5_arena_1024_two_model_games():
+    G, S_, spe, seed = 1024, 400, 16, 77
+    wa, wb = nets.init_rescnn4(0), nets.init_rescnn4(1)
+    t = make_trainer("hip", G, "", seed, S_, spe, 1.0, 0.25, 0, 1, True, trace=True)
+    t.set_net(NET_RESCNN4_X6, wa, slot=0)  # best model
+    t.set_net(NET_RESCNN4_X6, wb, slot=1)  # new model
+    assert t.run()
+    infos = [t.game_info(g) for g in range(G)]
+    assert all(i["done"] == 1 and i["error"] == 0 for i in infos)
+    assert all(i["result"] in (1, 2, 3) for i in infos)  # loss / draw / win of the first player (util.h:57-64)
+    assert t.num_samples() == 0  # testing_ disables samples (trainmc.cpp:114)
+    s = t.score()
+    assert 0.0 <= s <= 1.0
+    # score = mean over games of the new model's result, colours alternating with the game index
+    # (trainer.cpp:59-68): recompute it from the per-game results
+    pts = {1: 0.0, 2: 0.5, 3: 1.0}
+    mine = sum(pts[i["result"]] if g % 2 == 0 else 1.0 - pts[i["result"]] for g, i in enumerate(infos)) / G
+    assert abs(mine - s) < 1e-5
+    # ALL 1024 games on the oracle, driven by the reference loop (main.pyx:142-168) with the two device networks.
+    # (A subset cannot be replayed in arena mode: when a model's batch comes back empty the loop flips to_play and
+    # calls doIteration with the arrays of the LAST prediction (main.pyx:150-154), so the first evaluations a side
+    # consumes after a hand-over are whatever lies at its offset -- rows of other games.  The engine reproduces
+    # that; a game's trajectory therefore depends on the whole batch.  DESIGN.md, quirk 12.)
+    o = O.Trainer(G, seed=seed, max_searches=S_, searches_per_eval=spe, testing=True, num_threads=16)
+    o.enable_trace()
+    nets2 = (lambda st: t.net_forward(st, slot=1), lambda st: t.net_forward(st, slot=0))  # to_play 0 -> new model
+    H.play_generation(o, G, spe, None, nets_by_player=nets2)
+    for g in range(G):
+        assert np.array_equal(t.trace(g), o.trace(g)), "game %d" % g
+        assert infos[g]["result"] == o.game_result(g)
+    assert t.score() == o.score()

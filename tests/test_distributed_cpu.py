@@ -29,11 +29,11 @@ t.set_net(1, nets.init_mlp12x100(0, bn_noise=True))
 assert t.run()
 g = SampleGather(t, G, on_device=False)
 sp, oc = g.rows()
-score = torch.tensor([t.score() * G], dtype=torch.float64)
-dist.all_reduce(score)
+score, unfinished = g.score_and_unfinished(True)   # C2: one all-reduce of two scalars
+assert unfinished == 0
 if rank == 0:
     gs, ev, pr = expand_samples(sp, oc, _cdll=L)
-    np.savez(%(out)r, gs=gs, ev=ev, pr=pr, score=score.item() / (G * world))
+    np.savez(%(out)r, gs=gs, ev=ev, pr=pr, score=score, moved=g.bytes_moved, rows=sp.shape[0])
 dist.destroy_process_group()
 """
 
@@ -60,3 +60,5 @@ def test_two_rank_sharded_generation_matches_single_trainer(tmp_path):
     assert got["ev"].tobytes() == ev.tobytes()
     assert got["pr"].tobytes() == pr.tobytes()
     assert abs(float(got["score"]) - t.score()) < 1e-6
+    # the payload all-gather is sized by the largest shard, not by the 44-ply upper bound
+    assert int(got["moved"]) < 2 * int(got["rows"]) * 167 * 4 * 1.5

@@ -255,6 +255,48 @@ def test_arena_mode_matches_oracle(engine):
 
 
 @pytest.mark.parametrize("engine", ENGINES)
+@pytest.mark.parametrize("testing", [False, True], ids=["train", "arena"])
+def test_write_scores_file_matches_oracle(engine, testing, tmp_path):
+    """Trainer::writeScores (trainer.cpp:115-162): the six-line win/draw/loss summary, byte for byte"""
+    G, S_, spe = 14, 24, 8
+    t = make_trainer(engine, G, "", 21, S_, spe, 1.0, 0.25, 0, 1, testing)
+    o = O.Trainer(G, seed=21, max_searches=S_, searches_per_eval=spe, testing=testing)
+    for tr in (t, o):
+        if testing:
+            H.play_generation(tr, G, spe, None, nets_by_player=(lambda s: H.hash_net(s, 1), lambda s: H.hash_net(s, 2)))
+        else:
+            H.play_generation(tr, G, spe, H.hash_net)
+    fa, fb = str(tmp_path / "engine.txt"), str(tmp_path / "oracle.txt")
+    t.writeScores(fa)
+    o.writeScores(fb)
+    a, b = open(fa, "rb").read(), open(fb, "rb").read()
+    assert a == b
+    assert a.count(b"\n") == 6 and a.startswith(b"First player wins: ") and b"Second player losses: " in a
+    assert t.score() == o.score()
+
+
+def test_oracle_slice_equals_the_full_trainer():
+    """test infrastructure: games [5, 12) of an oracle Trainer(12) as a slice play the same games
+    (the GPU shard tests replay a shard of a 32768-game generation this way)"""
+    G, S_, spe = 12, 24, 8
+    for stagger in (False,):  # (a staggered slice has no request until its first game is released: the
+        # reference's play loop, main.pyx:161-163, would raise)
+        whole = O.Trainer(G, seed=77, max_searches=S_, searches_per_eval=spe)
+        whole.enable_trace()
+        whole.set_stagger(stagger)
+        H.play_generation(whole, G, spe, H.hash_net)
+        part = O.Trainer(7, seed=77, max_searches=S_, searches_per_eval=spe, game_base=5, total_games=G)
+        part.enable_trace()
+        part.set_stagger(stagger)
+        H.play_generation(part, 7, spe, H.hash_net)
+        for g in range(7):
+            assert np.array_equal(part.trace(g), whole.trace(5 + g))
+        n5 = sum(whole.game_num_samples(g) for g in range(5))
+        for x, y in zip(H.get_samples(part), H.get_samples(whole)):
+            assert x.tobytes() == y[n5 * 8:].tobytes()
+
+
+@pytest.mark.parametrize("engine", ENGINES)
 def test_sharded_trainers_equal_one_trainer(engine):
     """games [base, base+n) of a sharded generation replay the same games (seeds and
     colours follow the GLOBAL index, trainer.cpp:243-255)"""
