@@ -66,7 +66,7 @@ EXPORTS = [
     "ca_trainer_num_samples", "ca_trainer_score", "ca_trainer_avg_mate_length", "ca_trainer_write_requests",
     "ca_trainer_write_samples", "ca_trainer_write_scores", "ca_trainer_do_iteration", "ca_trainer_set_net",
     "ca_trainer_run", "ca_trainer_net_forward", "ca_trainer_net_bench", "ca_trainer_export_samples", "ca_trainer_pack_samples_device", "ca_trainer_reset", "ca_expand_samples", "ca_trainer_stats",
-    "ca_trainer_game_info", "ca_trainer_trace", "ca_rules_legal_moves", "ca_rules_do_move", "ca_rng_draw",
+    "ca_trainer_game_info", "ca_trainer_trace", "ca_trainer_prof", "ca_rules_legal_moves", "ca_rules_do_move", "ca_rng_draw",
     "ca_fp_probe",
     "ca_tourney_create", "ca_tourney_destroy", "ca_tourney_add_player", "ca_tourney_add_match", "ca_tourney_all_done",
     "ca_tourney_num_requests", "ca_tourney_write_requests", "ca_tourney_do_iteration", "ca_tourney_write_scores",
@@ -100,6 +100,7 @@ def declare(L):
     L.ca_trainer_stats.argtypes = [vp, C.POINTER(CaStats)]
     L.ca_trainer_game_info.argtypes = [vp, C.c_int, i32p]
     L.ca_trainer_trace.argtypes = [vp, C.c_int, i32p, C.c_int32, i32p]
+    L.ca_trainer_prof.argtypes = [vp, C.POINTER(C.c_ulonglong)]
     L.ca_rules_legal_moves.argtypes = [C.c_int, u64p, u32p, C.c_int32, u32p, i32p]
     L.ca_rules_do_move.argtypes = [C.c_int, u64p, u32p, i32p, C.c_int32, f32p]
     L.ca_rng_draw.argtypes = [C.c_int, C.c_uint32, C.c_int32, C.c_int32, u32p]

@@ -163,6 +163,9 @@ int ca_trainer_stats(ca_trainer *t, ca_stats *out);
 int ca_trainer_game_info(ca_trainer *t, int game, int32_t out[8]);
 /* per-ply trace of one game, same record format as the oracle's; returns words via *n */
 int ca_trainer_trace(ca_trainer *t, int game, int32_t *out, int32_t cap, int32_t *n);
+/* diagnostic builds of the library (-DCO_PROF) only: summed in-kernel cycle stamps of the search kernel
+ * (slots documented in csrc/mcts.h); the shipped build returns CA_ERR_STATE */
+int ca_trainer_prof(ca_trainer *t, unsigned long long out[36]);
 
 /* ---- Tourney: replaces `class Tourney` of corintho_ai/cpp/include/tourney.h:13-46
  * consumed by corintho_ai/rating/tourney.pyx:15-31.  One match = one slot of a device pool
