@@ -81,3 +81,9 @@ bool Trainer::run(int64_t max_iterations) {
   check(ca_trainer_run(impl_, max_iterations, &done));
   return done != 0;
 }
+
+bool Trainer::pinBuffer(void *p, size_t bytes) {
+  int32_t pinned = 0;
+  check(ca_trainer_pin_host(impl_, p, bytes, &pinned));
+  return pinned != 0;
+}

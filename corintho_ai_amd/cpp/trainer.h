@@ -40,6 +40,9 @@ class Trainer {
   // ---- additions (fused mode); not part of the reference interface ----
   void setNet(int32_t kind, const float *weights, size_t n_floats, int32_t slot = 0);
   bool run(int64_t max_iterations = 0);
+  // page-lock a caller array that is passed to every doIteration / writeRequests (main.pyx:132-134) so
+  // that its copies are direct DMA; it must outlive this object
+  bool pinBuffer(void *p, size_t bytes);
 
  private:
   ca_trainer *impl_{nullptr};

@@ -111,8 +111,15 @@ struct ca_trainer {
   DevBuf<uint4> arena;
   DevBuf<uint32_t> pend_leaf, pend_path, rng;
   DevBuf<int32_t> pend_depth, req_offset, trace, all_done;
-  DevBuf<float> req, nn_in, nn_eval, nn_probs, samples;
+  DevBuf<float> req, nn_in, nn_in70, nn_eval, nn_probs, samples;
   DevBuf<unsigned long long> row_counter, pack_counter, prof;
+  DevBuf<int32_t> ctl;
+  int32_t *h_ctl = nullptr; /* pinned: {batch rows, all done, any error, games not done} of the last scan */
+  /* buffers of the host-facing calls, kept (and grown on demand) instead of allocated per call */
+  DevBuf<int32_t> ws_off, fw_rows;
+  DevBuf<float> ws_gs, ws_ev, ws_pr, fw_in70, fw_in, fw_ev, fw_pr;
+  /* caller buffers page-locked for direct DMA (ca_trainer_pin_host) */
+  std::vector<std::pair<void *, size_t>> host_regs;
   /* host state */
   int64_t iterations = 0;
   int32_t trainer_iteration = 0; /* Trainer::searches_done_ (train mode only) */
@@ -152,7 +159,40 @@ struct ca_trainer {
   }
   ~ca_trainer() {
     free_pools();
+    for (auto &r : host_regs) rt_host_unregister(r.first);
+    rt_host_free(h_ctl);
     rt_stream_destroy(stream);
+  }
+
+  template <typename T>
+  static void ensure(DevBuf<T> &b, size_t count) {
+    if (b.n < count) b.alloc(count + count / 4);
+  }
+
+  /* Page-lock a caller buffer (the three arrays of main.pyx:132-134 live as long as the Trainer):
+   * copies from / to it are then direct DMA at PCIe speed instead of staged through the runtime's
+   * bounce buffers.  The buffer must stay allocated until it is unpinned or the trainer destroyed. */
+  bool pin_host(void *p, size_t bytes) {
+    for (auto &r : host_regs)
+      if (r.first == p) {
+        if (r.second >= bytes) return true;
+        rt_host_unregister(p);
+        r = host_regs.back();
+        host_regs.pop_back();
+        break;
+      }
+    if (!rt_host_register(p, bytes)) return false;
+    host_regs.emplace_back(p, bytes);
+    return true;
+  }
+  void unpin_host(void *p) {
+    for (size_t i = 0; i < host_regs.size(); ++i)
+      if (host_regs[i].first == p) {
+        rt_host_unregister(p);
+        host_regs[i] = host_regs.back();
+        host_regs.pop_back();
+        return;
+      }
   }
 
   void init(const ca_config &c) {
@@ -183,6 +223,9 @@ struct ca_trainer {
     req.alloc((size_t)G * spe * CO_STATE_STRIDE);
     req_offset.alloc((size_t)G + 1);
     nn_in.alloc((size_t)G * spe * CO_STATE_STRIDE);
+    nn_in70.alloc((size_t)G * spe * CO_GAME_STATE_SIZE);
+    ctl.alloc(4);
+    rt_host_alloc((void **)&h_ctl, 16);
     nn_eval.alloc((size_t)G * spe);
     nn_probs.alloc((size_t)G * spe * CO_NUM_MOVES);
     if (!cfg.testing) samples.alloc((size_t)G * CO_MAX_PLIES * CO_SAMPLE_FLOATS);
@@ -280,6 +323,8 @@ struct ca_trainer {
     P.nn_eval = nn_eval.p;
     P.nn_probs = nn_probs.p;
     P.nn_in = nn_in.p;
+    P.nn_in70 = nn_in70.p;
+    P.ctl = ctl.p;
     P.samples = samples.p;
     P.trace = trace.p;
     P.all_done = all_done.p;
@@ -298,18 +343,18 @@ struct ca_trainer {
 #endif
   }
 
-  /* offsets + compact batch for model `to_play` (K4) */
+  /* offsets + compact batch for model `to_play` (K4); ONE host synchronisation, on 16 bytes */
+  bool any_error = false;
   void pack(int to_play) {
     if (scan_valid && scan_valid_for == to_play) return;
     P.to_play = to_play;
     RT_LAUNCH(co_k_scan, 1, CO_WAVE, stream, P);
     RT_LAUNCH(co_k_compact, G, CO_WAVE, stream, P);
-    int32_t tot_done[2];
-    rt_d2h(&tot_done[0], req_offset.p + G, 4, stream);
-    rt_d2h(&tot_done[1], all_done.p, 4, stream);
+    rt_d2h(h_ctl, ctl.p, 16, stream);
     rt_sync(stream);
-    last_total = tot_done[0];
-    finished = tot_done[1] != 0;
+    last_total = h_ctl[0];
+    finished = h_ctl[1] != 0;
+    any_error = h_ctl[2] != 0;
     scan_valid_for = to_play;
     scan_valid = true;
   }
@@ -323,6 +368,7 @@ struct ca_trainer {
   }
 
   void check_errors() {
+    if (scan_valid && !any_error) return; /* the last scan saw no error bit in any game */
     fetch_games();
     for (int g = 0; g < G; ++g) {
       if (host_games[g].error) {
@@ -374,11 +420,9 @@ struct ca_trainer {
     if (to_play != 0 && to_play != 1) to_play = -1;
     pack(to_play);
     if (last_total == 0) return;
-    std::vector<float> tmp((size_t)last_total * CO_STATE_STRIDE);
-    rt_d2h(tmp.data(), nn_in.p, tmp.size() * 4, stream);
+    /* K4 has laid the rows out as the caller's array holds them: one copy, straight into it */
+    rt_d2h(out, nn_in70.p, (size_t)last_total * CO_GAME_STATE_SIZE * 4, stream);
     rt_sync(stream);
-    for (int r = 0; r < last_total; ++r)
-      memcpy(out + (size_t)r * CO_GAME_STATE_SIZE, &tmp[(size_t)r * CO_STATE_STRIDE], CO_GAME_STATE_SIZE * 4);
   }
 
   /* ---- Tourney (tourney.cpp) on the same pool: one match per game slot ---- */
@@ -389,11 +433,8 @@ struct ca_trainer {
   void tourney_write_requests(float *out, int id) {
     pack(id);
     if (last_total == 0) return;
-    std::vector<float> tmp((size_t)last_total * CO_STATE_STRIDE);
-    rt_d2h(tmp.data(), nn_in.p, tmp.size() * 4, stream);
+    rt_d2h(out, nn_in70.p, (size_t)last_total * CO_GAME_STATE_SIZE * 4, stream);
     rt_sync(stream);
-    for (int r = 0; r < last_total; ++r)
-      memcpy(out + (size_t)r * CO_GAME_STATE_SIZE, &tmp[(size_t)r * CO_STATE_STRIDE], CO_GAME_STATE_SIZE * 4);
   }
   /* Tourney::doIteration (tourney.cpp:53-70).  `rows` = rows of the caller's two arrays: the
    * reference reads them at its own offset table (quirk 10), so the whole arrays travel. */
@@ -462,17 +503,15 @@ struct ca_trainer {
     for (int g = 0; g < G; ++g) off[g + 1] = off[g] + host_games[g].n_samples;
     size_t n = (size_t)off[G];
     if (n == 0) return;
-    DevBuf<int32_t> d_off;
-    DevBuf<float> d_gs, d_ev, d_pr;
-    d_off.alloc(G + 1);
-    d_gs.alloc(n * 8 * CO_GAME_STATE_SIZE);
-    d_ev.alloc(n * 8);
-    d_pr.alloc(n * 8 * CO_NUM_MOVES);
-    rt_h2d(d_off.p, off.data(), off.size() * 4, stream);
-    RT_LAUNCH(co_k_write_samples, G, CO_WAVE, stream, P, (const int32_t *)d_off.p, d_gs.p, d_ev.p, d_pr.p);
-    rt_d2h(gs, d_gs.p, d_gs.n * 4, stream);
-    rt_d2h(ev, d_ev.p, d_ev.n * 4, stream);
-    rt_d2h(pr, d_pr.p, d_pr.n * 4, stream);
+    ensure(ws_off, (size_t)G + 1);
+    ensure(ws_gs, n * 8 * CO_GAME_STATE_SIZE);
+    ensure(ws_ev, n * 8);
+    ensure(ws_pr, n * 8 * CO_NUM_MOVES);
+    rt_h2d(ws_off.p, off.data(), off.size() * 4, stream);
+    RT_LAUNCH(co_k_write_samples, G, CO_WAVE, stream, P, (const int32_t *)ws_off.p, ws_gs.p, ws_ev.p, ws_pr.p);
+    rt_d2h(gs, ws_gs.p, n * 8 * CO_GAME_STATE_SIZE * 4, stream);
+    rt_d2h(ev, ws_ev.p, n * 8 * 4, stream);
+    rt_d2h(pr, ws_pr.p, n * 8 * CO_NUM_MOVES * 4, stream);
     rt_sync(stream);
   }
 
@@ -504,10 +543,9 @@ struct ca_trainer {
     for (int g = 0; g < G; ++g) off[g + 1] = off[g] + host_games[g].n_samples;
     if (off[G] > cap_rows) throw EngineError(CA_ERR_ARG, "pack_samples: destination too small");
     if (off[G] == 0) return 0;
-    DevBuf<int32_t> d_off;
-    d_off.alloc(G + 1);
-    rt_h2d(d_off.p, off.data(), off.size() * 4, stream);
-    RT_LAUNCH(co_k_pack_samples, G, CO_WAVE, stream, P, (const int32_t *)d_off.p, d_state_policy, d_outcome);
+    ensure(ws_off, (size_t)G + 1);
+    rt_h2d(ws_off.p, off.data(), off.size() * 4, stream);
+    RT_LAUNCH(co_k_pack_samples, G, CO_WAVE, stream, P, (const int32_t *)ws_off.p, d_state_policy, d_outcome);
     rt_sync(stream);
     return off[G];
   }
@@ -542,6 +580,28 @@ struct ca_trainer {
     if (slot < 0 || slot > 1) throw EngineError(CA_ERR_ARG, "net slot must be 0 or 1");
     nets[slot].reset(co_net_create(kind, weights, n, (size_t)G * spe, stream));
     if (!nets[slot]) throw EngineError(CA_ERR_ARG, "unknown net kind or bad weight count");
+  }
+
+  /* host rows in, host results out (ca_trainer_net_forward): persistent device buffers; the rows travel as
+   * the caller holds them (70 floats) and are widened to the kernels' 80-float rows on the device */
+  void net_forward_host(int slot, const float *states, int32_t n, float *evals, float *probs) {
+    if (slot < 0 || slot > 1 || !nets[slot]) throw EngineError(CA_ERR_STATE, "net slot not set");
+    CoNet *net = nets[slot].get();
+    if (n < 0 || (size_t)n > net->max_rows()) throw EngineError(CA_ERR_ARG, "net_forward: more rows than num_games*searches_per_eval");
+    if (n == 0) return;
+    ensure(fw_in70, (size_t)n * CO_GAME_STATE_SIZE);
+    ensure(fw_in, (size_t)n * CO_STATE_STRIDE);
+    ensure(fw_ev, (size_t)n);
+    ensure(fw_pr, (size_t)n * CO_NUM_MOVES);
+    ensure(fw_rows, 1);
+    rt_h2d(fw_in70.p, states, (size_t)n * CO_GAME_STATE_SIZE * 4, stream);
+    rt_h2d(fw_rows.p, &n, 4, stream);
+    const int nb = n * CO_STATE_STRIDE / CO_WAVE + 1 < 1024 ? n * CO_STATE_STRIDE / CO_WAVE + 1 : 1024;
+    RT_LAUNCH(co_k_expand_rows, nb, CO_WAVE, stream, (const float *)fw_in70.p, fw_in.p, (int)n, nb);
+    net->forward(fw_in.p, n, fw_rows.p, fw_ev.p, fw_pr.p, stream);
+    rt_d2h(evals, fw_ev.p, (size_t)n * 4, stream);
+    rt_d2h(probs, fw_pr.p, (size_t)n * CO_NUM_MOVES * 4, stream);
+    rt_sync(stream);
   }
 
   void net_forward_rows(int slot, const float *d_in, int32_t rows_cap, const int32_t *d_rows, float *d_eval,
@@ -695,6 +755,7 @@ struct ca_trainer {
     if (!failure.empty()) throw EngineError(CA_ERR_ENGINE, failure);
     pack(-1); /* refresh the done flag and the batch description */
     check_errors();
+    fetch_games();
     nn_rows = 0;
     for (int g = 0; g < G; ++g) nn_rows += host_games[g].evals; /* every consumed row was evaluated once */
     return finished;
@@ -798,6 +859,10 @@ struct ca_trainer {
     return CA_ERR_DEVICE;                 \
   }
 
+/* entry points on a trainer select its device first: the caller's thread may have another one current
+ * (two trainers on two GPUs in one process; torch.cuda.set_device between calls) */
+#define CA_TGUARD(...) CA_GUARD(rt_set_device(t->cfg.device); __VA_ARGS__)
+
 extern "C" int ca_trainer_create(const ca_config *cfg, ca_trainer **out) {
   if (!cfg || !out) {
     g_last_error = "null argument";
@@ -829,25 +894,29 @@ extern "C" int ca_trainer_create(const ca_config *cfg, ca_trainer **out) {
 
 extern "C" void ca_trainer_destroy(ca_trainer *t) { delete t; }
 
-extern "C" int ca_trainer_num_requests(ca_trainer *t, int to_play, int32_t *out) { CA_GUARD(*out = t->num_requests(to_play)) }
-extern "C" int ca_trainer_num_samples(ca_trainer *t, int32_t *out) { CA_GUARD(*out = t->num_samples()) }
-extern "C" int ca_trainer_score(ca_trainer *t, float *out) { CA_GUARD(*out = t->score()) }
-extern "C" int ca_trainer_avg_mate_length(ca_trainer *t, float *out) { CA_GUARD(*out = t->avg_mate_length()) }
-extern "C" int ca_trainer_write_requests(ca_trainer *t, float *gs, int to_play) { CA_GUARD(t->write_requests(gs, to_play)) }
-extern "C" int ca_trainer_write_samples(ca_trainer *t, float *gs, float *ev, float *pr) { CA_GUARD(t->write_samples(gs, ev, pr)) }
-extern "C" int ca_trainer_write_scores(ca_trainer *t, const char *file) { CA_GUARD(t->write_scores(file)) }
+extern "C" int ca_trainer_num_requests(ca_trainer *t, int to_play, int32_t *out) { CA_TGUARD(*out = t->num_requests(to_play)) }
+extern "C" int ca_trainer_num_samples(ca_trainer *t, int32_t *out) { CA_TGUARD(*out = t->num_samples()) }
+extern "C" int ca_trainer_score(ca_trainer *t, float *out) { CA_TGUARD(*out = t->score()) }
+extern "C" int ca_trainer_avg_mate_length(ca_trainer *t, float *out) { CA_TGUARD(*out = t->avg_mate_length()) }
+extern "C" int ca_trainer_write_requests(ca_trainer *t, float *gs, int to_play) { CA_TGUARD(t->write_requests(gs, to_play)) }
+extern "C" int ca_trainer_write_samples(ca_trainer *t, float *gs, float *ev, float *pr) { CA_TGUARD(t->write_samples(gs, ev, pr)) }
+extern "C" int ca_trainer_write_scores(ca_trainer *t, const char *file) { CA_TGUARD(t->write_scores(file)) }
 extern "C" int ca_trainer_do_iteration(ca_trainer *t, const float *ev, const float *pr, int to_play, int32_t *all_done) {
-  CA_GUARD(*all_done = t->do_iteration(ev, pr, to_play) ? 1 : 0)
+  CA_TGUARD(*all_done = t->do_iteration(ev, pr, to_play) ? 1 : 0)
 }
-extern "C" int ca_trainer_set_net(ca_trainer *t, int slot, int kind, const float *w, size_t n) { CA_GUARD(t->set_net(slot, kind, w, n)) }
+extern "C" int ca_trainer_set_net(ca_trainer *t, int slot, int kind, const float *w, size_t n) { CA_TGUARD(t->set_net(slot, kind, w, n)) }
 extern "C" int ca_trainer_run(ca_trainer *t, int64_t max_iterations, int32_t *all_done) {
-  CA_GUARD(*all_done = t->run(max_iterations) ? 1 : 0)
+  CA_TGUARD(*all_done = t->run(max_iterations) ? 1 : 0)
 }
-extern "C" int ca_trainer_export_samples(ca_trainer *t, float *sp, float *oc) { CA_GUARD(t->export_samples(sp, oc)) }
+extern "C" int ca_trainer_export_samples(ca_trainer *t, float *sp, float *oc) { CA_TGUARD(t->export_samples(sp, oc)) }
 extern "C" int ca_trainer_pack_samples_device(ca_trainer *t, void *d_sp, void *d_oc, int32_t cap_rows, int32_t *n_rows) {
-  CA_GUARD(*n_rows = t->pack_samples_device((float *)d_sp, (float *)d_oc, cap_rows))
+  CA_TGUARD(*n_rows = t->pack_samples_device((float *)d_sp, (float *)d_oc, cap_rows))
 }
-extern "C" int ca_trainer_reset(ca_trainer *t, int32_t seed) { CA_GUARD(t->reset_games(seed)) }
+extern "C" int ca_trainer_pin_host(ca_trainer *t, void *p, size_t bytes, int32_t *pinned) {
+  CA_TGUARD(*pinned = t->pin_host(p, bytes) ? 1 : 0)
+}
+extern "C" int ca_trainer_unpin_host(ca_trainer *t, void *p) { CA_TGUARD(t->unpin_host(p)) }
+extern "C" int ca_trainer_reset(ca_trainer *t, int32_t seed) { CA_TGUARD(t->reset_games(seed)) }
 /* ------------------------------------------------------------------ Tourney C ABI */
 struct ca_tourney {
   int device = 0;
@@ -1013,18 +1082,18 @@ extern "C" int ca_tourney_set_net(ca_tourney *t, int32_t model_id, int32_t kind,
   })
 }
 extern "C" int ca_tourney_run(ca_tourney *t, int64_t max_rounds, int32_t *all_done) {
-  CA_GUARD(*all_done = t->run(max_rounds) ? 1 : 0)
+  CA_GUARD(rt_set_device(t->device); *all_done = t->run(max_rounds) ? 1 : 0)
 }
 extern "C" int ca_tourney_all_done(ca_tourney *t, int32_t *out) { CA_GUARD(*out = t->built().tourney_all_done() ? 1 : 0) }
 extern "C" int ca_tourney_num_requests(ca_tourney *t, int32_t id, int32_t *out) {
-  CA_GUARD(*out = t->built().tourney_num_requests(id))
+  CA_GUARD(rt_set_device(t->device); *out = t->built().tourney_num_requests(id))
 }
 extern "C" int ca_tourney_write_requests(ca_tourney *t, float *game_states, int32_t id) {
-  CA_GUARD(t->built().tourney_write_requests(game_states, id))
+  CA_GUARD(rt_set_device(t->device); t->built().tourney_write_requests(game_states, id))
 }
 extern "C" int ca_tourney_do_iteration(ca_tourney *t, const float *evaluations, const float *probabilities,
                                        int32_t rows, int32_t id) {
-  CA_GUARD(t->built().tourney_do_iteration(evaluations, probabilities, rows, id))
+  CA_GUARD(rt_set_device(t->device); t->built().tourney_do_iteration(evaluations, probabilities, rows, id))
 }
 extern "C" int ca_tourney_num_matches(ca_tourney *t, int32_t *out) { CA_GUARD(*out = (int32_t)t->matches.size()) }
 /* out[8] = {player id 1, player id 2, done, result (util.h:57-64, first player's view), side to move, pending
@@ -1090,7 +1159,7 @@ extern "C" int ca_tourney_stats(ca_tourney *t, ca_stats *out) {
 
 /* diagnostic builds (-DCO_PROF): summed in-kernel cycle stamps, see mcts.h; not in the public header */
 extern "C" int ca_trainer_prof(ca_trainer *t, unsigned long long out[36]) {
-  CA_GUARD({
+  CA_TGUARD({
     for (int i = 0; i < 36; ++i) out[i] = 0;
     if (!t->prof.p) throw EngineError(CA_ERR_STATE, "not a -DCO_PROF build");
     std::vector<unsigned long long> h((size_t)t->G * 16);
@@ -1106,33 +1175,13 @@ extern "C" int ca_trainer_prof(ca_trainer *t, unsigned long long out[36]) {
 }
 
 extern "C" int ca_trainer_net_forward(ca_trainer *t, int slot, const float *states, int32_t n, float *evals, float *probs) {
-  CA_GUARD({
-    if (slot < 0 || slot > 1 || !t->nets[slot]) throw EngineError(CA_ERR_STATE, "net slot not set");
-    DevBuf<float> d_in, d_ev, d_pr;
-    DevBuf<int32_t> d_n;
-    d_in.alloc((size_t)n * CO_STATE_STRIDE);
-    d_ev.alloc(n);
-    d_pr.alloc((size_t)n * CO_NUM_MOVES);
-    d_n.alloc(1);
-    std::vector<float> pad((size_t)n * CO_STATE_STRIDE, 0.0f);
-    for (int r = 0; r < n; ++r)
-      memcpy(&pad[(size_t)r * CO_STATE_STRIDE], states + (size_t)r * CO_GAME_STATE_SIZE, CO_GAME_STATE_SIZE * 4);
-    rt_h2d(d_in.p, pad.data(), pad.size() * 4, t->stream);
-    rt_h2d(d_n.p, &n, 4, t->stream);
-    std::unique_ptr<CoNet> tmp;
-    CoNet *net = t->nets[slot].get();
-    if ((size_t)n > net->max_rows()) throw EngineError(CA_ERR_ARG, "net_forward: more rows than num_games*searches_per_eval");
-    net->forward(d_in.p, n, d_n.p, d_ev.p, d_pr.p, t->stream);
-    rt_d2h(evals, d_ev.p, (size_t)n * 4, t->stream);
-    rt_d2h(probs, d_pr.p, (size_t)n * CO_NUM_MOVES * 4, t->stream);
-    rt_sync(t->stream);
-  })
+  CA_TGUARD(t->net_forward_host(slot, states, n, evals, probs))
 }
 
 /* kernel-only timing of a network on `rows` resident rows (HIP events on the engine's stream);
  * diagnostics and the per-kernel roofline of bench.py */
 extern "C" int ca_trainer_net_bench(ca_trainer *t, int slot, const float *states, int32_t rows, int32_t reps, float *ms_per_call) {
-  CA_GUARD({
+  CA_TGUARD({
     if (slot < 0 || slot > 1 || !t->nets[slot]) throw EngineError(CA_ERR_STATE, "net slot not set");
     if ((size_t)rows > t->nets[slot]->max_rows()) throw EngineError(CA_ERR_ARG, "net_bench: too many rows");
     std::vector<float> pad((size_t)rows * CO_STATE_STRIDE, 0.0f);
@@ -1178,7 +1227,7 @@ extern "C" int ca_expand_samples(int device, const float *state_policy, const fl
 }
 
 extern "C" int ca_trainer_stats(ca_trainer *t, ca_stats *out) {
-  CA_GUARD({
+  CA_TGUARD({
     t->fetch_games();
     memset(out, 0, sizeof *out);
     for (int g = 0; g < t->G; ++g) {
@@ -1207,7 +1256,7 @@ extern "C" int ca_trainer_stats(ca_trainer *t, ca_stats *out) {
 }
 
 extern "C" int ca_trainer_game_info(ca_trainer *t, int game, int32_t out[8]) {
-  CA_GUARD({
+  CA_TGUARD({
     if (game < 0 || game >= t->G) throw EngineError(CA_ERR_ARG, "game index out of range");
     t->fetch_games();
     const GameCtl &gc = t->host_games[game];
@@ -1217,7 +1266,7 @@ extern "C" int ca_trainer_game_info(ca_trainer *t, int game, int32_t out[8]) {
 }
 
 extern "C" int ca_trainer_trace(ca_trainer *t, int game, int32_t *out, int32_t cap, int32_t *n) {
-  CA_GUARD({
+  CA_TGUARD({
     if (!t->cfg.trace) throw EngineError(CA_ERR_STATE, "trace not enabled");
     if (game < 0 || game >= t->G) throw EngineError(CA_ERR_ARG, "game index out of range");
     t->fetch_games();

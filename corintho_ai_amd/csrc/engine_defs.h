@@ -135,6 +135,8 @@ struct EngineParams {
   const float *nn_eval;   /* [rows] compact, row = req_offset[g] + k */
   const float *nn_probs;  /* [rows][96] */
   float *nn_in;           /* [rows][CO_STATE_STRIDE] compact request rows */
+  float *nn_in70;         /* [rows][70] the same rows as Trainer::writeRequests lays them out (compat mode), or null */
+  int32_t *ctl;           /* [4] written by co_k_scan: batch rows, all done, OR of the games' error bits, games not done */
   float *samples;       /* [G][CO_MAX_PLIES][166] */
   int32_t *trace;       /* [G][CO_TRACE_CAP] or null */
   int32_t *all_done;    /* [1] */

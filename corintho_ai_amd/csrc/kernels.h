@@ -33,20 +33,24 @@ CO_KERNEL co_k_scan(EngineParams P) {
   int chunk = (G + CO_WAVE - 1) / CO_WAVE;
   LV(int, csum);
   LV(int, nd);
+  LV(int, er);
   FOR_LANES {
-    int s = 0, notdone = 0;
+    int s = 0, notdone = 0, err = 0;
     for (int i = 0; i < chunk; ++i) {
       int g = lane * chunk + i;
       if (g < G) {
         GameCtl gc = P.games[g];
         if (co_game_active(P, g, gc, tp)) s += gc.n_pending;
         notdone += !gc.done;
+        err |= gc.error;
       }
     }
     L(csum) = s;
     L(nd) = notdone;
+    L(er) = err != 0;
   }
   int not_done = WAVE_SUM_I32(nd);
+  int any_error = WAVE_BALLOT(er) != 0;
   /* exclusive scan of the 64 chunk sums (uniform serial loop: 64 adds) */
   WAVE_SHARED(int, cbase, CO_WAVE + 1);
   FOR_LANES { cbase[lane + 1] = L(csum); }
@@ -84,6 +88,12 @@ CO_KERNEL co_k_scan(EngineParams P) {
     if (lane == 0) {
       P.req_offset[G] = run;
       P.all_done[0] = not_done == 0;
+      if (P.ctl) {
+        P.ctl[0] = run;
+        P.ctl[1] = not_done == 0;
+        P.ctl[2] = any_error;
+        P.ctl[3] = not_done;
+      }
       if (P.row_counter && (!P.arena_state || P.scan_phase == 1)) P.row_counter[0] += (unsigned long long)run;
       if (P.arena_state) {
         if (P.scan_phase == 0) {
@@ -116,6 +126,25 @@ CO_KERNEL co_k_compact(EngineParams P) {
   int total = n * CO_STATE_STRIDE;
   FOR_LANES {
     for (int i = lane; i < total; i += CO_WAVE) dst[i] = src[i];
+  }
+  if (P.nn_in70) {
+    /* the rows as the caller's array holds them: 70 floats each, no padding (trainer.cpp:79-101) */
+    float *d70 = P.nn_in70 + (size_t)P.req_offset[g] * CO_GAME_STATE_SIZE;
+    int t70 = n * CO_GAME_STATE_SIZE;
+    FOR_LANES {
+      for (int i = lane; i < t70; i += CO_WAVE) d70[i] = src[(i / CO_GAME_STATE_SIZE) * CO_STATE_STRIDE + i % CO_GAME_STATE_SIZE];
+    }
+  }
+}
+
+/* rows of 70 floats (the caller's layout) -> rows of CO_STATE_STRIDE floats (the network kernels' input) */
+CO_KERNEL co_k_expand_rows(const float *in70, float *out80, int rows, int nblocks) {
+  FOR_LANES {
+    int total = rows * CO_STATE_STRIDE;
+    for (int i = CO_BLOCK_IDX * CO_WAVE + lane; i < total; i += CO_WAVE * nblocks) {
+      int r = i / CO_STATE_STRIDE, c = i % CO_STATE_STRIDE;
+      out80[i] = c < CO_GAME_STATE_SIZE ? in70[(size_t)r * CO_GAME_STATE_SIZE + c] : 0.0f;
+    }
   }
 }
 

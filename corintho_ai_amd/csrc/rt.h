@@ -35,6 +35,8 @@ inline void rt_event_sync(rt_event_t) {}
 inline float rt_event_elapsed_ms(rt_event_t, rt_event_t) { return 0.0f; }
 inline void rt_host_alloc(void **p, size_t n) { rt_malloc(p, n); }
 inline void rt_host_free(void *p) { free(p); }
+inline bool rt_host_register(void *, size_t) { return true; }
+inline void rt_host_unregister(void *) {}
 #define RT_LAUNCH(kernel, grid, block, stream, ...)      \
   do {                                                   \
     int _grid = (int)(grid);                             \
@@ -90,6 +92,16 @@ inline float rt_event_elapsed_ms(rt_event_t a, rt_event_t b) {
 inline void rt_host_alloc(void **p, size_t n) { RT_CHECK(hipHostMalloc(p, n ? n : 1, hipHostMallocDefault)); }
 inline void rt_host_free(void *p) {
   if (p) (void)hipHostFree(p);
+}
+/* page-lock caller memory so that copies from / to it are direct DMA (no staging through the
+ * runtime's bounce buffers); false = the runtime refused (the copy still works, pageable) */
+inline bool rt_host_register(void *p, size_t n) {
+  if (hipHostRegister(p, n, hipHostRegisterDefault) == hipSuccess) return true;
+  (void)hipGetLastError();
+  return false;
+}
+inline void rt_host_unregister(void *p) {
+  if (p) (void)hipHostUnregister(p);
 }
 #define RT_LAUNCH(kernel, grid, block, stream, ...)                                           \
   do {                                                                                        \

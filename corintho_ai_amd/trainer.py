@@ -117,11 +117,28 @@ class Trainer:
         _lib.check(self._L, self._L.ca_trainer_run(self._t, max_iterations, C.byref(done)))
         return bool(done.value)
 
-    def net_forward(self, states, slot=0):
+    def pin(self, *arrays):
+        """Page-lock caller arrays (the evals / probs / game_states of the play loop, main.pyx:132-134) for
+        direct DMA.  They must outlive the trainer or be passed to unpin() first.  -> all pinned?"""
+        ok = True
+        for a in arrays:
+            _f32(a, "array")
+            got = C.c_int32()
+            _lib.check(self._L, self._L.ca_trainer_pin_host(self._t, C.c_void_p(a.ctypes.data), a.nbytes, C.byref(got)))
+            ok = ok and bool(got.value)
+        return ok
+
+    def unpin(self, *arrays):
+        for a in arrays:
+            _lib.check(self._L, self._L.ca_trainer_unpin_host(self._t, C.c_void_p(a.ctypes.data)))
+
+    def net_forward(self, states, slot=0, out_evals=None, out_probs=None):
+        """evaluate `states` with the network of `slot`; out_evals / out_probs: caller arrays to fill (their
+        first len(states) rows) instead of new ones"""
         s = np.ascontiguousarray(states, dtype=np.float32)
         n = s.shape[0]
-        ev = np.zeros(n, np.float32)
-        pr = np.zeros((n, NUM_MOVES), np.float32)
+        ev = np.zeros(n, np.float32) if out_evals is None else out_evals
+        pr = np.zeros((n, NUM_MOVES), np.float32) if out_probs is None else out_probs
         _lib.check(self._L, self._L.ca_trainer_net_forward(self._t, slot, _f32(s, "states"), n, _f32(ev, "ev"),
                                                            _f32(pr, "pr")))
         return ev, pr

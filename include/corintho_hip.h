@@ -97,6 +97,14 @@ int ca_trainer_write_scores(ca_trainer *t, const char *file);
 int ca_trainer_do_iteration(ca_trainer *t, const float *evaluations, const float *probabilities, int to_play,
                             int32_t *all_done);
 
+/* Optional, for the reference protocol above: page-lock a caller-owned array (the three arrays the
+ * reference's play loop allocates once and passes to every call, main.pyx:132-134) so that the
+ * per-iteration copies from / to it are direct DMA at PCIe speed instead of staged copies from
+ * pageable memory.  The array must stay allocated until ca_trainer_unpin_host or
+ * ca_trainer_destroy.  *pinned = 0 if the runtime refused (the calls still work, slower). */
+int ca_trainer_pin_host(ca_trainer *t, void *p, size_t bytes, int32_t *pinned);
+int ca_trainer_unpin_host(ca_trainer *t, void *p);
+
 /* ---------------- fused mode (no reference counterpart; opt-in) ----------------
  * The network runs on the device, so the play loop of main.pyx:123-187 never
  * leaves the GPU.  Weights are a flat float32 buffer in the layout documented in

@@ -11,10 +11,10 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from corintho_ai_amd import NET_MLP12X100, NET_RESCNN4_X3, Tourney, Trainer, nets  # noqa: E402
+from corintho_ai_amd import NET_MLP12X100, NET_RESCNN4_X3, NET_RESCNN4_X6, Tourney, Trainer, nets  # noqa: E402
 
 which = sys.argv[1:] or ["cfg1", "cfg4", "cfg5", "tourney", "compat"]
-net_kind = NET_RESCNN4_X3
+net_kind, net_name = (NET_RESCNN4_X3, "rescnn4x3") if "x3" in which else (NET_RESCNN4_X6, "rescnn4x6")
 w0, w1 = nets.init_rescnn4(0), nets.init_rescnn4(1)
 
 
@@ -31,7 +31,7 @@ def run(name, G, S, testing=False, reps=1):
         assert t.run()
         dt = time.perf_counter() - t0
         st = t.stats()
-        rec = {"config": name, "games": G, "sims": S, "testing": testing, "net": "rescnn4x3", "seconds": dt,
+        rec = {"config": name, "games": G, "sims": S, "testing": testing, "net": net_name, "seconds": dt,
                "games_per_s": G / dt, "iterations": st["iterations"], "searches": st["searches"], "evals": st["evals"],
                "plies_per_game": st["plies"] / G, "device_ms": {k: st[k] for k in ("mcts_ms", "nn_ms", "pack_ms")},
                "peak_arena_units_per_tree": st["peak_arena_units"], "score": t.score()}
@@ -75,7 +75,7 @@ def run_tourney(n_matches=1024):
     st = t.stats()
     score = sum(t.match_score(i) for i in range(n_matches)) / n_matches
     print(json.dumps({"config": "tourney: %d matches, 5 players, 2 models + random" % n_matches, "matches": n_matches,
-                      "net": "rescnn4x3", "seconds": dt, "matches_per_s": n_matches / dt, "iterations": st["iterations"],
+                      "net": net_name, "seconds": dt, "matches_per_s": n_matches / dt, "iterations": st["iterations"],
                       "searches": st["searches"], "evals": st["evals"], "plies_per_match": st["plies"] / n_matches,
                       "mean_first_player_score": score}), flush=True)
     t.close()
@@ -97,18 +97,18 @@ def run_compat(G=4096, S=400):
     evals = np.zeros(cap, np.float32)
     probs = np.zeros((cap, 96), np.float32)
     gs = np.zeros((cap, 70), np.float32)
+    pinned = t.pin(evals, probs, gs) if "nopin" not in which else False  # the arrays of main.pyx:132-134, allocated once
     t0 = time.perf_counter()
     iters = 0
     while not t.doIteration(evals, probs, -1):
         n = t.num_requests(-1)
         t.writeRequests(gs, -1)
-        e, p = t.net_forward(gs[:n])
-        evals[:n] = e
-        probs[:n] = p
+        t.net_forward(gs[:n], out_evals=evals, out_probs=probs)
         iters += 1
     dt = time.perf_counter() - t0
     print(json.dumps({"config": "compat: %d games x %d sims, host-driven protocol, network via net_forward" % (G, S),
-                      "games": G, "sims": S, "net": "rescnn4x3", "seconds": dt, "games_per_s": G / dt, "iterations": iters}),
+                      "games": G, "sims": S, "net": net_name, "pinned_host_arrays": bool(pinned), "seconds": dt, "games_per_s": G / dt,
+                      "iterations": iters}),
           flush=True)
     t.close()
 
