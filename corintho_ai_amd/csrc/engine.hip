@@ -145,6 +145,11 @@ struct ca_trainer {
   DevBuf<int32_t> read_offset;
   bool scan_valid = false;
 
+  /* analysis mode: the positions (DockerMC constructor arguments) */
+  std::vector<uint32_t> an_pos;   /* [G][3] board lo, board hi, meta */
+  std::vector<uint32_t> an_seed;  /* [G] */
+  std::vector<int32_t> an_pre;    /* [G] Node result of a position that is terminal as given, else 0 */
+
   std::vector<Pool> pools;
   void free_pools() {
     for (auto &q : pools) {
@@ -197,6 +202,11 @@ struct ca_trainer {
 
   void init(const ca_config &c) {
     cfg = c;
+    if (cfg.analyse) {
+      cfg.testing = 1;    /* trainmc.cpp:43 */
+      cfg.no_stagger = 1;
+      cfg.game_base = cfg.total_games = 0;
+    }
     if (cfg.max_searches <= 0) cfg.max_searches = 1600;
     if (cfg.searches_per_eval <= 0) cfg.searches_per_eval = 16;
     if (cfg.c_puct <= 0.0f) cfg.c_puct = 1.0f;
@@ -260,12 +270,32 @@ struct ca_trainer {
     std::vector<TreeCtl> ht(T);
     for (int g = 0; g < G; ++g) {
       uint32_t *x = &st[(size_t)g * CO_MT_N];
-      x[0] = tourney ? match_seeds[g] : seeds[cfg.game_base + g];
+      x[0] = tourney ? match_seeds[g] : (cfg.analyse && !an_seed.empty()) ? an_seed[g] : seeds[cfg.game_base + g];
       for (int i = 1; i < CO_MT_N; ++i) x[i] = 1812433253u * (x[i - 1] ^ (x[i - 1] >> 30)) + (uint32_t)i;
       memset(&hg[g], 0, sizeof(GameCtl));
       hg[g].parity = (cfg.game_base + g) % 2;
       hg[g].rng_idx = CO_MT_N;
       hg[g].pos_meta = CO_META_START; /* Match::root_ = Node{} (match.h:91): the empty board */
+      if (cfg.analyse && !an_pos.empty()) {
+        hg[g].parity = 0;
+        hg[g].pos_lo = an_pos[3 * g];
+        hg[g].pos_hi = an_pos[3 * g + 1];
+        hg[g].pos_meta = an_pos[3 * g + 2];
+        if (an_pre[g]) hg[g].done = 1; /* choose_move.pyx:194-197: a terminal position is not searched */
+      }
+    }
+    if (cfg.analyse && !an_pos.empty()) {
+      /* result rows of the positions that were terminal as given */
+      std::vector<uint32_t> rows((size_t)G * spe * CO_STATE_STRIDE, 0u);
+      for (int g = 0; g < G; ++g)
+        if (an_pre[g]) {
+          uint32_t *o = &rows[(size_t)g * spe * CO_STATE_STRIDE];
+          o[0] = 0xFFFFFFFFu;
+          o[1] = (uint32_t)an_pre[g];
+          o[2] = 1u;
+          o[7] = 1u;
+        }
+      rt_h2d(req.p, rows.data(), rows.size() * 4, stream);
     }
     for (size_t t = 0; t < T; ++t) {
       ht[t].root = CO_NONE;
@@ -307,6 +337,7 @@ struct ca_trainer {
     P.game_base = cfg.game_base;
     P.cap_units = cap;
     P.trace_on = cfg.trace;
+    P.analyse = cfg.analyse;
     P.pcfg = tourney ? pcfg.p : nullptr;
     P.read_offset = tourney ? read_offset.p : nullptr;
     P.arena_state = nullptr;
@@ -575,6 +606,77 @@ struct ca_trainer {
     fclose(f);
   }
 
+  /* ------------------------------------------------------------ analysis mode (DockerMC) */
+  void set_positions(const int32_t *boards, const int32_t *to_play, const int32_t *pieces, const int32_t *seeds) {
+    if (!cfg.analyse) throw EngineError(CA_ERR_STATE, "set_positions: not an analysis trainer (ca_config.analyse)");
+    if (iterations > 0) throw EngineError(CA_ERR_STATE, "set_positions after the first iteration");
+    an_pos.assign((size_t)3 * G, 0u);
+    an_seed.assign(G, 0u);
+    an_pre.assign(G, 0);
+    std::vector<uint64_t> hb(G);
+    std::vector<uint32_t> hm(G);
+    for (int g = 0; g < G; ++g) {
+      uint64_t b = 0;
+      for (int i = 0; i < 64; ++i) {
+        int v = boards[(size_t)g * 64 + i];
+        if (v != 0 && v != 1) throw EngineError(CA_ERR_ARG, "set_positions: board entries must be 0 or 1");
+        if (v) b |= 1ull << i;
+      }
+      uint32_t meta = 0;
+      for (int i = 0; i < 6; ++i) {
+        int pc = pieces[(size_t)g * 6 + i];
+        if (pc < 0 || pc > 4) throw EngineError(CA_ERR_ARG, "set_positions: piece counts must be 0..4");
+        meta |= (uint32_t)pc << (3 * i);
+      }
+      if (to_play[g] != 0 && to_play[g] != 1) throw EngineError(CA_ERR_ARG, "set_positions: to_play must be 0 or 1");
+      meta |= (uint32_t)to_play[g] << 18;
+      an_pos[3 * g] = (uint32_t)b;
+      an_pos[3 * g + 1] = (uint32_t)(b >> 32);
+      an_pos[3 * g + 2] = meta;
+      an_seed[g] = (uint32_t)seeds[g];
+      hb[g] = b;
+      hm[g] = meta;
+    }
+    /* Node result of every given position (node.cpp:256-271), by the rule kernel */
+    DevBuf<uint64_t> db;
+    DevBuf<uint32_t> dm, dk;
+    DevBuf<int32_t> dl;
+    db.alloc(G); dm.alloc(G); dk.alloc((size_t)G * 3); dl.alloc(G);
+    rt_h2d(db.p, hb.data(), (size_t)G * 8, stream);
+    rt_h2d(dm.p, hm.data(), (size_t)G * 4, stream);
+    RT_LAUNCH(co_k_rules_batch, G, CO_WAVE, stream, (const uint64_t *)db.p, (const uint32_t *)dm.p, G, dk.p, dl.p);
+    std::vector<uint32_t> mk((size_t)G * 3);
+    std::vector<int32_t> ln(G);
+    rt_d2h(mk.data(), dk.p, mk.size() * 4, stream);
+    rt_d2h(ln.data(), dl.p, ln.size() * 4, stream);
+    rt_sync(stream);
+    for (int g = 0; g < G; ++g)
+      if ((mk[3 * g] | mk[3 * g + 1] | mk[3 * g + 2]) == 0u) an_pre[g] = ln[g] ? CO_RESULT_LOSS : CO_RESULT_DRAW;
+    reset_games(cfg.seed);
+  }
+
+  void analysis(int32_t *out) {
+    if (!cfg.analyse) throw EngineError(CA_ERR_STATE, "not an analysis trainer");
+    std::vector<uint32_t> rows((size_t)G * spe * CO_STATE_STRIDE);
+    rt_d2h(rows.data(), req.p, rows.size() * 4, stream);
+    rt_sync(stream);
+    fetch_games();
+    for (int g = 0; g < G; ++g) {
+      const uint32_t *r = &rows[(size_t)g * spe * CO_STATE_STRIDE];
+      int32_t *o = out + (size_t)g * 8;
+      if (!host_games[g].done || r[7] != 1u) throw EngineError(CA_ERR_STATE, "analysis: search of position " + std::to_string(g) + " is not finished");
+      const int res = (int)r[1];
+      o[0] = (int32_t)r[0];
+      o[1] = res == CO_RESULT_LOSS || res == CO_RESULT_DRAW;   /* Node::terminal, node.cpp:96-98 */
+      o[2] = res == CO_RESULT_DRAW || res == CO_DEDUCED_DRAW;  /* Node::drawn */
+      o[3] = (int32_t)r[2];
+      o[4] = (int32_t)r[3];
+      o[5] = (int32_t)r[4];
+      o[6] = (int32_t)r[5];
+      o[7] = (int32_t)r[6];
+    }
+  }
+
   /* ------------------------------------------------------------ fused mode */
   void set_net(int slot, int kind, const float *weights, size_t n) {
     if (slot < 0 || slot > 1) throw EngineError(CA_ERR_ARG, "net slot must be 0 or 1");
@@ -763,8 +865,8 @@ struct ca_trainer {
 
   bool run(int64_t max_iterations) {
     if (!nets[0]) throw EngineError(CA_ERR_STATE, "ca_trainer_run: no network set (ca_trainer_set_net)");
-    if (cfg.testing && !nets[1]) throw EngineError(CA_ERR_STATE, "arena mode needs both networks");
-    if (!cfg.testing) {
+    if (cfg.testing && !cfg.analyse && !nets[1]) throw EngineError(CA_ERR_STATE, "arena mode needs both networks");
+    if (!cfg.testing || cfg.analyse) { /* one network, every slot active: self-play training, or N position searches */
       int npools = cfg.pools > 0 ? cfg.pools : (G >= 2048 ? 2 : 1);
       if (npools > CO_MAX_POOLS) npools = CO_MAX_POOLS;
       if (npools > G) npools = G;
@@ -916,6 +1018,11 @@ extern "C" int ca_trainer_pin_host(ca_trainer *t, void *p, size_t bytes, int32_t
   CA_TGUARD(*pinned = t->pin_host(p, bytes) ? 1 : 0)
 }
 extern "C" int ca_trainer_unpin_host(ca_trainer *t, void *p) { CA_TGUARD(t->unpin_host(p)) }
+extern "C" int ca_trainer_set_positions(ca_trainer *t, const int32_t *boards, const int32_t *to_play, const int32_t *pieces,
+                                        const int32_t *seeds) {
+  CA_TGUARD(t->set_positions(boards, to_play, pieces, seeds))
+}
+extern "C" int ca_trainer_analysis(ca_trainer *t, int32_t *out) { CA_TGUARD(t->analysis(out)) }
 extern "C" int ca_trainer_reset(ca_trainer *t, int32_t seed) { CA_TGUARD(t->reset_games(seed)) }
 /* ------------------------------------------------------------------ Tourney C ABI */
 struct ca_tourney {

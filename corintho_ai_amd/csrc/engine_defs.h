@@ -110,6 +110,10 @@ struct EngineParams {
   int32_t game_base;   /* global index of local game 0 (multi-GPU shard): parity = (base + g) % 2 */
   uint32_t cap_units;  /* arena units per tree */
   int32_t trace_on;
+  /* analysis mode (DockerMC, dockermc.cpp / trainmc.cpp:38-45): every slot is ONE position to search --
+   * the root is created from gc.pos_* at depth 0, testing = true, and the slot finishes with its
+   * first chooseMove; results in the slot's request area (mcts.h co_analyse_finish) */
+  int32_t analyse;
   /* tournament mode (Match / Tourney): per-match players [2G]; to_play then carries the MODEL id
    * whose matches run (Match::to_play, match.cpp:42-44); read_offset[G] = the reference's
    * offset table of Tourney::doIteration (tourney.cpp:55-62) */

@@ -56,7 +56,7 @@ struct CoWave {
   int32_t *trace;
   unsigned long long *prof;
   /* config */
-  int max_searches, spe, testing, trace_on, defer_handover;
+  int max_searches, spe, testing, trace_on, defer_handover, analyse;
   float c_puct, epsilon;
   const PlayerCfg *pc; /* tournament match: the two players' settings, else null */
 };
@@ -740,6 +740,14 @@ CO_DEV void co_search(CoWave &w, CoTree &t, CoRoot &rc) {
       uint32_t nb = co_create_node(w, t, board, meta, depth, cur, child_slot, &res);
       CO_PROF_ADD(w, 3, CO_CLK() - te);
       if (nb == CO_NONE) return;
+      if (w.analyse) {
+        /* Node::countNodes (node.cpp:179-187) without a traversal: word z of unit b + 1 counts the
+         * nodes below block b; a new node adds one to every node of its path */
+        FOR_LANES {
+          if (lane <= D) A[path_block[lane] + 1].z += 1u;
+        }
+        WAVE_SYNC();
+      }
       cs = make_uint4(nb, 0u, (best_slot.z & 0xFFFFu) | (1u << 16), (uint32_t)res | 0x100u);
       cur = nb;
       cur_slot = child_slot;
@@ -818,7 +826,10 @@ CO_DEV void co_request_root(CoWave &w, CoTree &t) {
 CO_DEV int co_mc_do_iteration(CoWave &w, CoTree &t, const float *eval, const float *probs) {
   if (t.tc.root == CO_NONE) {
     int res;
-    uint32_t b = co_create_node(w, t, 0ull, CO_META_START, 0, CO_NONE, CO_NONE, &res);
+    /* a search from the start position; in analysis mode TrainMC(..., board, to_play, pieces) ->
+     * createRoot(Game{...}, 0) (trainmc.cpp:38-45), whose first doIteration asks for the root's evaluation */
+    const uint64_t b0 = w.analyse ? ((uint64_t)w.gc.pos_lo | ((uint64_t)w.gc.pos_hi << 32)) : 0ull;
+    uint32_t b = co_create_node(w, t, b0, w.analyse ? (w.gc.pos_meta & 0x7FFFFu) : CO_META_START, 0, CO_NONE, CO_NONE, &res);
     if (b == CO_NONE) return 0;
     t.tc.root = b;
     t.tc.searches_done = 1;
@@ -1121,6 +1132,32 @@ CO_DEV int co_nth_move(const uint32_t lm[3], int k) {
   return -1;
 }
 
+/* Analysis mode: what docker/choose_move.pyx:206-221 reads off the DockerMC after chooseMove(), written as
+ * eight words into the slot's request area: {move, Node result of the new root (util.h:57-64), nodes in
+ * the kept tree (num_nodes), bits of the new root's summed evaluation (eval), legal-move mask of the new
+ * root [3], 1} -- done() = result is a terminal one, drawn() = result is a draw. */
+CO_DEV void co_analyse_finish(CoWave &w, CoTree &t, int choice) {
+  uint4 h0 = co_load_unit(t.A, t.tc.root);
+  uint4 h1 = co_load_unit(t.A, t.tc.root + 1);
+  uint4 rs = co_load_unit(t.A, h1.x);
+  uint32_t lm[3];
+  co_legal_moves((uint64_t)h0.x | ((uint64_t)h0.y << 32), h0.z, lm);
+  uint32_t *out = (uint32_t *)w.req;
+  FOR_LANES {
+    if (lane == 0) {
+      out[0] = (uint32_t)choice;
+      out[1] = (uint32_t)co_slot_result(rs);
+      out[2] = h1.z + 1u;
+      out[3] = rs.y;
+      out[4] = lm[0];
+      out[5] = lm[1];
+      out[6] = lm[2];
+      out[7] = 1u;
+    }
+  }
+  WAVE_SYNC();
+}
+
 /* One step of a game:
  *   self-play   SelfPlayer::doIteration (selfplayer.cpp:115-122) + chooseMoveAndContinue
  *               (:246-291; chooseMove :234-244, endGame :206-232),
@@ -1188,6 +1225,11 @@ CO_DEV int co_game_step(CoWave &w, const float *eval, const float *probs) {
       }
       choice = co_choose_move(w, me, sample);
       if (w.gc.error) return 0;
+      if (w.analyse) {
+        co_analyse_finish(w, me, choice);
+        w.gc.plies++;
+        return 1;
+      }
       if (!w.testing) w.gc.n_samples++;
       co_trace_push(w, choice);
       w.gc.plies++;
@@ -1294,6 +1336,7 @@ CO_DEV void co_mcts_step_wave(const EngineParams &P, int g) {
   w.testing = P.testing;
   w.trace_on = P.trace_on && P.trace;
   w.defer_handover = P.defer_handover;
+  w.analyse = P.analyse;
   w.c_puct = P.c_puct;
   w.epsilon = P.epsilon;
   w.pc = P.pcfg ? P.pcfg + 2 * g : (const PlayerCfg *)0;

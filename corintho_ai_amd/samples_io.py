@@ -38,3 +38,24 @@ def load_samples(sample_folder):
         with np.load(os.path.join(sample_folder, name + ".npz")) as z:
             out.append(np.reshape(z["arr_0"], shape))
     return tuple(out)
+
+
+def samples_for_training(trainer, sample_folder, old_training_samples=(), mix_old=False):
+    """The whole of get_samples (main.pyx:189-219): fetch this generation's samples, save them, then walk the
+    replay window `old_training_samples` (folders of earlier generations, wrapper.py passes the last few).
+
+    The reference loads every old generation and calls np.concatenate on it -- and DISCARDS the result
+    (main.pyx:212-214), so what it returns, and trains on, is the current generation alone.  That is
+    reproduced by default (the old files are still opened, read and shape-checked like the reference does,
+    so a corrupt window fails here too).  mix_old=True returns what the code evidently meant: the current
+    samples followed by the window's."""
+    game_states, eval_labels, prob_labels = get_samples(trainer)
+    save_samples(sample_folder, game_states, eval_labels, prob_labels)
+    for cur_path in old_training_samples:
+        old_gs, old_ev, old_pr = load_samples(cur_path)
+        a = np.concatenate((game_states, old_gs))
+        b = np.concatenate((eval_labels, old_ev))
+        c = np.concatenate((prob_labels, old_pr))
+        if mix_old:
+            game_states, eval_labels, prob_labels = a, b, c
+    return game_states, eval_labels, prob_labels

@@ -40,7 +40,7 @@ def _f32(a, what):
 class Trainer:
     def __init__(self, num_games, log_folder="", seed=0, max_searches=1600, searches_per_eval=16, c_puct=1.0,
                  epsilon=0.25, num_logged=0, num_threads=1, testing=False, *, device=0, stagger=True, arena_units=0,
-                 trace=False, game_base=0, total_games=0, pools=0, _cdll=None):
+                 trace=False, game_base=0, total_games=0, pools=0, analyse=False, _cdll=None):
         self._L = _cdll if _cdll is not None else _lib.load()
         self._t = C.c_void_p()
         if num_logged:
@@ -49,7 +49,7 @@ class Trainer:
                             max_searches=max_searches, searches_per_eval=searches_per_eval, c_puct=c_puct,
                             epsilon=epsilon, num_logged=0, num_threads=num_threads, testing=int(bool(testing)),
                             device=device, no_stagger=int(not stagger), arena_units=arena_units, trace=int(bool(trace)),
-                            game_base=game_base, total_games=total_games, pools=pools)
+                            game_base=game_base, total_games=total_games, pools=pools, analyse=int(bool(analyse)))
         self.num_games = num_games
         self.searches_per_eval = searches_per_eval
         self.testing = bool(testing)
@@ -168,6 +168,20 @@ class Trainer:
         _lib.check(self._L, self._L.ca_trainer_pack_samples_device(self._t, C.c_void_p(d_state_policy_ptr),
                                                                    C.c_void_p(d_outcome_ptr), cap_rows, C.byref(n)))
         return n.value
+
+    # ---- analysis mode (N x DockerMC, dockermc.h:13-51) ----
+    def set_positions(self, boards, to_play, pieces, seeds):
+        b = np.ascontiguousarray(boards, dtype=np.int32).reshape(self.num_games, 64)
+        tp = np.ascontiguousarray(to_play, dtype=np.int32).reshape(self.num_games)
+        pc = np.ascontiguousarray(pieces, dtype=np.int32).reshape(self.num_games, 6)
+        sd = np.ascontiguousarray(seeds, dtype=np.int32).reshape(self.num_games)
+        p = lambda a: a.ctypes.data_as(_lib.i32p)  # noqa: E731
+        _lib.check(self._L, self._L.ca_trainer_set_positions(self._t, p(b), p(tp), p(pc), p(sd)))
+
+    def analysis(self):
+        out = np.zeros((self.num_games, 8), np.int32)
+        _lib.check(self._L, self._L.ca_trainer_analysis(self._t, out.ctypes.data_as(_lib.i32p)))
+        return out
 
     # ---- introspection ----
     def stats(self):

@@ -65,6 +65,9 @@ typedef struct ca_config {
   /* fused training: number of independent game pools run on separate HIP streams of the same
    * GPU (one pool's search overlaps another's network kernel); 0 = automatic */
   int32_t pools;
+  /* analysis mode (DockerMC, dockermc.h:13-51): every "game" is ONE position to search,
+   * given by ca_trainer_set_positions; testing is implied; a slot is finished by its first chooseMove */
+  int32_t analyse;
 } ca_config;
 
 const char *ca_last_error(void);
@@ -104,6 +107,22 @@ int ca_trainer_do_iteration(ca_trainer *t, const float *evaluations, const float
  * ca_trainer_destroy.  *pinned = 0 if the runtime refused (the calls still work, slower). */
 int ca_trainer_pin_host(ca_trainer *t, void *p, size_t bytes, int32_t *pinned);
 int ca_trainer_unpin_host(ca_trainer *t, void *p);
+
+/* ---------------- analysis of N positions (replaces N x `class DockerMC`, dockermc.h:13-51) ----------------
+ * A trainer created with ca_config.analyse = 1 searches num_games independent positions, one wavefront
+ * each -- what docker/choose_move.pyx does for one position with one DockerMC, batched.  Position i is the
+ * DockerMC constructor's (seed, board[64] (bit = cell*4 + {base, column, capital, frozen}), to_play,
+ * pieces[6]) (dockermc.cpp:11-19, game.cpp:14-26); max_searches, searches_per_eval, c_puct, epsilon come
+ * from ca_config.  Call once, before the first iteration.  Then either protocol applies: the reference's
+ * (ca_trainer_do_iteration / num_requests / write_requests with to_play = -1: DockerMC::doIteration /
+ * num_requests / writeRequests over all positions at once) or the fused one (ca_trainer_set_net +
+ * ca_trainer_run).  A position whose search is over has chosen its move (DockerMC::chooseMove). */
+int ca_trainer_set_positions(ca_trainer *t, const int32_t *boards /* [n][64] */, const int32_t *to_play /* [n] */,
+                             const int32_t *pieces /* [n][6] */, const int32_t *seeds /* [n] */);
+/* out[i] = {move (chooseMove; -1: the given position was already terminal), done (DockerMC::done of the
+ * position after the move), drawn (DockerMC::drawn), nodes (num_nodes), evaluation bits (float eval()),
+ * legal-move mask of the new position [3] (getLegalMoves)}: what choose_move.pyx:206-221 reads */
+int ca_trainer_analysis(ca_trainer *t, int32_t *out /* [n][8] */);
 
 /* ---------------- fused mode (no reference counterpart; opt-in) ----------------
  * The network runs on the device, so the play loop of main.pyx:123-187 never

@@ -1341,6 +1341,71 @@ void co_trainer_counters(const co_trainer *t, int64_t out[4]) {
   }
 }
 
+/* ================================================================== DockerMC
+ * ref: dockermc.h:13-51, dockermc.cpp:1-53 -- a TrainMC started from an arbitrary position
+ * (trainmc.cpp:38-45: testing = true, createRoot(Game{board, to_play, pieces}, 0)) that owns its
+ * generator and request buffer; the web app's single-position search (docker/choose_move.pyx). */
+struct co_dockermc {
+  co_mt19937 generator;
+  float *to_eval;
+  trainmc_t mc;
+  counters_t ctr;
+};
+
+/* ref: game.cpp:14-26 */
+co_dockermc *co_dockermc_create(int seed, int max_searches, int searches_per_eval, float c_puct, float epsilon,
+                                const int32_t board[64], int to_play, const int32_t pieces[6]) {
+  if (max_searches <= 0 || searches_per_eval <= 0) return NULL;
+  co_dockermc *d = (co_dockermc *)calloc(1, sizeof *d);
+  mt_seed(&d->generator, (uint32_t)seed);
+  d->to_eval = (float *)calloc((size_t)searches_per_eval * CO_GAME_STATE_SIZE, sizeof(float));
+  mc_init(&d->mc, &d->generator, d->to_eval, max_searches, searches_per_eval, c_puct, epsilon, 1, &d->ctr);
+  uint64_t b = 0;
+  for (int i = 0; i < 64; ++i)
+    if (board[i] != 0) b |= 1ull << i;
+  int8_t pc[6];
+  for (int i = 0; i < 6; ++i) pc[i] = (int8_t)pieces[i];
+  game_t g = make_game(b, pc, to_play);
+  mc_create_root(&d->mc, &g, 0);
+  return d;
+}
+
+void co_dockermc_destroy(co_dockermc *d) {
+  if (!d) return;
+  mc_free(&d->mc);
+  free(d->to_eval);
+  free(d);
+}
+
+/* ref: node.cpp:179-187 */
+static int32_t count_nodes(const node_t *n) {
+  int32_t counter = 1;
+  for (const node_t *c = n->first_child; c != NULL; c = c->next_sibling) counter += count_nodes(c);
+  return counter;
+}
+
+float co_dockermc_eval(const co_dockermc *d) { return d->mc.root->evaluation; }           /* trainmc.cpp:51-53 */
+int co_dockermc_num_requests(const co_dockermc *d) { return d->mc.n_searched; }          /* :55-57 */
+int co_dockermc_num_nodes(const co_dockermc *d) { return d->mc.root ? count_nodes(d->mc.root) : 0; } /* :67-72 */
+int co_dockermc_done(const co_dockermc *d) { return n_terminal(d->mc.root); }            /* :74-76 */
+int co_dockermc_drawn(const co_dockermc *d) { return n_drawn(d->mc.root); }              /* :78-80 */
+/* ref: trainmc.cpp:89-94 */
+void co_dockermc_write_requests(const co_dockermc *d, float *game_states) {
+  for (int i = 0; i < d->mc.n_searched; ++i) write_game_state(&d->mc.searched[i]->game, game_states + (size_t)i * CO_GAME_STATE_SIZE);
+}
+/* ref: trainmc.cpp:96-108 */
+void co_dockermc_get_legal_moves(const co_dockermc *d, int32_t legal_moves[CO_NUM_MOVES]) {
+  mask96 legal;
+  get_legal_moves(&d->mc.root->game, &legal);
+  for (int i = 0; i < CO_NUM_MOVES; ++i) legal_moves[i] = m_test(&legal, i) ? 1 : 0;
+}
+/* ref: dockermc.cpp:47-49 (TrainMC::chooseMove with null sample pointers: testing_ is true) */
+int co_dockermc_choose_move(co_dockermc *d) { return mc_choose_move(&d->mc, NULL, NULL); }
+/* ref: dockermc.cpp:51-53 */
+int co_dockermc_do_iteration(co_dockermc *d, const float *eval, const float *probs) {
+  return mc_do_iteration(&d->mc, eval, probs);
+}
+
 /* ================================================================== Match / Tourney
  * The "next" row of SURVEY 8f.1: tournaments between any number of models
  * (ref: match.h:13-103, match.cpp, tourney.h, tourney.cpp; Python driver rating/tourney.pyx). */

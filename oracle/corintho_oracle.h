@@ -102,6 +102,21 @@ int co_trainer_trace(const co_trainer *t, int game, int32_t *out, int cap);
 /* counters summed over games: [searches, leaf_evals, nodes_created, plies] */
 void co_trainer_counters(const co_trainer *t, int64_t out[4]);
 
+/* ---- DockerMC (dockermc.h:13-51): single-position search from an arbitrary position ---- */
+typedef struct co_dockermc co_dockermc;
+co_dockermc *co_dockermc_create(int seed, int max_searches, int searches_per_eval, float c_puct, float epsilon,
+                                const int32_t board[64], int to_play, const int32_t pieces[6]);
+void co_dockermc_destroy(co_dockermc *d);
+float co_dockermc_eval(const co_dockermc *d);
+int co_dockermc_num_requests(const co_dockermc *d);
+int co_dockermc_num_nodes(const co_dockermc *d);
+int co_dockermc_done(const co_dockermc *d);
+int co_dockermc_drawn(const co_dockermc *d);
+void co_dockermc_write_requests(const co_dockermc *d, float *game_states);
+void co_dockermc_get_legal_moves(const co_dockermc *d, int32_t legal_moves[CO_NUM_MOVES]);
+int co_dockermc_choose_move(co_dockermc *d);
+int co_dockermc_do_iteration(co_dockermc *d, const float *eval, const float *probs);
+
 /* ---- Match / Tourney (match.h, tourney.h:13-46) ---- */
 typedef struct co_tourney co_tourney;
 co_tourney *co_tourney_create(int num_threads);

@@ -87,6 +87,19 @@ def lib():
     L.co_trainer_trace.restype = C.c_int
     L.co_trainer_counters.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
     vp = C.c_void_p
+    L.co_dockermc_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, i32p, C.c_int, i32p]
+    L.co_dockermc_create.restype = vp
+    L.co_dockermc_destroy.argtypes = [vp]
+    L.co_dockermc_eval.argtypes = [vp]
+    L.co_dockermc_eval.restype = C.c_float
+    for name in ("num_requests", "num_nodes", "done", "drawn", "choose_move"):
+        fn = getattr(L, "co_dockermc_" + name)
+        fn.argtypes = [vp]
+        fn.restype = C.c_int
+    L.co_dockermc_write_requests.argtypes = [vp, f32p]
+    L.co_dockermc_get_legal_moves.argtypes = [vp, i32p]
+    L.co_dockermc_do_iteration.argtypes = [vp, f32p, f32p]
+    L.co_dockermc_do_iteration.restype = C.c_int
     L.co_tourney_create.argtypes = [C.c_int]
     L.co_tourney_create.restype = vp
     L.co_tourney_destroy.argtypes = [vp]
@@ -301,6 +314,60 @@ class Trainer:
         out = (C.c_int64 * 4)()
         lib().co_trainer_counters(self._t, out)
         return {"searches": out[0], "leaf_evals": out[1], "nodes_created": out[2], "plies": out[3]}
+
+
+class DockerMC:
+    """Same surface as the reference DockerMC (dockermc.h:13-51, docker/choose_move.pyx:21-42)."""
+
+    def __init__(self, seed, max_searches, searches_per_eval, c_puct, epsilon, board, to_play, pieces):
+        b = np.ascontiguousarray(board, dtype=np.int32)
+        p = np.ascontiguousarray(pieces, dtype=np.int32)
+        assert b.size == 64 and p.size == 6
+        i32p = C.POINTER(C.c_int32)
+        self.searches_per_eval = searches_per_eval
+        self._d = lib().co_dockermc_create(seed, max_searches, searches_per_eval, c_puct, epsilon, b.ctypes.data_as(i32p),
+                                           to_play, p.ctypes.data_as(i32p))
+        if not self._d:
+            raise ValueError("bad DockerMC arguments")
+
+    def __del__(self):
+        try:
+            if self._d:
+                lib().co_dockermc_destroy(self._d)
+                self._d = None
+        except Exception:
+            pass
+
+    def eval(self):
+        return float(lib().co_dockermc_eval(self._d))
+
+    def num_requests(self):
+        return lib().co_dockermc_num_requests(self._d)
+
+    def num_nodes(self):
+        return lib().co_dockermc_num_nodes(self._d)
+
+    def done(self):
+        return bool(lib().co_dockermc_done(self._d))
+
+    def drawn(self):
+        return bool(lib().co_dockermc_drawn(self._d))
+
+    def writeRequests(self, game_states):
+        lib().co_dockermc_write_requests(self._d, _f32(game_states))
+
+    def getLegalMoves(self):
+        out = np.zeros(96, np.int32)
+        lib().co_dockermc_get_legal_moves(self._d, out.ctypes.data_as(C.POINTER(C.c_int32)))
+        return out
+
+    def chooseMove(self):
+        return lib().co_dockermc_choose_move(self._d)
+
+    def doIteration(self, evaluations=None, probabilities=None):
+        e = _f32(evaluations) if evaluations is not None else None
+        p = _f32(probabilities) if probabilities is not None else None
+        return bool(lib().co_dockermc_do_iteration(self._d, e, p))
 
 
 class Tourney:

@@ -80,6 +80,34 @@ def test_cpp_trainer_plays_a_generation_equal_to_the_oracle(engine, testing, tmp
     assert open(prefix + ".scores.txt", "rb").read() == open(fo, "rb").read()
 
 
+@pytest.mark.parametrize("engine", ENGINES)
+def test_cpp_dockermc_chooses_the_oracles_moves(engine, tmp_path):
+    """`class DockerMC` (corintho_ai_amd/cpp/dockermc.h = dockermc.h:13-51) driven from C++ by the loop of
+    docker/choose_move.pyx: move, done / drawn, node count, evaluation and legal moves equal the oracle's DockerMC"""
+    from tests.test_analyse import _oracle_result, _positions
+
+    libdir, libname = _lib_for(engine)
+    exe = str(tmp_path / ("dockermc_driver_" + engine))
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-o", exe, os.path.join(ROOT, "tests", "cxx", "dockermc_driver.cpp"),
+                           "-L" + libdir, "-l" + libname, "-Wl,-rpath," + libdir, "-fopenmp"])
+    n, S_, spe = 10, 60, 8
+    boards, tp, pc = _positions(n, seed=77)
+    seeds = [11 * i + 5 for i in range(n)]
+    text = "".join("%d %d %s %s\n" % (seeds[i], tp[i], " ".join(map(str, pc[i])), " ".join(map(str, boards[i]))) for i in range(n))
+    out = subprocess.run([exe, str(S_), str(spe)], input=text.encode(), stdout=subprocess.PIPE, check=True).stdout.decode().split("\n")
+    for i in range(n):
+        want, _ = _oracle_result(boards[i], tp[i], pc[i], seeds[i], S_, spe, H.hash_net)
+        if "pre-result" in want:
+            assert out[i] == "pre " + want["pre-result"]
+            continue
+        move, done, drawn, nodes, eb, m0, m1, m2 = [int(x) for x in out[i].split()]
+        mask = m0 | (m1 << 32) | (m2 << 64)
+        assert move == want["move"] and bool(done) == want["is_done"] and nodes == want["nodes_searched"]
+        assert bool(done and not drawn) == want["has_won"]
+        assert [j for j in range(96) if mask >> j & 1] == (want["legal_moves"] if not done else [j for j in range(96) if mask >> j & 1])
+        assert np.array([eb], np.uint32).view(np.float32)[0] == np.float32(want["eval_sum"])
+
+
 def test_reference_main_pyx_compiles_against_this_trainer(tmp_path):
     """main.pyx:17 `cdef extern from "../cpp/src/trainer.cpp"` -> this repository's trainer.cpp; everything
     else of the reference's Cython module unchanged.  Cythonize + compile + link (python/setup.py:15-38 flags)."""
