@@ -121,29 +121,29 @@ def read_tflite(path_or_bytes):
     return {"tensors": tensors, "ops": ops, "inputs": sg.ints(1), "outputs": sg.ints(2)}
 
 
-def tflite_forward_np(model, states):
-    """Evaluates the operators of `model` (read_tflite) as stored, in float32 numpy: the check
-    of the import (tests) -- FULLY_CONNECTED (+ fused ReLU), TANH, SOFTMAX only.
-    Returns {output tensor index: array}."""
+def tflite_forward_np(model, states, dtype=np.float32):
+    """Evaluates the operators of `model` (read_tflite) as stored, in numpy at `dtype` (float32 = what the
+    TFLite runtime computes; float64 = the yardstick of the precision tests): the check of the import
+    (tests) -- FULLY_CONNECTED (+ fused ReLU), TANH, SOFTMAX only.  Returns {output tensor index: array}."""
     T = model["tensors"]
-    val = {model["inputs"][0]: np.asarray(states, np.float32)[:, :nets.GAME_STATE_SIZE]}
+    val = {model["inputs"][0]: np.asarray(states, np.float32)[:, :nets.GAME_STATE_SIZE].astype(dtype)}
     for op in model["ops"]:
         x = val[op["inputs"][0]]
         if op["code"] == OP_FULLY_CONNECTED:
-            w = T[op["inputs"][1]]["data"]  # [out, in]
-            y = (x @ w.T).astype(np.float32)
+            w = T[op["inputs"][1]]["data"].astype(dtype)  # [out, in]
+            y = (x @ w.T).astype(dtype)
             if len(op["inputs"]) > 2 and op["inputs"][2] >= 0:
-                y = (y + T[op["inputs"][2]]["data"].reshape(1, -1)).astype(np.float32)
+                y = (y + T[op["inputs"][2]]["data"].astype(dtype).reshape(1, -1)).astype(dtype)
             if op["activation"] == ACT_RELU:
                 y = np.maximum(y, 0.0)
             elif op["activation"] != ACT_NONE:
                 raise TFLiteFormatError("unsupported fused activation %d" % op["activation"])
         elif op["code"] == OP_TANH:
-            y = np.tanh(x).astype(np.float32)
+            y = np.tanh(x).astype(dtype)
         elif op["code"] == OP_SOFTMAX:
             z = x - x.max(axis=1, keepdims=True)
-            e = np.exp(z).astype(np.float32)
-            y = (e / e.sum(axis=1, keepdims=True)).astype(np.float32)
+            e = np.exp(z).astype(dtype)
+            y = (e / e.sum(axis=1, keepdims=True)).astype(dtype)
         else:
             raise TFLiteFormatError("unsupported operator %d" % op["code"])
         val[op["outputs"][0]] = y

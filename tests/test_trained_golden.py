@@ -1,0 +1,79 @@
+"""Network kernels on TRAINED weights: three of the reference's checkpoints
+(corintho_ai/rating/tflite_models/model_{3,47,93}.tflite), committed as data by
+tools/gen_trained_golden.py (imported flat weights, 256 positions met in play, the stored TFLite graph
+evaluated in float64).  Random-init weights keep activations O(1) and logits flat; a trained network
+has sharp priors (entropy 2.2 nats, max prior 0.3) and values near +-1 -- the regime in which a
+narrow product would show.  Policy/value within the north-star's 1e-4 of the float64 evaluation for
+every arithmetic width, and the float32-equivalent kinds no worse than twice the fp32-MFMA kernel."""
+import os
+
+import numpy as np
+import pytest
+
+from corintho_ai_amd import NET_MLP12X100, NET_MLP12X100_X3, NET_MLP12X100_X6, nets
+from oracle import oracle as O
+from tests import harness as H
+from tests.engines import ENGINES, make_trainer
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TAGS = ("early", "middle", "last")
+
+
+def load(tag):
+    with np.load(os.path.join(GOLDEN, "trained_%s.npz" % tag)) as z:
+        return {k: z[k] for k in z.files}
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_float64_restatement_reproduces_the_stored_graph(tag):
+    """CPU: the engine's weight layout evaluated in float64 is the checkpoint's graph in float64, and the
+    float32 restatement is within float32 rounding of it"""
+    z = load(tag)
+    v, p = nets.mlp12x100_forward_f64(z["weights"], z["states"])
+    assert np.max(np.abs(v - z["value_f64"])) < 2e-6 and np.max(np.abs(p - z["policy_f64"])) < 2e-6
+    v32, p32 = nets.mlp12x100_forward_np(z["weights"], z["states"])
+    assert np.max(np.abs(v32 - z["value_f64"])) < 2e-5 and np.max(np.abs(p32 - z["policy_f64"])) < 2e-5
+
+
+@pytest.mark.parametrize("engine", ENGINES)
+@pytest.mark.parametrize("tag", TAGS)
+def test_fp32_kernel_on_trained_weights(engine, tag):
+    z = load(tag)
+    t = make_trainer(engine, 16, "", 1, 50, 16, 1.0, 0.25, 0, 1, False)
+    t.set_net(NET_MLP12X100, z["weights"])
+    ev, pr = t.net_forward(z["states"])
+    assert np.max(np.abs(ev - z["value_f64"])) < 1e-4
+    assert np.max(np.abs(pr - z["policy_f64"])) < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", TAGS)
+def test_split_precision_kernels_on_trained_weights(tag):
+    z = load(tag)
+    t = make_trainer("hip", 16, "", 1, 50, 16, 1.0, 0.25, 0, 1, False)
+    err = {}
+    for name, kind in (("fp32", NET_MLP12X100), ("bf16x6", NET_MLP12X100_X6), ("bf16x3", NET_MLP12X100_X3)):
+        t.set_net(kind, z["weights"])
+        ev, pr = t.net_forward(z["states"])
+        err[name] = (float(np.max(np.abs(ev - z["value_f64"]))), float(np.max(np.abs(pr - z["policy_f64"]))))
+        assert err[name][0] < 1e-4 and err[name][1] < 1e-4, (name, err[name])
+    print("%s (%s): |err| vs float64 (value, policy): %s" % (tag, z["checkpoint"], err))
+    assert err["bf16x6"][0] <= 2 * err["fp32"][0] + 2.4e-7 and err["bf16x6"][1] <= 2 * err["fp32"][1] + 2.4e-7
+    assert err["bf16x6"][0] < 5e-6 and err["bf16x6"][1] < 5e-6
+
+
+@pytest.mark.gpu
+def test_generation_with_a_trained_checkpoint_at_bf16x6_replays_on_the_oracle():
+    """a trained network plays differently from a random one (sharp priors, solved lines): a fused
+    generation driven by the last checkpoint at float32-equivalent precision is replayed move for move"""
+    z = load("last")
+    G, S_, spe = 32, 120, 16
+    f = make_trainer("hip", G, "", 4242, S_, spe, 1.0, 0.25, 0, 1, False, stagger=False)
+    f.set_net(NET_MLP12X100_X6, z["weights"])
+    assert f.run()
+    o = O.Trainer(G, seed=4242, max_searches=S_, searches_per_eval=spe, num_threads=8)
+    o.set_stagger(False)
+    H.play_generation(o, G, spe, lambda s: f.net_forward(s))
+    for x, y in zip(H.get_samples(f), H.get_samples(o)):
+        assert x.tobytes() == y.tobytes()
+    assert f.score() == o.score() and f.avg_mate_length() == o.avg_mate_length()
