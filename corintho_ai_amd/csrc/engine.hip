@@ -109,7 +109,7 @@ struct ca_trainer {
   DevBuf<GameCtl> games;
   DevBuf<TreeCtl> trees;
   DevBuf<uint4> arena;
-  DevBuf<uint32_t> pend_leaf, pend_path, rng;
+  DevBuf<uint32_t> pend_leaf, pend_path, pend_n, noise_raw, rng;
   DevBuf<int32_t> pend_depth, req_offset, trace, all_done;
   DevBuf<float> req, nn_in, nn_in70, nn_eval, nn_probs, samples;
   DevBuf<unsigned long long> row_counter, pack_counter, prof;
@@ -228,6 +228,8 @@ struct ca_trainer {
     arena.alloc(T * ((size_t)cap + CO_ARENA_PAD));
     pend_leaf.alloc((size_t)G * spe);
     pend_depth.alloc((size_t)G * spe);
+    pend_n.alloc((size_t)G * spe);
+    noise_raw.alloc((size_t)G * spe * CO_NUM_MOVES);
     pend_path.alloc((size_t)G * spe * CO_PATH_MAX);
     rng.alloc((size_t)G * CO_MT_N);
     req.alloc((size_t)G * spe * CO_STATE_STRIDE);
@@ -347,6 +349,8 @@ struct ca_trainer {
     P.arena = arena.p;
     P.pend_leaf = pend_leaf.p;
     P.pend_depth = pend_depth.p;
+    P.pend_n = pend_n.p;
+    P.noise_raw = noise_raw.p;
     P.pend_path = pend_path.p;
     P.rng = rng.p;
     P.req = req.p;
@@ -362,6 +366,7 @@ struct ca_trainer {
     P.row_counter = nullptr; /* counted in fused mode only */
     P.fused_pack = 0;
     P.defer_handover = 0;
+    P.sim_cap = 0;
     P.pool_lo = 0;
     P.pool_n = G;
     P.pool_row_base = 0;
@@ -430,6 +435,7 @@ struct ca_trainer {
     }
     P.to_play = to_play;
     P.iteration = trainer_iteration;
+    RT_LAUNCH(co_k_priors, ((G) * P.searches_per_eval + CO_WAVES_PER_BLOCK - 1) / CO_WAVES_PER_BLOCK, CO_WAVE * CO_WAVES_PER_BLOCK, stream, P);
     RT_LAUNCH(co_k_mcts_step, G, CO_WAVE, stream, P);
     if (to_play == -1) ++trainer_iteration;
     ++iterations;
@@ -479,6 +485,7 @@ struct ca_trainer {
       rt_h2d(nn_probs.p, probs, (size_t)rows * CO_NUM_MOVES * 4, stream);
     }
     P.iteration = trainer_iteration;
+    RT_LAUNCH(co_k_priors, ((G) * P.searches_per_eval + CO_WAVES_PER_BLOCK - 1) / CO_WAVES_PER_BLOCK, CO_WAVE * CO_WAVES_PER_BLOCK, stream, P);
     RT_LAUNCH(co_k_mcts_step, G, CO_WAVE, stream, P);
     ++iterations;
     ++mcts_launches;
@@ -794,6 +801,7 @@ struct ca_trainer {
          * iterations of the longest game is what the generation waits for.  Per-game results do
          * not depend on the choice. */
         pp.defer_handover = q.running * 2 > q.n ? 1 : 0;
+        pp.sim_cap = pp.defer_handover ? spe + spe / 4 : 0; /* same reasoning: only while the launches are full */
         pp.pool_lo = q.lo;
         pp.pool_n = q.n;
         pp.pool_row_base = q.row_base;
@@ -801,6 +809,7 @@ struct ca_trainer {
         const bool timed = in_window == poll - 1 || (max_iterations > 0 && it + 1 == max_iterations);
         rt_event_t *e = q.ev[parity];
         if (timed) rt_event_record(e[0], q.st);
+        RT_LAUNCH(co_k_priors, ((q.n) * pp.searches_per_eval + CO_WAVES_PER_BLOCK - 1) / CO_WAVES_PER_BLOCK, CO_WAVE * CO_WAVES_PER_BLOCK, q.st, pp);
         RT_LAUNCH(co_k_mcts_step, q.n, CO_WAVE, q.st, pp);
         if (timed) rt_event_record(e[1], q.st);
         const int32_t *d_rows = (const int32_t *)(pack_counter.p + 2 * p + (trainer_iteration & 1));
@@ -894,6 +903,7 @@ struct ca_trainer {
       P.scan_phase = 0;
       RT_LAUNCH(co_k_scan, 1, CO_WAVE, stream, P); /* offsets at entry (trainer.cpp:208-215) */
       if (timed) rt_event_record(ev[0], stream);
+      RT_LAUNCH(co_k_priors, ((G) * P.searches_per_eval + CO_WAVES_PER_BLOCK - 1) / CO_WAVES_PER_BLOCK, CO_WAVE * CO_WAVES_PER_BLOCK, stream, P);
       RT_LAUNCH(co_k_mcts_step, G, CO_WAVE, stream, P);
       if (timed) rt_event_record(ev[1], stream);
       P.scan_phase = 1;
@@ -1078,6 +1088,7 @@ struct ca_tourney {
           nets[id]->forward(p.nn_in.p, p.G * p.spe, p.req_offset.p + p.G, p.nn_eval.p, p.nn_probs.p, p.stream);
           ++p.nn_launches;
         }
+        RT_LAUNCH(co_k_priors, ((p.G) * p.P.searches_per_eval + CO_WAVES_PER_BLOCK - 1) / CO_WAVES_PER_BLOCK, CO_WAVE * CO_WAVES_PER_BLOCK, p.stream, p.P);
         RT_LAUNCH(co_k_mcts_step, p.G, CO_WAVE, p.stream, p.P);
         ++p.mcts_launches;
         ++p.iterations;

@@ -17,6 +17,26 @@ CO_KERNEL co_k_mcts_step(EngineParams P) {
   if (CO_BLOCK_IDX < P.pool_n && g < P.num_games) co_mcts_step_wave(P, g);
 }
 
+/* K2b: the priors of every pending leaf whose evaluation this launch consumes -- one wavefront per
+ * (game, pending leaf), before the search kernel (mcts.h "receiveEval, split in two").
+ * getFilteredProbs + generateDirichlet + setProbs, trainmc.cpp:212-267. */
+CO_KERNEL co_k_priors(EngineParams P) {
+  const int spe = P.searches_per_eval;
+  const int unit = CO_BLOCK_IDX * CO_WAVES_PER_BLOCK + CO_WAVE_IN_BLOCK; /* (game of the pool, pending leaf) */
+  const int g = P.pool_lo + unit / spe, k = unit % spe;
+  if (unit / spe >= P.pool_n || g >= P.num_games) return;
+  GameCtl gc = P.games[g];
+  if (co_step_gate(P, g, gc) != 1 || k >= gc.n_pending || gc.resume == 2) return; /* a cut step has nothing to consume */
+  const size_t stride = (size_t)P.cap_units + CO_ARENA_PAD;
+  uint4 *A = P.arena + (size_t)(2 * g + gc.to_play) * stride; /* the mover's tree holds the pending leaves */
+  const uint32_t leaf = P.pend_leaf[(size_t)g * spe + k];
+  const uint32_t pn = P.pend_n[(size_t)g * spe + k];
+  const int row = co_step_row(P, g, gc) + k;
+  const float eps = P.pcfg ? P.pcfg[2 * g + gc.to_play].epsilon : P.epsilon; /* match.h:13-31: per-side settings */
+  co_prior_leaf(A, leaf, P.nn_probs + (size_t)row * CO_NUM_MOVES,
+                P.noise_raw + (size_t)g * spe * CO_NUM_MOVES + (pn >> 8), eps);
+}
+
 /* is game g part of the batch of model `tp` (trainer.cpp:42-46, 84-98)? */
 CO_DEV int co_game_active(const EngineParams &P, int g, const GameCtl &gc, int tp) {
   if (gc.done) return 0;

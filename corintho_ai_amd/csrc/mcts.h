@@ -51,12 +51,16 @@ struct CoWave {
   uint32_t *pend_leaf;
   int32_t *pend_depth;
   uint32_t *pend_path;
+  uint32_t *pend_n;
+  uint32_t *noise_raw;
+  int noise_words; /* generator outputs owed to the leaves queued so far in this step */
   float *req;
   float *samples;
   int32_t *trace;
   unsigned long long *prof;
   /* config */
-  int max_searches, spe, testing, trace_on, defer_handover, analyse;
+  int max_searches, spe, testing, trace_on, defer_handover, analyse, sim_cap;
+  int held; /* this step continues one that was cut at the simulation cap: nothing to receive */
   float c_puct, epsilon;
   const PlayerCfg *pc; /* tournament match: the two players' settings, else null */
 };
@@ -109,13 +113,14 @@ CO_DEV void co_trace_push(CoWave &w, int32_t v) {
  * that carries its own stat slot.  Returns the block offset (CO_NONE on arena
  * overflow); *res_out = kResultLoss / kResultDraw / kResultNone. */
 CO_DEV uint32_t co_create_node(CoWave &w, CoTree &t, uint64_t board, uint32_t meta_game, int depth, uint32_t parent,
-                               uint32_t self_slot, int *res_out) {
+                               uint32_t self_slot, int *res_out, int *n_out = (int *)0) {
   uint32_t lm[3];
   int is_lines = co_legal_moves(board, meta_game, lm);
   int n = co_popc32(lm[0]) + co_popc32(lm[1]) + co_popc32(lm[2]);
   int res = CO_RESULT_NONE;
   if (n == 0) res = is_lines ? CO_RESULT_LOSS : CO_RESULT_DRAW;
   *res_out = res;
+  if (n_out) *n_out = n;
   uint32_t units = 2u + (uint32_t)n + (self_slot == CO_NONE ? 1u : 0u);
   if (t.tc.units_used + units > t.cap) {
     w.gc.error |= CO_ERR_ARENA_FULL;
@@ -152,14 +157,18 @@ CO_DEV uint32_t co_create_node(CoWave &w, CoTree &t, uint64_t board, uint32_t me
 
 /* A leaf asks for a network evaluation: TrainMC writes the state into to_eval_
  * and records the node in searched_ (trainmc.cpp:684-692, 150-153). */
-CO_DEV void co_request(CoWave &w, uint64_t board, uint32_t meta, uint32_t leaf, int D, const uint32_t *path_slot) {
+CO_DEV void co_request(CoWave &w, uint64_t board, uint32_t meta, uint32_t leaf, int n_edges, int D,
+                       const uint32_t *path_slot) {
   int k = w.gc.n_pending;
   co_write_state(board, meta, w.req + (size_t)k * CO_STATE_STRIDE);
   uint32_t *pp = w.pend_path + (size_t)k * CO_PATH_MAX;
+  const uint32_t pn = ((uint32_t)w.noise_words << 8) | (uint32_t)n_edges;
+  w.noise_words += n_edges; /* one generator output per legal move (trainmc.cpp:236-246) */
   FOR_LANES {
     if (lane == 0) {
       w.pend_leaf[k] = leaf;
       w.pend_depth[k] = D;
+      w.pend_n[k] = pn;
     }
     if (lane <= D && lane < CO_PATH_MAX) pp[lane] = path_slot[lane];
   }
@@ -167,48 +176,97 @@ CO_DEV void co_request(CoWave &w, uint64_t board, uint32_t meta, uint32_t leaf, 
   w.gc.n_pending = k + 1;
 }
 
-/* receiveEval for one pending leaf: getFilteredProbs (trainmc.cpp:212-234),
- * generateDirichlet (:236-246), setProbs (:248-267), backup (:280-295). */
-CO_DEV void co_receive_one(CoWave &w, CoTree &t, int k, float leaf_eval, const float *probs) {
-  uint4 *A = t.A;
-  uint32_t leaf = w.pend_leaf[k];
-  int D = w.pend_depth[k];
-  const uint32_t *pp = w.pend_path + (size_t)k * CO_PATH_MAX;
+/* ---- receiveEval (trainmc.cpp:269-296), split in two.
+ *
+ * What a leaf's evaluation does to the tree has two parts.  (1) The leaf's own priors:
+ * getFilteredProbs (trainmc.cpp:212-234), generateDirichlet (:236-246), setProbs (:248-267) -- a
+ * function of the network's row for that leaf, of the leaf's legal moves and of the generator
+ * outputs owed to it, and of nothing else.  (2) The backup of the value along the path to the root
+ * (:280-295), which touches slots shared with other leaves and must run in request order.
+ * Round 1 ran both inside the game's wavefront, leaf after leaf: 37 % of the search kernel's wave
+ * cycles, serial per game, with ~28 of 64 lanes busy.  Part (1) is independent per LEAF: it is its
+ * own kernel now (co_k_priors, kernels.h: one wavefront per pending leaf of every game that steps in
+ * this launch, tens of thousands at once), run right before the search kernel; the game's wavefront
+ * keeps part (2) only.
+ *
+ * The generator: a game's two searchers share one std::mt19937 (selfplayer.cpp:23-28) and the
+ * reference draws a leaf's noise when the leaf's evaluation is received.  Between queueing a leaf
+ * and receiving its evaluation the game draws nothing else (a move is only chosen with no request
+ * pending, trainmc.cpp:139-178), so the outputs a leaf will consume are fixed when it is queued:
+ * co_capture_noise copies them (raw state words, tempered by the consumer) into the game's noise
+ * buffer at the end of the step and advances the generator -- the stream is consumed in the
+ * reference's order, leaf by leaf in request order. */
+
+/* the generator outputs owed to the leaves queued in this step -> noise_raw[0 .. noise_words) */
+CO_DEV void co_capture_noise(CoWave &w) {
+  int done = 0;
+  const int total = w.noise_words;
+  while (done < total) {
+    if (w.gc.rng_idx >= CO_MT_N) {
+      co_mt_twist(w.mt);
+      w.gc.rng_idx = 0;
+    }
+    int cnt = total - done;
+    if (cnt > CO_MT_N - w.gc.rng_idx) cnt = CO_MT_N - w.gc.rng_idx;
+    const uint32_t *src = w.mt + w.gc.rng_idx;
+    uint32_t *dst = w.noise_raw + done;
+    FOR_LANES {
+      for (int i = lane; i < cnt; i += CO_WAVE) dst[i] = src[i];
+    }
+    WAVE_SYNC();
+    w.gc.rng_idx += cnt;
+    done += cnt;
+  }
+}
+
+/* Part (1) for ONE leaf, one wavefront: lanes = edges (two per lane beyond 64).  A = the leaf's tree,
+ * probs = the network's 96 priors of the leaf's row, raw = the leaf's generator outputs.  The two sums
+ * are sequential float additions in edge order, as the reference's loops. */
+CO_DEV void co_prior_leaf(uint4 *A, uint32_t leaf, const float *probs, const uint32_t *raw, float epsilon) {
   uint4 h0 = co_load_unit(A, leaf);
-  int n = (int)CO_META_NEDGES(h0.z);
-  WAVE_SHARED(float, fp, CO_NUM_MOVES);  /* filtered priors, then weights */
-  WAVE_SHARED(float, dn, CO_NUM_MOVES);  /* dirichlet */
-  WAVE_SHARED(uint32_t, mz, CO_NUM_MOVES); /* slot.z of every edge */
-  /* gather priors of the legal moves (edge order = ascending move id) */
-  for (int base = 0; base < n; base += CO_WAVE) {
-    FOR_LANES {
-      int e = base + lane;
-      if (e < n) {
-        uint32_t z = A[leaf + 2 + e].z;
-        mz[e] = z;
-        fp[e] = probs[z & 127u];
-      }
+  const int n = (int)CO_META_NEDGES(h0.z);
+  LV(uint32_t, z0);
+  LV(uint32_t, z1);
+  LV(float, fp0); /* filtered priors: edge `lane` and edge `lane + 64` */
+  LV(float, fp1);
+  LV(float, dn0); /* dirichlet */
+  LV(float, dn1);
+  FOR_LANES {
+    L(z0) = 0u;
+    L(z1) = 0u;
+    L(fp0) = L(fp1) = L(dn0) = L(dn1) = 0.0f;
+    /* unconditional loads (lanes beyond n read edge 0 / prior 0 / word 0), so that the three dependent
+     * fetches of all lanes are in flight together */
+    const int e0 = lane < n ? lane : 0;
+    const uint32_t m0 = A[leaf + 2 + e0].z & 127u; /* a leaf awaiting its evaluation has no children: the word is the move id */
+    const uint32_t r0 = raw[e0];
+    const float p0 = probs[m0 < (uint32_t)CO_NUM_MOVES ? m0 : 0u];
+    const float g0 = co_u2f(CO_GAMMA_BITS[co_mt_temper(r0) % CO_NUM_GAMMA]);
+    if (lane < n) {
+      L(z0) = m0;
+      L(fp0) = p0;
+      L(dn0) = g0;
+    }
+    if (lane + CO_WAVE < n) {
+      L(z1) = A[leaf + 2 + lane + CO_WAVE].z & 127u;
+      L(fp1) = probs[L(z1)];
+      L(dn1) = co_u2f(CO_GAMMA_BITS[co_mt_temper(raw[lane + CO_WAVE]) % CO_NUM_GAMMA]);
     }
   }
-  /* noise: one 32-bit draw per legal move, in edge order */
-  for (int base = 0; base < n; base += CO_WAVE) {
-    int cnt = n - base < CO_WAVE ? n - base : CO_WAVE;
-    LV(uint32_t, r);
-    CO_MT_DRAW(w.mt, w.gc.rng_idx, cnt, r);
-    FOR_LANES {
-      if (lane < cnt) dn[base + lane] = co_u2f(CO_GAMMA_BITS[L(r) % CO_NUM_GAMMA]);
-    }
-  }
-  WAVE_SYNC();
-  /* the two sums are sequential float additions in edge order */
+  /* sequential float additions in edge order (trainmc.cpp:219-229, 238-241): lane broadcasts, no memory */
   float sum = 0.0f, dsum = 0.0f;
-  for (int e = 0; e < n; ++e) {
-    sum += fp[e];
-    dsum += dn[e];
+  const int n0 = n < CO_WAVE ? n : CO_WAVE;
+  for (int e = 0; e < n0; ++e) {
+    sum += WAVE_BCAST(fp0, e);
+    dsum += WAVE_BCAST(dn0, e);
   }
-  float one_minus = (float)1 - w.epsilon;
+  for (int e = CO_WAVE; e < n; ++e) {
+    sum += WAVE_BCAST(fp1, e - CO_WAVE);
+    dsum += WAVE_BCAST(dn1, e - CO_WAVE);
+  }
+  float one_minus = (float)1 - epsilon;
   float scalar = (float)(1.0 / (double)sum * (double)one_minus);
-  float dscalar = (float)(1.0 / (double)dsum * (double)w.epsilon);
+  float dscalar = (float)(1.0 / (double)dsum * (double)epsilon);
   LV(float, wt0);
   LV(float, wt1);
   LV(float, mxl);
@@ -217,20 +275,20 @@ CO_DEV void co_receive_one(CoWave &w, CoTree &t, int k, float leaf_eval, const f
     L(wt0) = 0.0f;
     L(wt1) = 0.0f;
     if (lane < n) {
-      float a = fp[lane] * scalar;
-      float d = dn[lane] * dscalar;
+      float a = L(fp0) * scalar;
+      float d = L(dn0) * dscalar;
       L(wt0) = a + d;
       m = L(wt0) > m ? L(wt0) : m;
     }
     if (lane + CO_WAVE < n) {
-      float a = fp[lane + CO_WAVE] * scalar;
-      float d = dn[lane + CO_WAVE] * dscalar;
+      float a = L(fp1) * scalar;
+      float d = L(dn1) * dscalar;
       L(wt1) = a + d;
       m = L(wt1) > m ? L(wt1) : m;
     }
     L(mxl) = m;
   }
-  float max_prob = WAVE_MAX_F32(mxl);
+  float max_prob = WAVE_MAX_F32(mxl); /* weights are >= 0, as the reference's max_prob start value */
   float denom = 511.0f / max_prob;
   LV(int, qs);
   FOR_LANES {
@@ -245,8 +303,7 @@ CO_DEV void co_receive_one(CoWave &w, CoTree &t, int k, float leaf_eval, const f
         if (x - fl >= 0.5f) q += 1;
         if (!(q >= 1)) q = 1;
         s += q;
-        uint32_t z = mz[e];
-        A[leaf + 2 + e].z = (z & 0xFFFF007Fu) | ((uint32_t)(q & 511) << 7);
+        A[leaf + 2 + e].z = (h ? L(z1) : L(z0)) | ((uint32_t)(q & 511) << 7);
       }
     }
     L(qs) = s;
@@ -256,92 +313,19 @@ CO_DEV void co_receive_one(CoWave &w, CoTree &t, int k, float leaf_eval, const f
   FOR_LANES {
     if (lane == 0) A[leaf + 1].y = co_f2u(denominator);
   }
-  WAVE_SYNC();
-  /* backup: the node k levels above the leaf receives eval*(-1)^k - 1; every
-   * node on the path becomes searchable again (all_visited := false) */
-  FOR_LANES {
-    if (lane <= D) {
-      int kk = D - lane;
-      float ce = (kk & 1) ? (float)((double)leaf_eval * -1.0) : leaf_eval;
-      float add = (float)((double)ce - 1.0);
-      uint4 s = A[pp[lane]];
-      s.y = co_f2u(co_u2f(s.y) + add);
-      s = co_slot_set_all_visited(s, 0);
-      A[pp[lane]] = s;
-    }
-  }
-  WAVE_SYNC();
-  w.gc.evals++;
 }
 
-/* receiveEval for a batch of up to CO_RB pending leaves at once (trainmc.cpp:269-296).
- * Same arithmetic as co_receive_one, reorganised so that loads overlap and lanes are busy:
- *   A  lane k: leaf k's header; the backup path of every leaf and its stat slots are
- *      requested here already (consumed in G)
- *   B  per leaf, lanes = edges: move ids and priors -> LDS tables (all loads in flight together)
- *   C  lanes = consecutive mt19937 draws: noise in stream order (leaf 0's edges first)
- *   D  lane k: the two SEQUENTIAL float sums of leaf k (the only order-sensitive part)
- *   E  per leaf, lanes = edges: weights, max, 9-bit quantisation, write-back
- *   G  lanes = path levels: the backups, in request order by register forwarding
- * Falls back to co_receive_one when a leaf has more than CO_RE legal moves. */
+/* Part (2): the backups of up to CO_RB pending leaves at once.  The node k levels above a leaf
+ * receives eval*(-1)^k - 1; every node on the path becomes searchable again (all_visited := false).
+ * The slot of a shared ancestor must receive the leaves' contributions in request order (float
+ * addition is not associative): the slots of all paths are fetched together, and leaf k starts from
+ * the value left by the latest earlier leaf of the batch that touched the same slot (register
+ * forwarding) instead of re-reading memory. */
 #define CO_RB 8
-#define CO_RE 48
-#define CO_RS (CO_RE + 1) /* LDS row stride: odd, so lane k's column walk is conflict-free */
-
-/* up to 64*CO_RC consecutive generator outputs starting at state position `from` (no wrap):
- * draw base+lane of chunk c -> noise table entry of its (leaf, edge) */
-#define CO_RC 6
-CO_DEV void co_receive_draws(CoWave &w, float *tn, const int (&offs)[CO_RB + 1], int nb, int from, int first, int count) {
-  LV(uint32_t, raw[CO_RC]);
-#pragma unroll
-  for (int c = 0; c < CO_RC; ++c) {
-    FOR_LANES {
-      int i = c * CO_WAVE + lane;
-      L(raw[c]) = w.mt[from + (i < count ? i : 0)];
-    }
-  }
-  LV(float, gv[CO_RC]);
-#pragma unroll
-  for (int c = 0; c < CO_RC; ++c) {
-    FOR_LANES { L(gv[c]) = co_u2f(CO_GAMMA_BITS[co_mt_temper(L(raw[c])) % CO_NUM_GAMMA]); }
-  }
-#pragma unroll
-  for (int c = 0; c < CO_RC; ++c) {
-    FOR_LANES {
-      int i = c * CO_WAVE + lane;
-      if (i < count) {
-        int d = first + i; /* index of this draw within the batch */
-        int k = 0, ob = 0; /* offs is non-decreasing: the last j with offs[j] <= d owns the draw */
-#pragma unroll
-        for (int j = 1; j < CO_RB; ++j)
-          if (j < nb && offs[j] <= d) {
-            k = j;
-            ob = offs[j];
-          }
-        tn[k * CO_RS + (d - ob)] = L(gv[c]);
-      }
-    }
-  }
-}
-
-CO_DEV void co_receive_batch(CoWave &w, CoTree &t, int k0, int nb, const float *eval, const float *probs) {
+CO_DEV void co_backup_batch(CoWave &w, CoTree &t, int k0, int nb, const float *eval) {
   uint4 *A = t.A;
-  WAVE_SHARED(float, tp, CO_RB * CO_RS + 4);  /* priors (+4: phase D reads four ahead) */
-  WAVE_SHARED(float, tn, CO_RB * CO_RS + 4);  /* noise */
-  WAVE_SHARED(uint8_t, tm, CO_RB * CO_RS + 3); /* move ids */
-  unsigned long long tA = CO_CLK();
-  (void)tA; /* only read by profiling builds */
-  /* ---- A */
-  LV(uint32_t, leafv);
-  LV(int, nv);
   LV(int, dv);
-  FOR_LANES {
-    int kk = lane < nb ? k0 + lane : k0;
-    L(leafv) = w.pend_leaf[kk];
-    L(dv) = w.pend_depth[kk];
-  }
-  FOR_LANES { L(nv) = lane < nb ? (int)CO_META_NEDGES(A[L(leafv)].z) : 0; }
-  /* backup operands: path slot addresses and their current contents */
+  FOR_LANES { L(dv) = w.pend_depth[lane < nb ? k0 + lane : k0]; }
   LV(uint32_t, at[CO_RB]);
   LV(uint32_t, ny[CO_RB]);
   LV(uint32_t, nw[CO_RB]);
@@ -364,192 +348,49 @@ CO_DEV void co_receive_batch(CoWave &w, CoTree &t, int k0, int nb, const float *
       L(nw[k]) = sl.w & ~0x100u; /* all_visited := false */
     }
   }
-  int offs[CO_RB + 1];
-  int total = 0, too_wide = 0;
-  offs[0] = 0;
 #pragma unroll
   for (int k = 0; k < CO_RB; ++k) {
-    int n = WAVE_BCAST(nv, k);
-    if (n > CO_RE) too_wide = 1;
-    total += n;
-    offs[k + 1] = total;
-  }
-  if (too_wide) {
-    for (int k = 0; k < nb; ++k) co_receive_one(w, t, k0 + k, eval[k0 + k], probs + (size_t)(k0 + k) * CO_NUM_MOVES);
-    return;
-  }
-  CO_PROF_ADD(w, 8, CO_CLK() - tA);
-  tA = CO_CLK();
-  /* ---- B: loads are unconditional (inactive lanes read unit 0 / prior 0) so that none of
-   * them sits in a predicated block with its first use: all eight stay in flight */
-  {
-    LV(uint32_t, mvv[CO_RB]);
-    LV(float, prv[CO_RB]);
+    int D = WAVE_BCAST(dv, k);
+    float leaf_eval = k < nb ? eval[k0 + k] : 0.0f;
+    FOR_LANES {
+      if (L(on[k])) {
+        uint32_t cur = L(ny[k]);
 #pragma unroll
-    for (int k = 0; k < CO_RB; ++k) {
-      uint32_t leaf = WAVE_BCAST(leafv, k);
-      int n = WAVE_BCAST(nv, k);
-      FOR_LANES {
-        uint32_t ad = (k < nb && lane < n) ? leaf + 2u + (uint32_t)lane : 0u;
-        L(mvv[k]) = A[ad].z;
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < CO_RB; ++k) {
-      const float *pr = probs + (size_t)(k < nb ? k0 + k : k0) * CO_NUM_MOVES;
-      FOR_LANES {
-        L(mvv[k]) &= 127u;
-        L(prv[k]) = pr[L(mvv[k]) < (uint32_t)CO_NUM_MOVES ? L(mvv[k]) : 0u];
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < CO_RB; ++k) {
-      int n = WAVE_BCAST(nv, k);
-      FOR_LANES {
-        if (k < nb && lane < n) {
-          tm[k * CO_RS + lane] = (uint8_t)L(mvv[k]);
-          tp[k * CO_RS + lane] = L(prv[k]);
-        }
+        for (int j = 0; j < k; ++j)
+          if (L(on[j]) && L(at[j]) == L(at[k])) cur = L(ny[j]);
+        int kk = D - lane;
+        float ce = (kk & 1) ? (float)((double)leaf_eval * -1.0) : leaf_eval;
+        float add = (float)((double)ce - 1.0);
+        L(ny[k]) = co_f2u(co_u2f(cur) + add);
       }
     }
   }
-  CO_PROF_ADD(w, 9, CO_CLK() - tA);
-  tA = CO_CLK();
-  /* ---- C: `total` outputs of the game's generator; at most one twist in between */
-  {
-    int done = 0;
-    while (done < total) {
-      if (w.gc.rng_idx >= CO_MT_N) {
-        co_mt_twist(w.mt);
-        w.gc.rng_idx = 0;
+#pragma unroll
+  for (int k = 0; k < CO_RB; ++k) {
+    FOR_LANES {
+      if (L(on[k])) {
+        A[L(at[k])].y = L(ny[k]);
+        A[L(at[k])].w = L(nw[k]);
       }
-      int cnt = total - done;
-      if (cnt > CO_MT_N - w.gc.rng_idx) cnt = CO_MT_N - w.gc.rng_idx;
-      if (cnt > CO_WAVE * CO_RC) cnt = CO_WAVE * CO_RC;
-      co_receive_draws(w, tn, offs, nb, w.gc.rng_idx, done, cnt);
-      w.gc.rng_idx += cnt;
-      done += cnt;
     }
   }
   WAVE_SYNC();
-  CO_PROF_ADD(w, 10, CO_CLK() - tA);
-  tA = CO_CLK();
-  /* ---- D: lane k owns leaf k; sequential float additions in edge order, reading four
-   * entries ahead to keep the LDS latency off the dependent add chain (x + 0.0f == x) */
-  LV(float, scv);
-  LV(float, dscv);
-  FOR_LANES {
-    L(scv) = 0.0f;
-    L(dscv) = 0.0f;
-    if (lane < nb) {
-      const int n = L(nv);
-      const float *fp = tp + lane * CO_RS;
-      const float *dn = tn + lane * CO_RS;
-      float sum = 0.0f, dsum = 0.0f;
-      for (int e = 0; e < n; e += 4) {
-        float a0 = fp[e], a1 = fp[e + 1], a2 = fp[e + 2], a3 = fp[e + 3];
-        float d0 = dn[e], d1 = dn[e + 1], d2 = dn[e + 2], d3 = dn[e + 3];
-        sum += a0;
-        dsum += d0;
-        sum += e + 1 < n ? a1 : 0.0f;
-        dsum += e + 1 < n ? d1 : 0.0f;
-        sum += e + 2 < n ? a2 : 0.0f;
-        dsum += e + 2 < n ? d2 : 0.0f;
-        sum += e + 3 < n ? a3 : 0.0f;
-        dsum += e + 3 < n ? d3 : 0.0f;
-      }
-      float one_minus = (float)1 - w.epsilon;
-      L(scv) = (float)(1.0 / (double)sum * (double)one_minus);
-      L(dscv) = (float)(1.0 / (double)dsum * (double)w.epsilon);
-    }
-  }
-  CO_PROF_ADD(w, 11, CO_CLK() - tA);
-  tA = CO_CLK();
-  /* ---- E: per leaf, lanes = edges.  max and the integer sum are order independent.  A leaf
-   * that waits for its evaluation has no children (all_visited is born true, node.h:186), so
-   * its edge words are just the move id: plain stores, no reload */
-  for (int k = 0; k < nb; ++k) {
-    uint32_t leaf = WAVE_BCAST(leafv, k);
-    int n = WAVE_BCAST(nv, k);
-    float scalar = WAVE_BCAST(scv, k), dscalar = WAVE_BCAST(dscv, k);
-    LV(float, wt);
-    FOR_LANES {
-      float a = tp[k * CO_RS + (lane < n ? lane : 0)] * scalar;
-      float d = tn[k * CO_RS + (lane < n ? lane : 0)] * dscalar;
-      L(wt) = lane < n ? a + d : 0.0f;
-    }
-    float max_prob = WAVE_MAX_F32(wt); /* weights are >= 0, as the reference's max_prob start value */
-    float denom = 511.0f / max_prob;
-    LV(int, qv);
-    FOR_LANES {
-      int q = 0;
-      if (lane < n) {
-        float x = L(wt) * denom;
-        float fl = __builtin_truncf(x);
-        q = (int)fl;
-        if (x - fl >= 0.5f) q += 1;
-        if (!(q >= 1)) q = 1;
-        A[leaf + 2 + lane].z = (uint32_t)tm[k * CO_RS + lane] | ((uint32_t)(q & 511) << 7);
-      }
-      L(qv) = q;
-    }
-    int final_sum = WAVE_SUM_I32(qv);
-    float den = (float)(1.0 / (double)(float)final_sum);
-    FOR_LANES {
-      if (lane == 0) A[leaf + 1].y = co_f2u(den);
-    }
-  }
-  WAVE_SYNC();
-  CO_PROF_ADD(w, 12, CO_CLK() - tA);
-  tA = CO_CLK();
-  /* ---- G: backups, lane = path level.  The slot of a shared ancestor must receive the
-   * leaves' contributions in request order (float addition is not associative).  The slots
-   * were fetched in phase A; leaf k starts from the value left by the latest earlier leaf of
-   * the batch that touched the same slot (register forwarding) instead of re-reading memory. */
-  {
-#pragma unroll
-    for (int k = 0; k < CO_RB; ++k) {
-      int D = WAVE_BCAST(dv, k);
-      float leaf_eval = k < nb ? eval[k0 + k] : 0.0f;
-      FOR_LANES {
-        if (L(on[k])) {
-          uint32_t cur = L(ny[k]);
-#pragma unroll
-          for (int j = 0; j < k; ++j)
-            if (L(on[j]) && L(at[j]) == L(at[k])) cur = L(ny[j]);
-          int kk = D - lane;
-          float ce = (kk & 1) ? (float)((double)leaf_eval * -1.0) : leaf_eval;
-          float add = (float)((double)ce - 1.0);
-          L(ny[k]) = co_f2u(co_u2f(cur) + add);
-        }
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < CO_RB; ++k) {
-      FOR_LANES {
-        if (L(on[k])) {
-          A[L(at[k])].y = L(ny[k]);
-          A[L(at[k])].w = L(nw[k]);
-        }
-      }
-    }
-    WAVE_SYNC();
-  }
-  CO_PROF_ADD(w, 13, CO_CLK() - tA);
   w.gc.evals += (uint32_t)nb;
 }
 
-/* trainmc.cpp:269-296 */
-CO_DEV void co_receive_eval(CoWave &w, CoTree &t, const float *eval, const float *probs) {
+/* trainmc.cpp:269-296, the game's share: the priors of the pending leaves are in the tree already
+ * (co_k_priors ran on this launch's rows) */
+CO_DEV void co_receive_eval(CoWave &w, CoTree &t, const float *eval) {
   int n = w.gc.n_pending;
   unsigned long long t0 = CO_CLK();
   for (int k0 = 0; k0 < n; k0 += CO_RB) {
     int nb = n - k0 < CO_RB ? n - k0 : CO_RB;
-    co_receive_batch(w, t, k0, nb, eval, probs);
+    co_backup_batch(w, t, k0, nb, eval);
   }
   CO_PROF_ADD(w, 0, CO_CLK() - t0);
   CO_PROF_ADD(w, 6, (unsigned long long)n);
   w.gc.n_pending = 0;
+  w.noise_words = 0;
 }
 
 /* propagateTerminal, trainmc.cpp:497-538 (including the parent-for-child draw
@@ -615,18 +456,42 @@ CO_DEV double co_div_small(double x, float df) {
   return __builtin_fma(rem, r, q0);
 }
 
-/* Register copy of the root's header and stat slot, kept across the simulations
- * of one step so that a simulation starts without any dependent load. */
+/* Copy of the root kept across the simulations of one step, so that a simulation starts without any
+ * dependent load: header and stat slot in registers, the first 64 edge slots (the whole PUCT scan of
+ * the root for all but the widest positions) in LDS.  Every simulation reads them and changes one:
+ * stores to a root edge slot go to memory AND to the copy (co_store_slot); the rare paths that
+ * rewrite several path slots in memory (terminal leaf, dead end) drop the copy (valid = 0). */
 struct CoRoot {
   uint4 h0, h1, cs;
   int valid;
+  uint4 *ev;      /* LDS: edge slots 0..63 of the root */
+  uint32_t e0;    /* unit offset of the root's edge slot 0 */
+  uint32_t ne;    /* edge slots held: min(edges, 64) */
 };
 
 CO_DEV void co_root_load(CoTree &t, CoRoot &rc) {
   rc.h0 = co_load_unit(t.A, t.tc.root);
   rc.h1 = co_load_unit(t.A, t.tc.root + 1);
   rc.cs = co_load_unit(t.A, rc.h1.x);
+  rc.e0 = t.tc.root + 2u;
+  uint32_t n = CO_META_NEDGES(rc.h0.z);
+  rc.ne = n < (uint32_t)CO_WAVE ? n : (uint32_t)CO_WAVE;
+  const uint4 *A = t.A;
+  FOR_LANES { rc.ev[lane] = A[rc.e0 + lane]; } /* arena is padded: lanes >= n read unused units */
+  WAVE_SYNC();
   rc.valid = 1;
+}
+
+/* single-lane store of a stat slot, mirrored into the root copy when it is one of the root's edge slots */
+CO_DEV void co_store_slot(uint4 *A, uint32_t slot, uint4 v, CoRoot &rc) {
+  const uint32_t idx = slot - rc.e0; /* unsigned: anything outside the root's edges is >= ne */
+  FOR_LANES {
+    if (lane == 0) {
+      A[slot] = v;
+      if (idx < rc.ne) rc.ev[idx] = v;
+    }
+  }
+  WAVE_SYNC();
 }
 
 /* One simulation: TrainMC::search (trainmc.cpp:602-696) with chooseNext
@@ -644,8 +509,9 @@ CO_DEV void co_search(CoWave &w, CoTree &t, CoRoot &rc) {
   uint32_t cur_slot = h1.x;
   uint4 cs = rc.cs;
   LV(uint4, ev);
-  FOR_LANES { L(ev) = A[cur + 2 + lane]; } /* arena is padded: lanes >= n read unused units */
+  FOR_LANES { L(ev) = rc.ev[lane]; }
   int D = 0;
+  int leaf_n = 0; /* legal moves of the node this simulation creates */
   FOR_LANES {
     if (lane == 0) {
       path_block[0] = cur;
@@ -706,7 +572,7 @@ CO_DEV void co_search(CoWave &w, CoTree &t, CoRoot &rc) {
     if (best_e < 0) {
       /* kNone: nothing searchable below; mark, undo the path, un-count the search */
       cs = co_slot_set_all_visited(cs, 1);
-      co_store_unit(A, cur_slot, cs);
+      co_store_slot(A, cur_slot, cs, rc);
       FOR_LANES {
         if (lane <= D) {
           uint4 s = A[path_slot[lane]];
@@ -721,7 +587,7 @@ CO_DEV void co_search(CoWave &w, CoTree &t, CoRoot &rc) {
       rc.valid = 0;
       return;
     }
-    co_store_unit(A, cur_slot, cs);
+    co_store_slot(A, cur_slot, cs, rc);
     if (D == 0) rc.cs = cs;
     if (D + 1 >= CO_PATH_MAX) {
       w.gc.error |= CO_ERR_PATH_TOO_DEEP;
@@ -737,7 +603,7 @@ CO_DEV void co_search(CoWave &w, CoTree &t, CoRoot &rc) {
       int res;
       int depth = (int)CO_META_DEPTH(h0.z) + 1;
       unsigned long long te = CO_CLK();
-      uint32_t nb = co_create_node(w, t, board, meta, depth, cur, child_slot, &res);
+      uint32_t nb = co_create_node(w, t, board, meta, depth, cur, child_slot, &res, &leaf_n);
       CO_PROF_ADD(w, 3, CO_CLK() - te);
       if (nb == CO_NONE) return;
       if (w.analyse) {
@@ -783,7 +649,7 @@ CO_DEV void co_search(CoWave &w, CoTree &t, CoRoot &rc) {
     /* trainmc.cpp:663-682.  (For a fresh child the slot is first written here.) */
     float cur_eval = co_res_drawn(r) ? 0.0f : -1.0f;
     cs.y = co_f2u(cur_eval);
-    co_store_unit(A, cur_slot, cs);
+    co_store_slot(A, cur_slot, cs, rc);
     co_propagate_terminal(t, path_block, path_slot, D);
     FOR_LANES {
       if (lane < D) {
@@ -800,9 +666,9 @@ CO_DEV void co_search(CoWave &w, CoTree &t, CoRoot &rc) {
   } else {
     /* trainmc.cpp:684-692: default +1 evaluation, queue the leaf */
     cs.y = co_f2u(1.0f);
-    co_store_unit(A, cur_slot, cs);
+    co_store_slot(A, cur_slot, cs, rc);
     uint64_t board = (uint64_t)h0.x | ((uint64_t)h0.y << 32);
-    co_request(w, board, h0.z, cur, D, path_slot);
+    co_request(w, board, h0.z, cur, leaf_n, D, path_slot);
   }
 }
 
@@ -819,7 +685,7 @@ CO_DEV void co_request_root(CoWave &w, CoTree &t) {
   }
   WAVE_SYNC();
   uint64_t board = (uint64_t)h0.x | ((uint64_t)h0.y << 32);
-  co_request(w, board, h0.z, root, 0, one_path);
+  co_request(w, board, h0.z, root, (int)CO_META_NEDGES(h0.z), 0, one_path);
 }
 
 /* TrainMC::doIteration, trainmc.cpp:139-178.  Returns "turn finished". */
@@ -842,14 +708,32 @@ CO_DEV int co_mc_do_iteration(CoWave &w, CoTree &t, const float *eval, const flo
     co_request_root(w, t);
     return 0;
   }
-  if (w.gc.n_pending > 0) co_receive_eval(w, t, eval, probs);
+  /* A reference step runs simulations until searches_per_eval leaves are queued -- however many
+   * simulations that takes: near the end of a game most simulations end in solved positions and
+   * queue nothing, and one such game makes a whole launch wait (the slowest wavefront of a launch
+   * ran ~1.7x the mean).  Lock-step scheduling only (as the deferred hand-over): past sim_cap
+   * simulations the step is CUT -- the leaves queued so far are not submitted, nothing is received
+   * early, and the next launch simply goes on searching.  The game's own sequence of operations is
+   * the reference's; it takes one more launch. */
+  if (w.held) w.held = 0;
+  else if (w.gc.n_pending > 0) co_receive_eval(w, t, eval);
+  int sims = 0;
+  WAVE_SHARED(uint4, root_ev, CO_WAVE);
   CoRoot rc;
   rc.valid = 0;
+  rc.ev = root_ev;
+  rc.e0 = 0u;
+  rc.ne = 0u;
   for (;;) {
     if (!(w.gc.n_pending < w.spe && t.tc.searches_done < w.max_searches)) break;
     if (!rc.valid) co_root_load(t, rc);
     if (co_res_known(co_slot_result(rc.cs)) || co_slot_all_visited(rc.cs)) break;
     if (w.gc.error) break;
+    if (w.sim_cap > 0 && sims >= w.sim_cap) {
+      w.gc.resume = 2;
+      return 0;
+    }
+    ++sims;
     unsigned long long t0 = CO_CLK();
     co_search(w, t, rc);
     CO_PROF_ADD(w, 1, CO_CLK() - t0);
@@ -1170,8 +1054,9 @@ CO_DEV void co_analyse_finish(CoWave &w, CoTree &t, int choice) {
  * (250 KB of instructions in front of a 64 KB instruction cache).  Returns "game over". */
 CO_DEV int co_game_step(CoWave &w, const float *eval, const float *probs) {
   const float *ev = eval, *pr = probs;
+  w.held = w.gc.resume == 2;
   if (w.gc.resume) {
-    /* continuation of a deferred hand-over: selfplayer.cpp:287-288 */
+    /* continuation of a deferred hand-over (selfplayer.cpp:287-288) or of a cut step */
     w.gc.resume = 0;
     ev = pr = (const float *)0;
   }
@@ -1289,6 +1174,27 @@ CO_DEV int co_game_step(CoWave &w, const float *eval, const float *probs) {
   }
 }
 
+/* Does game g step in this launch?  0 no, 1 yes, 2 not yet released by the staggered start.
+ * (trainer.cpp:176-196 training, :216-229 arena, tourney.cpp:63-72; shared by the search kernel and
+ * by co_k_priors, which must agree on the games whose evaluations are consumed) */
+CO_DEV int co_step_gate(const EngineParams &P, int g, const GameCtl &gc) {
+  if (gc.done || gc.error) return 0;
+  const int tp = P.arena_state ? P.arena_state[0] : P.to_play;
+  if (P.pcfg) {
+    if (P.pcfg[2 * g + gc.to_play].model_id != tp) return 0; /* tourney.cpp:66 */
+  } else if (tp == 0 || tp == 1) {
+    if (gc.to_play != (tp + gc.parity) % 2) return 0;
+  } else if (P.stagger_div > 0) {
+    if ((P.game_base + g) / P.stagger_div > P.iteration) return 2;
+  }
+  return 1;
+}
+
+/* first row of game g's evaluations in nn_eval / nn_probs */
+CO_DEV int co_step_row(const EngineParams &P, int g, const GameCtl &gc) {
+  return P.fused_pack ? gc.row_off : P.read_offset ? P.read_offset[g] : P.req_offset[g];
+}
+
 /* Trainer::doIteration for game g (trainer.cpp:164-236): the body of the
  * `omp parallel for`, one wavefront per game. */
 CO_DEV void co_mcts_step_wave(const EngineParams &P, int g) {
@@ -1298,17 +1204,10 @@ CO_DEV void co_mcts_step_wave(const EngineParams &P, int g) {
     }
   }
   GameCtl gc = P.games[g];
-  if (gc.done || gc.error) return;
-  const int tp = P.arena_state ? P.arena_state[0] : P.to_play;
-  if (P.pcfg) {
-    if (P.pcfg[2 * g + gc.to_play].model_id != tp) return; /* tourney.cpp:66 */
-  } else if (tp == 0 || tp == 1) {
-    if (gc.to_play != (tp + gc.parity) % 2) return;
-  } else if (P.stagger_div > 0) {
-    if ((P.game_base + g) / P.stagger_div > P.iteration) {
-      if (P.fused_pack) co_atomic_add_u64(P.pack_counter + (P.iteration & 1), 1ull << 32); /* still running */
-      return;
-    }
+  const int gate = co_step_gate(P, g, gc);
+  if (gate != 1) {
+    if (gate == 2 && P.fused_pack) co_atomic_add_u64(P.pack_counter + (P.iteration & 1), 1ull << 32); /* still running */
+    return;
   }
   CoWave w;
   w.g = g;
@@ -1327,6 +1226,11 @@ CO_DEV void co_mcts_step_wave(const EngineParams &P, int g) {
   w.pend_leaf = P.pend_leaf + (size_t)g * P.searches_per_eval;
   w.pend_depth = P.pend_depth + (size_t)g * P.searches_per_eval;
   w.pend_path = P.pend_path + (size_t)g * P.searches_per_eval * CO_PATH_MAX;
+  w.pend_n = P.pend_n + (size_t)g * P.searches_per_eval;
+  w.noise_raw = P.noise_raw + (size_t)g * P.searches_per_eval * CO_NUM_MOVES;
+  w.noise_words = (int)gc.noise_words; /* reset when the pending leaves are received */
+  w.sim_cap = P.sim_cap;
+  w.held = 0;
   w.req = P.req + (size_t)g * P.searches_per_eval * CO_STATE_STRIDE;
   w.samples = P.samples ? P.samples + (size_t)g * CO_MAX_PLIES * CO_SAMPLE_FLOATS : (float *)0;
   w.trace = P.trace ? P.trace + (size_t)g * CO_TRACE_CAP : (int32_t *)0;
@@ -1346,13 +1250,16 @@ CO_DEV void co_mcts_step_wave(const EngineParams &P, int g) {
 #if defined(CO_PROF) && !defined(CO_EMU)
   unsigned long long t_real0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  int off = P.fused_pack ? gc.row_off : P.read_offset ? P.read_offset[g] : P.req_offset[g];
+  int off = co_step_row(P, g, gc);
   int done = co_game_step(w, P.nn_eval + off, P.nn_probs + (size_t)off * CO_NUM_MOVES);
   if (done) w.gc.done = 1;
+  const int cut = w.gc.resume == 2; /* leaves stay queued, unsubmitted */
+  if (!done && !w.gc.error && w.gc.n_pending > 0 && !cut) co_capture_noise(w);
+  w.gc.noise_words = (uint32_t)w.noise_words;
   if (P.fused_pack && !w.gc.done && !w.gc.error) {
     /* Trainer::writeRequests fused into the step: reserve rows of the compact batch
      * (any order: a row's evaluation does not depend on its position) and copy */
-    int n = w.gc.n_pending;
+    int n = cut ? 0 : w.gc.n_pending;
     unsigned long long old = co_atomic_add_u64(P.pack_counter + (P.iteration & 1), (1ull << 32) | (unsigned long long)n);
     int base = P.pool_row_base + (int)(unsigned)(old & 0xFFFFFFFFull);
     w.gc.row_off = base;

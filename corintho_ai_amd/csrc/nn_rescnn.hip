@@ -392,11 +392,13 @@ __global__ __launch_bounds__(256, 2) void co_k_rescnn_forward(RcParams P) {
 #define RC3_NUM_GROUPS 27
 #define RCS_GROUP_WORDS(NT) (3 * RCS_CONV_CHUNK(NT)) /* 48 KB / 72 KB */
 #define RCS_FEAT_WORDS(NP) (8 * 2 * (NP) * 96)
-/* LDS: [2 weight groups][head features][epilogue constants][NT = 2: head weights].  With three terms
- * the head weights do not fit beside two 72 KB groups: they are staged into the idle group buffer
- * while the last group computes. */
+/* LDS: [2 weight groups][NT = 2: head features][epilogue constants][NT = 2: head weights].  With three
+ * terms the head weights do not fit beside two 72 KB groups: they are staged into the idle group
+ * buffer while the last group computes, and the head features go where the last group was once every
+ * wave has left it.  151 KB: what is left of the CU's 160 KB (and of its registers, see the kernel's
+ * attributes) is room for wavefronts of the search kernel beside this one. */
 #define RCS_LDS_WORDS(NT, NP) \
-  (2 * RCS_GROUP_WORDS(NT) + RCS_FEAT_WORDS(NP) + RC3_EPI_WORDS + ((NT) == 2 ? RCS_HEAD_WORDS(NT) : 0))
+  (2 * RCS_GROUP_WORDS(NT) + ((NT) == 2 ? RCS_FEAT_WORDS(NP) : 0) + RC3_EPI_WORDS + ((NT) == 2 ? RCS_HEAD_WORDS(NT) : 0))
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -647,11 +649,13 @@ extern "C" int ca_net_prof(unsigned long long out[8]) {
 #endif
 
 template <int NP, int NT>
-__global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_split_t(Rc3Params Q) {
+__device__ __forceinline__ void rcs_forward(const Rc3Params &Q) {
   const RcParams &P = Q.base;
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
   uint32_t *lds_w = lds_dyn;
-  float *lds_feat = reinterpret_cast<float *>(lds_dyn + 2 * RCS_GROUP_WORDS(NT));
+  /* NT = 3: the features reuse the buffer of the last group (RC3_NUM_GROUPS - 1 = 26 -> buffer 0), free behind
+   * the barrier in front of the heads */
+  float *lds_feat = reinterpret_cast<float *>(NT == 2 ? lds_dyn + 2 * RCS_GROUP_WORDS(NT) : lds_dyn);
   const int rows = *P.d_rows;
   if (NT == 2 && (rows <= RC3_SMALL_ROWS) != (NP == 1)) return; /* the other kernel takes this batch */
   const int row0 = blockIdx.x * (16 * NP);
@@ -663,8 +667,9 @@ __global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_split_t(Rc3Params 
   const unsigned long long start_ = stamp_;
 #endif
   const uint32_t lds_w_addr = co_lds_addr(lds_dyn);
-  uint32_t *lds_epi_w = lds_dyn + 2 * RCS_GROUP_WORDS(NT) + RCS_FEAT_WORDS(NP);
-  const uint32_t lds_epi_addr = lds_w_addr + (2 * RCS_GROUP_WORDS(NT) + RCS_FEAT_WORDS(NP)) * 4u;
+  constexpr int epi_off = 2 * RCS_GROUP_WORDS(NT) + (NT == 2 ? RCS_FEAT_WORDS(NP) : 0);
+  uint32_t *lds_epi_w = lds_dyn + epi_off;
+  const uint32_t lds_epi_addr = lds_w_addr + epi_off * 4u;
   const uint32_t *lds_head = NT == 2 ? lds_epi_w + RC3_EPI_WORDS : lds_w + (RC3_NUM_GROUPS & 1) * RCS_GROUP_WORDS(NT);
 
   /* input planes: register 4g + i of tile 0 = channel 8g + 4h + i:
@@ -787,9 +792,14 @@ __global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_split_t(Rc3Params 
 /* NT = 2  <2>: throughput kernel, batches of more than RC3_SMALL_ROWS rows, 32 positions per workgroup;
  *         <1>: small-batch kernel, up to RC3_SMALL_ROWS rows, 16 positions per workgroup, one round
  * NT = 3  <1> only */
-#define co_k_rescnn_forward_x3 co_k_rescnn_forward_split_t<2, 2>
-#define co_k_rescnn_forward_x3_small co_k_rescnn_forward_split_t<1, 2>
-#define co_k_rescnn_forward_x6 co_k_rescnn_forward_split_t<1, 3>
+__global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_x3(Rc3Params Q) { rcs_forward<2, 2>(Q); }
+__global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_x3_small(Rc3Params Q) { rcs_forward<1, 2>(Q); }
+/* (Capping this kernel at 168 registers so that a wave of the search kernel fits beside two of its waves on a SIMD was
+ * measured: the network kernel alone 5 % slower, the generation 4 % slower -- the kernel trace shows 81 % of the search
+ * kernel's time overlapping the other pool's network launches already, tools/overlap.py.) */
+__global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_x6(Rc3Params Q) {
+  rcs_forward<1, 3>(Q);
+}
 
 /* ------------------------------------------------------------------ host */
 struct ResCnnNet : CoNet {

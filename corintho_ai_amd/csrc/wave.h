@@ -80,6 +80,10 @@ static inline unsigned long long co_atomic_add_u64(unsigned long long *p, unsign
 }
 extern thread_local int co_emu_block_idx;
 #define CO_BLOCK_IDX co_emu_block_idx
+/* kernels whose wavefronts are independent may pack several per workgroup on the GPU (fewer, fatter
+ * workgroups for the dispatcher); the emulation runs one wavefront per block */
+#define CO_WAVES_PER_BLOCK 1
+#define CO_WAVE_IN_BLOCK 0
 
 #else
 // ------------------------------------------------------------------- gfx950
@@ -172,6 +176,8 @@ __device__ __forceinline__ unsigned long long co_atomic_add_u64(unsigned long lo
   return ((unsigned long long)hi << 32) | lo;
 }
 #define CO_BLOCK_IDX ((int)blockIdx.x)
+#define CO_WAVES_PER_BLOCK 4
+#define CO_WAVE_IN_BLOCK ((int)(threadIdx.x >> 6))
 #endif
 
 CO_DEV float co_u2f(uint32_t u) {

@@ -17,11 +17,13 @@ DST = sys.argv[4] if len(sys.argv) > 4 else os.path.join(ROOT, "profiles")
 
 
 def kname(name):
-    """kernel name as the docs use it: no signature, the two instances of the residual-CNN template
-    under their macro names"""
+    """kernel name as the docs use it: no signature, the instances of the network templates under their macro names"""
     n = name.split("(")[0].replace("void ", "").strip()
-    return n.replace("co_k_rescnn_forward_x3_t<2>", "co_k_rescnn_forward_x3").replace("co_k_rescnn_forward_x3_t<1>",
-                                                                                     "co_k_rescnn_forward_x3_small")
+    for a, b in (("co_k_rescnn_forward_split_t<1, 3>", "co_k_rescnn_forward_x6"), ("co_k_rescnn_forward_split_t<2, 2>", "co_k_rescnn_forward_x3"),
+                 ("co_k_rescnn_forward_split_t<1, 2>", "co_k_rescnn_forward_x3_small"), ("co_k_mlp_forward_split_t<3>", "co_k_mlp_forward_x6"),
+                 ("co_k_mlp_forward_split_t<2>", "co_k_mlp_forward_x3")):
+        n = n.replace(a, b)
+    return n
 
 
 def db_of(kind):
