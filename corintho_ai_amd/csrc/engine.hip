@@ -228,7 +228,7 @@ struct ca_trainer {
     arena.alloc(T * ((size_t)cap + CO_ARENA_PAD));
     pend_leaf.alloc((size_t)G * spe);
     pend_depth.alloc((size_t)G * spe);
-    pend_n.alloc((size_t)G * spe);
+    pend_n.alloc((size_t)G * spe * 4);
     noise_raw.alloc((size_t)G * spe * CO_NUM_MOVES);
     pend_path.alloc((size_t)G * spe * CO_PATH_MAX);
     rng.alloc((size_t)G * CO_MT_N);

@@ -136,7 +136,8 @@ struct EngineParams {
   uint32_t *pend_leaf;  /* [G][spe] */
   int32_t *pend_depth;  /* [G][spe] */
   uint32_t *pend_path;  /* [G][spe][CO_PATH_MAX] */
-  uint32_t *pend_n;     /* [G][spe] (first noise word of the leaf << 8) | legal moves of the leaf */
+  uint32_t *pend_n;     /* [G][spe][4] {(first noise word of the leaf << 8) | legal moves of the leaf, legal-move mask [3]}:
+                         * everything co_k_priors needs to fetch the leaf's priors without walking the tree first */
   uint32_t *noise_raw;  /* [G][spe * CO_NUM_MOVES] generator outputs (untempered state words) reserved for the pending
                          * leaves' Dirichlet noise, in request order: drawn when the leaves are queued (mcts.h
                          * co_capture_noise), consumed by co_k_priors */

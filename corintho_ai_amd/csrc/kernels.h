@@ -25,16 +25,17 @@ CO_KERNEL co_k_priors(EngineParams P) {
   const int unit = CO_BLOCK_IDX * CO_WAVES_PER_BLOCK + CO_WAVE_IN_BLOCK; /* (game of the pool, pending leaf) */
   const int g = P.pool_lo + unit / spe, k = unit % spe;
   if (unit / spe >= P.pool_n || g >= P.num_games) return;
+  /* the three fetches the rest depends on are independent of each other: issued together */
   GameCtl gc = P.games[g];
+  const uint32_t leaf = P.pend_leaf[(size_t)g * spe + k];
+  const uint4 pn = ((const uint4 *)P.pend_n)[(size_t)g * spe + k];
   if (co_step_gate(P, g, gc) != 1 || k >= gc.n_pending || gc.resume == 2) return; /* a cut step has nothing to consume */
   const size_t stride = (size_t)P.cap_units + CO_ARENA_PAD;
   uint4 *A = P.arena + (size_t)(2 * g + gc.to_play) * stride; /* the mover's tree holds the pending leaves */
-  const uint32_t leaf = P.pend_leaf[(size_t)g * spe + k];
-  const uint32_t pn = P.pend_n[(size_t)g * spe + k];
   const int row = co_step_row(P, g, gc) + k;
   const float eps = P.pcfg ? P.pcfg[2 * g + gc.to_play].epsilon : P.epsilon; /* match.h:13-31: per-side settings */
-  co_prior_leaf(A, leaf, P.nn_probs + (size_t)row * CO_NUM_MOVES,
-                P.noise_raw + (size_t)g * spe * CO_NUM_MOVES + (pn >> 8), eps);
+  co_prior_leaf(A, leaf, (int)(pn.x & 255u), pn.y, pn.z, pn.w, P.nn_probs + (size_t)row * CO_NUM_MOVES,
+                P.noise_raw + (size_t)g * spe * CO_NUM_MOVES + (pn.x >> 8), eps);
 }
 
 /* is game g part of the batch of model `tp` (trainer.cpp:42-46, 84-98)? */

@@ -113,9 +113,14 @@ CO_DEV void co_trace_push(CoWave &w, int32_t v) {
  * that carries its own stat slot.  Returns the block offset (CO_NONE on arena
  * overflow); *res_out = kResultLoss / kResultDraw / kResultNone. */
 CO_DEV uint32_t co_create_node(CoWave &w, CoTree &t, uint64_t board, uint32_t meta_game, int depth, uint32_t parent,
-                               uint32_t self_slot, int *res_out, int *n_out = (int *)0) {
+                               uint32_t self_slot, int *res_out, int *n_out = (int *)0, uint32_t *lm_out = (uint32_t *)0) {
   uint32_t lm[3];
   int is_lines = co_legal_moves(board, meta_game, lm);
+  if (lm_out) {
+    lm_out[0] = lm[0];
+    lm_out[1] = lm[1];
+    lm_out[2] = lm[2];
+  }
   int n = co_popc32(lm[0]) + co_popc32(lm[1]) + co_popc32(lm[2]);
   int res = CO_RESULT_NONE;
   if (n == 0) res = is_lines ? CO_RESULT_LOSS : CO_RESULT_DRAW;
@@ -157,7 +162,7 @@ CO_DEV uint32_t co_create_node(CoWave &w, CoTree &t, uint64_t board, uint32_t me
 
 /* A leaf asks for a network evaluation: TrainMC writes the state into to_eval_
  * and records the node in searched_ (trainmc.cpp:684-692, 150-153). */
-CO_DEV void co_request(CoWave &w, uint64_t board, uint32_t meta, uint32_t leaf, int n_edges, int D,
+CO_DEV void co_request(CoWave &w, uint64_t board, uint32_t meta, uint32_t leaf, int n_edges, const uint32_t lm[3], int D,
                        const uint32_t *path_slot) {
   int k = w.gc.n_pending;
   co_write_state(board, meta, w.req + (size_t)k * CO_STATE_STRIDE);
@@ -168,8 +173,8 @@ CO_DEV void co_request(CoWave &w, uint64_t board, uint32_t meta, uint32_t leaf, 
     if (lane == 0) {
       w.pend_leaf[k] = leaf;
       w.pend_depth[k] = D;
-      w.pend_n[k] = pn;
     }
+    if (lane < 4) w.pend_n[4 * k + lane] = lane == 0 ? pn : lm[lane == 1 ? 0 : lane == 2 ? 1 : 2];
     if (lane <= D && lane < CO_PATH_MAX) pp[lane] = path_slot[lane];
   }
   WAVE_SYNC();
@@ -219,12 +224,38 @@ CO_DEV void co_capture_noise(CoWave &w) {
   }
 }
 
+/* the id of the r-th legal move (r-th set bit of the 96-bit mask), r < number of set bits */
+CO_DEV uint32_t co_nth_set(uint32_t m0, uint32_t m1, uint32_t m2, uint32_t r) {
+  const uint32_t c0 = (uint32_t)co_popc32(m0), c1 = (uint32_t)co_popc32(m1);
+  uint32_t word = m0, base = 0u;
+  if (r >= c0 + c1) {
+    word = m2;
+    base = 64u;
+    r -= c0 + c1;
+  } else if (r >= c0) {
+    word = m1;
+    base = 32u;
+    r -= c0;
+  }
+  uint32_t pos = 0u;
+#pragma unroll
+  for (uint32_t s = 16u; s >= 1u; s >>= 1) {
+    const uint32_t cnt = (uint32_t)co_popc32((word >> pos) & ((1u << s) - 1u));
+    if (r >= cnt) {
+      r -= cnt;
+      pos += s;
+    }
+  }
+  return base + pos;
+}
+
 /* Part (1) for ONE leaf, one wavefront: lanes = edges (two per lane beyond 64).  A = the leaf's tree,
- * probs = the network's 96 priors of the leaf's row, raw = the leaf's generator outputs.  The two sums
- * are sequential float additions in edge order, as the reference's loops. */
-CO_DEV void co_prior_leaf(uint4 *A, uint32_t leaf, const float *probs, const uint32_t *raw, float epsilon) {
-  uint4 h0 = co_load_unit(A, leaf);
-  const int n = (int)CO_META_NEDGES(h0.z);
+ * n / lm = the leaf's legal moves (count and mask, recorded when the leaf was queued, so that the
+ * gathers below depend on nothing in the tree), probs = the network's 96 priors of the leaf's row,
+ * raw = the leaf's generator outputs.  The two sums are sequential float additions in edge order, as
+ * the reference's loops. */
+CO_DEV void co_prior_leaf(uint4 *A, uint32_t leaf, int n, uint32_t lm0, uint32_t lm1, uint32_t lm2, const float *probs,
+                          const uint32_t *raw, float epsilon) {
   LV(uint32_t, z0);
   LV(uint32_t, z1);
   LV(float, fp0); /* filtered priors: edge `lane` and edge `lane + 64` */
@@ -235,12 +266,10 @@ CO_DEV void co_prior_leaf(uint4 *A, uint32_t leaf, const float *probs, const uin
     L(z0) = 0u;
     L(z1) = 0u;
     L(fp0) = L(fp1) = L(dn0) = L(dn1) = 0.0f;
-    /* unconditional loads (lanes beyond n read edge 0 / prior 0 / word 0), so that the three dependent
-     * fetches of all lanes are in flight together */
-    const int e0 = lane < n ? lane : 0;
-    const uint32_t m0 = A[leaf + 2 + e0].z & 127u; /* a leaf awaiting its evaluation has no children: the word is the move id */
-    const uint32_t r0 = raw[e0];
-    const float p0 = probs[m0 < (uint32_t)CO_NUM_MOVES ? m0 : 0u];
+    /* unconditional loads (lanes beyond n read move 0 / word 0): every lane's fetches are in flight together */
+    const uint32_t m0 = lane < n ? co_nth_set(lm0, lm1, lm2, (uint32_t)lane) : 0u; /* edges are the legal moves in ascending id */
+    const uint32_t r0 = raw[lane < n ? lane : 0];
+    const float p0 = probs[m0];
     const float g0 = co_u2f(CO_GAMMA_BITS[co_mt_temper(r0) % CO_NUM_GAMMA]);
     if (lane < n) {
       L(z0) = m0;
@@ -248,7 +277,7 @@ CO_DEV void co_prior_leaf(uint4 *A, uint32_t leaf, const float *probs, const uin
       L(dn0) = g0;
     }
     if (lane + CO_WAVE < n) {
-      L(z1) = A[leaf + 2 + lane + CO_WAVE].z & 127u;
+      L(z1) = co_nth_set(lm0, lm1, lm2, (uint32_t)(lane + CO_WAVE));
       L(fp1) = probs[L(z1)];
       L(dn1) = co_u2f(CO_GAMMA_BITS[co_mt_temper(raw[lane + CO_WAVE]) % CO_NUM_GAMMA]);
     }
@@ -512,6 +541,7 @@ CO_DEV void co_search(CoWave &w, CoTree &t, CoRoot &rc) {
   FOR_LANES { L(ev) = rc.ev[lane]; }
   int D = 0;
   int leaf_n = 0; /* legal moves of the node this simulation creates */
+  uint32_t leaf_lm[3] = {0u, 0u, 0u};
   FOR_LANES {
     if (lane == 0) {
       path_block[0] = cur;
@@ -603,7 +633,7 @@ CO_DEV void co_search(CoWave &w, CoTree &t, CoRoot &rc) {
       int res;
       int depth = (int)CO_META_DEPTH(h0.z) + 1;
       unsigned long long te = CO_CLK();
-      uint32_t nb = co_create_node(w, t, board, meta, depth, cur, child_slot, &res, &leaf_n);
+      uint32_t nb = co_create_node(w, t, board, meta, depth, cur, child_slot, &res, &leaf_n, leaf_lm);
       CO_PROF_ADD(w, 3, CO_CLK() - te);
       if (nb == CO_NONE) return;
       if (w.analyse) {
@@ -668,7 +698,7 @@ CO_DEV void co_search(CoWave &w, CoTree &t, CoRoot &rc) {
     cs.y = co_f2u(1.0f);
     co_store_slot(A, cur_slot, cs, rc);
     uint64_t board = (uint64_t)h0.x | ((uint64_t)h0.y << 32);
-    co_request(w, board, h0.z, cur, leaf_n, D, path_slot);
+    co_request(w, board, h0.z, cur, leaf_n, leaf_lm, D, path_slot);
   }
 }
 
@@ -685,7 +715,9 @@ CO_DEV void co_request_root(CoWave &w, CoTree &t) {
   }
   WAVE_SYNC();
   uint64_t board = (uint64_t)h0.x | ((uint64_t)h0.y << 32);
-  co_request(w, board, h0.z, root, (int)CO_META_NEDGES(h0.z), 0, one_path);
+  uint32_t lm[3];
+  co_legal_moves(board, h0.z, lm); /* (a root asks once per tree; its edges hold the same moves) */
+  co_request(w, board, h0.z, root, (int)CO_META_NEDGES(h0.z), lm, 0, one_path);
 }
 
 /* TrainMC::doIteration, trainmc.cpp:139-178.  Returns "turn finished". */
@@ -1226,7 +1258,7 @@ CO_DEV void co_mcts_step_wave(const EngineParams &P, int g) {
   w.pend_leaf = P.pend_leaf + (size_t)g * P.searches_per_eval;
   w.pend_depth = P.pend_depth + (size_t)g * P.searches_per_eval;
   w.pend_path = P.pend_path + (size_t)g * P.searches_per_eval * CO_PATH_MAX;
-  w.pend_n = P.pend_n + (size_t)g * P.searches_per_eval;
+  w.pend_n = P.pend_n + (size_t)g * P.searches_per_eval * 4;
   w.noise_raw = P.noise_raw + (size_t)g * P.searches_per_eval * CO_NUM_MOVES;
   w.noise_words = (int)gc.noise_words; /* reset when the pending leaves are received */
   w.sim_cap = P.sim_cap;
