@@ -7,6 +7,7 @@
 // the whole loop on the device.
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -366,7 +367,6 @@ struct ca_trainer {
     P.row_counter = nullptr; /* counted in fused mode only */
     P.fused_pack = 0;
     P.defer_handover = 0;
-    P.sim_cap = 0;
     P.pool_lo = 0;
     P.pool_n = G;
     P.pool_row_base = 0;
@@ -801,7 +801,6 @@ struct ca_trainer {
          * iterations of the longest game is what the generation waits for.  Per-game results do
          * not depend on the choice. */
         pp.defer_handover = q.running * 2 > q.n ? 1 : 0;
-        pp.sim_cap = pp.defer_handover ? spe + spe / 4 : 0; /* same reasoning: only while the launches are full */
         pp.pool_lo = q.lo;
         pp.pool_n = q.n;
         pp.pool_row_base = q.row_base;

@@ -77,12 +77,9 @@ struct GameCtl {
   uint32_t nodes;     /* ... nodes created */
   int32_t trace_len;
   int32_t row_off;    /* fused mode: first row of this game's requests in the compact batch */
-  int32_t resume;     /* fused mode: 1 = the new mover's first searches of a turn were deferred to the next step;
-                       * 2 = the step was cut at the simulation cap: its leaves are queued but NOT submitted yet,
-                       * the next step goes on searching (mcts.h co_mc_do_iteration) */
+  int32_t resume;     /* fused mode: the new mover's first searches of a turn were deferred to the next step */
   /* tournament matches only: Match::root_, the position on the board (match.h:91) */
-  uint32_t pos_lo, pos_hi, pos_meta;
-  uint32_t noise_words; /* generator outputs owed to the leaves queued so far (kept across the steps of a cut step) */
+  uint32_t pos_lo, pos_hi, pos_meta, pos_pad;
 };
 
 /* one side of a tournament match: Player, match.h:13-31 */
@@ -158,7 +155,6 @@ struct EngineParams {
    * cleared for the next iteration.  The network kernels read the low word. */
   int32_t fused_pack;
   int32_t defer_handover; /* fused mode: end a game's step at the hand-over (see mcts.h co_choose_move_and_continue) */
-  int32_t sim_cap;        /* fused mode: simulations after which a step is cut (0 = never), see GameCtl.resume */
   /* fused training runs the games as independent pools on separate streams, so that one pool's
    * search overlaps another pool's network kernel: this launch covers games [pool_lo, pool_lo +
    * pool_n) and its batch rows start at row pool_row_base of nn_in / nn_eval / nn_probs */

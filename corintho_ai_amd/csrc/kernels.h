@@ -29,7 +29,7 @@ CO_KERNEL co_k_priors(EngineParams P) {
   GameCtl gc = P.games[g];
   const uint32_t leaf = P.pend_leaf[(size_t)g * spe + k];
   const uint4 pn = ((const uint4 *)P.pend_n)[(size_t)g * spe + k];
-  if (co_step_gate(P, g, gc) != 1 || k >= gc.n_pending || gc.resume == 2) return; /* a cut step has nothing to consume */
+  if (co_step_gate(P, g, gc) != 1 || k >= gc.n_pending) return;
   const size_t stride = (size_t)P.cap_units + CO_ARENA_PAD;
   uint4 *A = P.arena + (size_t)(2 * g + gc.to_play) * stride; /* the mover's tree holds the pending leaves */
   const int row = co_step_row(P, g, gc) + k;

@@ -59,8 +59,7 @@ struct CoWave {
   int32_t *trace;
   unsigned long long *prof;
   /* config */
-  int max_searches, spe, testing, trace_on, defer_handover, analyse, sim_cap;
-  int held; /* this step continues one that was cut at the simulation cap: nothing to receive */
+  int max_searches, spe, testing, trace_on, defer_handover, analyse;
   float c_puct, epsilon;
   const PlayerCfg *pc; /* tournament match: the two players' settings, else null */
 };
@@ -740,16 +739,7 @@ CO_DEV int co_mc_do_iteration(CoWave &w, CoTree &t, const float *eval, const flo
     co_request_root(w, t);
     return 0;
   }
-  /* A reference step runs simulations until searches_per_eval leaves are queued -- however many
-   * simulations that takes: near the end of a game most simulations end in solved positions and
-   * queue nothing, and one such game makes a whole launch wait (the slowest wavefront of a launch
-   * ran ~1.7x the mean).  Lock-step scheduling only (as the deferred hand-over): past sim_cap
-   * simulations the step is CUT -- the leaves queued so far are not submitted, nothing is received
-   * early, and the next launch simply goes on searching.  The game's own sequence of operations is
-   * the reference's; it takes one more launch. */
-  if (w.held) w.held = 0;
-  else if (w.gc.n_pending > 0) co_receive_eval(w, t, eval);
-  int sims = 0;
+  if (w.gc.n_pending > 0) co_receive_eval(w, t, eval);
   WAVE_SHARED(uint4, root_ev, CO_WAVE);
   CoRoot rc;
   rc.valid = 0;
@@ -761,11 +751,6 @@ CO_DEV int co_mc_do_iteration(CoWave &w, CoTree &t, const float *eval, const flo
     if (!rc.valid) co_root_load(t, rc);
     if (co_res_known(co_slot_result(rc.cs)) || co_slot_all_visited(rc.cs)) break;
     if (w.gc.error) break;
-    if (w.sim_cap > 0 && sims >= w.sim_cap) {
-      w.gc.resume = 2;
-      return 0;
-    }
-    ++sims;
     unsigned long long t0 = CO_CLK();
     co_search(w, t, rc);
     CO_PROF_ADD(w, 1, CO_CLK() - t0);
@@ -1086,9 +1071,8 @@ CO_DEV void co_analyse_finish(CoWave &w, CoTree &t, int choice) {
  * (250 KB of instructions in front of a 64 KB instruction cache).  Returns "game over". */
 CO_DEV int co_game_step(CoWave &w, const float *eval, const float *probs) {
   const float *ev = eval, *pr = probs;
-  w.held = w.gc.resume == 2;
   if (w.gc.resume) {
-    /* continuation of a deferred hand-over (selfplayer.cpp:287-288) or of a cut step */
+    /* continuation of a deferred hand-over: selfplayer.cpp:287-288 */
     w.gc.resume = 0;
     ev = pr = (const float *)0;
   }
@@ -1260,9 +1244,7 @@ CO_DEV void co_mcts_step_wave(const EngineParams &P, int g) {
   w.pend_path = P.pend_path + (size_t)g * P.searches_per_eval * CO_PATH_MAX;
   w.pend_n = P.pend_n + (size_t)g * P.searches_per_eval * 4;
   w.noise_raw = P.noise_raw + (size_t)g * P.searches_per_eval * CO_NUM_MOVES;
-  w.noise_words = (int)gc.noise_words; /* reset when the pending leaves are received */
-  w.sim_cap = P.sim_cap;
-  w.held = 0;
+  w.noise_words = 0; /* a step consumes every pending leaf before it queues new ones */
   w.req = P.req + (size_t)g * P.searches_per_eval * CO_STATE_STRIDE;
   w.samples = P.samples ? P.samples + (size_t)g * CO_MAX_PLIES * CO_SAMPLE_FLOATS : (float *)0;
   w.trace = P.trace ? P.trace + (size_t)g * CO_TRACE_CAP : (int32_t *)0;
@@ -1285,13 +1267,11 @@ CO_DEV void co_mcts_step_wave(const EngineParams &P, int g) {
   int off = co_step_row(P, g, gc);
   int done = co_game_step(w, P.nn_eval + off, P.nn_probs + (size_t)off * CO_NUM_MOVES);
   if (done) w.gc.done = 1;
-  const int cut = w.gc.resume == 2; /* leaves stay queued, unsubmitted */
-  if (!done && !w.gc.error && w.gc.n_pending > 0 && !cut) co_capture_noise(w);
-  w.gc.noise_words = (uint32_t)w.noise_words;
+  if (!done && !w.gc.error && w.gc.n_pending > 0) co_capture_noise(w);
   if (P.fused_pack && !w.gc.done && !w.gc.error) {
     /* Trainer::writeRequests fused into the step: reserve rows of the compact batch
      * (any order: a row's evaluation does not depend on its position) and copy */
-    int n = cut ? 0 : w.gc.n_pending;
+    int n = w.gc.n_pending;
     unsigned long long old = co_atomic_add_u64(P.pack_counter + (P.iteration & 1), (1ull << 32) | (unsigned long long)n);
     int base = P.pool_row_base + (int)(unsigned)(old & 0xFFFFFFFFull);
     w.gc.row_off = base;

@@ -519,6 +519,8 @@ __device__ __forceinline__ u32x4 rc3_tap4_sel(const uint32_t (&in)[4], int tap, 
 template <int CS, int G, int NP, int NT>
 __device__ __forceinline__ void rcs_conv_group(f32x16 (&acc)[NP][2], const uint32_t (&p)[NT][NP][4][4], const uint32_t *wg,
                                                int lane) {
+  /* terms the B operand has: the stem's inputs (board bits 0 / 1, reserves k / 4) are exact in bf16 */
+  constexpr int XT = CS == 1 ? 1 : NT;
   constexpr int tw = CS == 1 ? RCS_STEM_CHUNK(NT) : RCS_CONV_CHUNK(NT);
   constexpr int N = 3 * CS;
   uint32_t zero;
@@ -543,17 +545,19 @@ __device__ __forceinline__ void rcs_conv_group(f32x16 (&acc)[NP][2], const uint3
     }
 #pragma unroll
     for (int np = 0; np < NP; ++np) {
-      bf16x8 B[NT];
+      bf16x8 B[XT];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) B[t] = __builtin_bit_cast(bf16x8, rc3_tap4_sel(p[t][np][s], 3 * G + tg, zero));
+      for (int t = 0; t < XT; ++t) B[t] = __builtin_bit_cast(bf16x8, rc3_tap4_sel(p[t][np][s], 3 * G + tg, zero));
 #pragma unroll
       for (int sum = 0; sum < NT; ++sum)
 #pragma unroll
         for (int i = 0; i <= sum; ++i)
+          if (sum - i < XT) {
 #pragma unroll
-          for (int to = 0; to < 2; ++to)
-            acc[np][to] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[cur][i][to]), B[sum - i],
-                                                                  acc[np][to], 0, 0, 0);
+            for (int to = 0; to < 2; ++to)
+              acc[np][to] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[cur][i][to]), B[sum - i],
+                                                                    acc[np][to], 0, 0, 0);
+          }
     }
   }
 }
