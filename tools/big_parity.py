@@ -2,7 +2,7 @@
 """One-off parity run at the bench's full size: a fused generation on the GPU, then EVERY game
 replayed on the CPU oracle (fed by the same device network through ca_trainer_net_forward) and
 compared bit for bit: sample tensors (state, policy, outcome), score, mate length.
-usage: big_parity.py [games] [sims] [net: mlp12x100|mlp12x100x3|rescnn4x3] [seed]"""
+usage: big_parity.py [games] [sims] [net: mlp12x100|mlp12x100x3|mlp12x100x6|rescnn4|rescnn4x3|rescnn4x6] [seed]"""
 import os
 import sys
 import time
@@ -11,15 +11,19 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from corintho_ai_amd import NET_MLP12X100, NET_RESCNN4_X3, Trainer, nets  # noqa: E402
+import corintho_ai_amd as CA  # noqa: E402
+from corintho_ai_amd import Trainer, nets  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 from tests import harness as H  # noqa: E402
 
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 400
-net = sys.argv[3] if len(sys.argv) > 3 else "rescnn4x3"
+net = sys.argv[3] if len(sys.argv) > 3 else "rescnn4x6"
 seed = int(sys.argv[4]) if len(sys.argv) > 4 else 12345
-kind, w = ((4 if net.endswith("x3") else NET_MLP12X100), nets.init_mlp12x100(0)) if net.startswith("mlp12x100") else (NET_RESCNN4_X3, nets.init_rescnn4(0))
+KINDS = {"mlp12x100": "NET_MLP12X100", "mlp12x100x3": "NET_MLP12X100_X3", "mlp12x100x6": "NET_MLP12X100_X6",
+         "rescnn4": "NET_RESCNN4", "rescnn4x3": "NET_RESCNN4_X3", "rescnn4x6": "NET_RESCNN4_X6"}
+kind = getattr(CA, KINDS[net])
+w = nets.init_mlp12x100(0) if net.startswith("mlp12x100") else nets.init_rescnn4(0)
 spe = 16
 t = Trainer(G, "", seed, S, spe, 1.0, 0.25, 0, 1, False, stagger=False)
 t.set_net(kind, w)
