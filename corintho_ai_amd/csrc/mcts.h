@@ -214,8 +214,23 @@ CO_DEV void co_capture_noise(CoWave &w) {
     if (cnt > CO_MT_N - w.gc.rng_idx) cnt = CO_MT_N - w.gc.rng_idx;
     const uint32_t *src = w.mt + w.gc.rng_idx;
     uint32_t *dst = w.noise_raw + done;
-    FOR_LANES {
-      for (int i = lane; i < cnt; i += CO_WAVE) dst[i] = src[i];
+    /* four chunks of 64 words at a time, loads first: their latencies overlap (a step owes ~450 words) */
+    for (int base = 0; base < cnt; base += 4 * CO_WAVE) {
+      LV(uint32_t, v[4]);
+      FOR_LANES {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int i = base + j * CO_WAVE + lane;
+          L(v[j]) = src[i < cnt ? i : 0];
+        }
+      }
+      FOR_LANES {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int i = base + j * CO_WAVE + lane;
+          if (i < cnt) dst[i] = L(v[j]);
+        }
+      }
     }
     WAVE_SYNC();
     w.gc.rng_idx += cnt;
@@ -1220,6 +1235,8 @@ CO_DEV void co_mcts_step_wave(const EngineParams &P, int g) {
     }
   }
   GameCtl gc = P.games[g];
+  /* both trees' control words, fetched with the game's (not behind it) */
+  const TreeCtl tc0 = P.trees[2 * g], tc1 = P.trees[2 * g + 1];
   const int gate = co_step_gate(P, g, gc);
   if (gate != 1) {
     if (gate == 2 && P.fused_pack) co_atomic_add_u64(P.pack_counter + (P.iteration & 1), 1ull << 32); /* still running */
@@ -1232,10 +1249,10 @@ CO_DEV void co_mcts_step_wave(const EngineParams &P, int g) {
     const size_t stride = (size_t)P.cap_units + CO_ARENA_PAD;
     const int tm = 2 * g + gc.to_play, to = 2 * g + 1 - gc.to_play;
     w.me.A = P.arena + (size_t)tm * stride;
-    w.me.tc = P.trees[tm];
+    w.me.tc = gc.to_play ? tc1 : tc0;
     w.me.cap = P.cap_units;
     w.opp.A = P.arena + (size_t)to * stride;
-    w.opp.tc = P.trees[to];
+    w.opp.tc = gc.to_play ? tc0 : tc1;
     w.opp.cap = P.cap_units;
   }
   w.mt = P.rng + (size_t)g * CO_MT_N;
@@ -1267,19 +1284,37 @@ CO_DEV void co_mcts_step_wave(const EngineParams &P, int g) {
   int off = co_step_row(P, g, gc);
   int done = co_game_step(w, P.nn_eval + off, P.nn_probs + (size_t)off * CO_NUM_MOVES);
   if (done) w.gc.done = 1;
+  /* Trainer::writeRequests fused into the step: reserve rows of the compact batch (any order: a row's
+   * evaluation does not depend on its position).  The atomic's round trip runs under the noise capture. */
+  const int packs = P.fused_pack && !w.gc.done && !w.gc.error;
+  unsigned long long old = 0ull;
+  if (packs) old = co_atomic_add_u64(P.pack_counter + (P.iteration & 1), (1ull << 32) | (unsigned long long)w.gc.n_pending);
   if (!done && !w.gc.error && w.gc.n_pending > 0) co_capture_noise(w);
-  if (P.fused_pack && !w.gc.done && !w.gc.error) {
-    /* Trainer::writeRequests fused into the step: reserve rows of the compact batch
-     * (any order: a row's evaluation does not depend on its position) and copy */
-    int n = w.gc.n_pending;
-    unsigned long long old = co_atomic_add_u64(P.pack_counter + (P.iteration & 1), (1ull << 32) | (unsigned long long)n);
-    int base = P.pool_row_base + (int)(unsigned)(old & 0xFFFFFFFFull);
+  if (packs) {
+    const int n = w.gc.n_pending;
+    const int base = P.pool_row_base + (int)(unsigned)(old & 0xFFFFFFFFull);
     w.gc.row_off = base;
-    const float *src = w.req;
-    float *dst = P.nn_in + (size_t)base * CO_STATE_STRIDE;
-    int total = n * CO_STATE_STRIDE;
-    FOR_LANES {
-      for (int i = lane; i < total; i += CO_WAVE) dst[i] = src[i];
+    /* rows are 80 floats = 20 16-byte units, contiguous on both sides; five units per lane and pass,
+     * loads first */
+    const uint4 *src = (const uint4 *)w.req;
+    uint4 *dst = (uint4 *)(P.nn_in + (size_t)base * CO_STATE_STRIDE);
+    const int total = n * (CO_STATE_STRIDE / 4);
+    for (int b0 = 0; b0 < total; b0 += 5 * CO_WAVE) {
+      LV(uint4, v[5]);
+      FOR_LANES {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          const int i = b0 + j * CO_WAVE + lane;
+          L(v[j]) = src[i < total ? i : 0];
+        }
+      }
+      FOR_LANES {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          const int i = b0 + j * CO_WAVE + lane;
+          if (i < total) dst[i] = L(v[j]);
+        }
+      }
     }
   }
   CO_PROF_ADD(w, 7, CO_CLK() - t_wave0);
