@@ -1051,3 +1051,9 @@ CoNet *co_rescnn_split_create(const float *weights, size_t n_floats, size_t max_
   if (n_floats != (size_t)RC_NUM_WEIGHTS || (nterms != 2 && nterms != 3)) return nullptr;
   return new ResCnnSplitNet(weights, max_rows, s, nterms);
 }
+
+#ifdef CO_WINOGRAD
+/* experiment, not part of the product build: the F(2x2, 3x3) formulation of the convolutions (kind 7).  Measured slower
+ * than co_k_rescnn_forward_x6 on gfx950 -- DESIGN.md "Measured and rejected" has the numbers and the reasons. */
+#include "exp/nn_rescnn_wino.inc"
+#endif

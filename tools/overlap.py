@@ -60,3 +60,15 @@ print("span %.1f ms; network busy (union) %.1f ms; search+priors busy (union) %.
       (span / 1e6, total(un) / 1e6, total(uk) / 1e6, inter(un, uk) / 1e6, (span - total(union(nn + k3 + pr))) / 1e6))
 print("search kernel: %d launches, mean %.1f us; priors mean %.1f us; network: %d launches, mean %.1f us" %
       (len(k3), total(k3) / max(len(k3), 1) / 1e3, total(pr) / max(len(pr), 1) / 1e3, len(nn), total(nn) / max(len(nn), 1) / 1e3))
+
+# distribution of the network launches by duration: how much of the span the thin iterations take
+import collections
+buckets = collections.OrderedDict((b, [0, 0.0]) for b in (100, 150, 200, 300, 500, 800, 1200, 10**9))
+for s, e in nn:
+    d = (e - s) / 1e3
+    for b in buckets:
+        if d < b:
+            buckets[b][0] += 1
+            buckets[b][1] += d
+            break
+print("network launches by duration (us): " + ", ".join("<%s: %d launches, %.1f ms" % ("inf" if b > 10**8 else b, n, t / 1e3) for b, (n, t) in buckets.items()))
