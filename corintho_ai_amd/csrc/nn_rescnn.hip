@@ -165,9 +165,9 @@ __device__ __forceinline__ void rc_epilogue(float (&out)[RC_NB][4][4], const f32
 /* ---- heads, shared by both precisions: x = the trunk output of this wave's RC_NB
  * positions (fp32, accumulator layout); feat_w = RC_NB x 96 floats of LDS owned by the wave */
 __device__ __forceinline__ void rc_dense_policy(const RcParams &P, const float *wpol, const float *feat16, int rows,
-                                                int pos_base, int lane);
+                                                int pos_base, int lane, int ncols = 16);
 __device__ __forceinline__ void rc_dense_value(const RcParams &P, const float *wv1, const float *wv2, const float *feat16,
-                                               int rows, int pos_base, int lane);
+                                               int rows, int pos_base, int lane, int ncols = 16);
 
 __device__ __forceinline__ void rc_heads(const RcParams &P, const float (&x)[RC_NB][4][4], float *feat_wg, int wave,
                                          int rows, int row0, int lane, int q, int c) {
@@ -215,7 +215,7 @@ __device__ __forceinline__ void rc_heads(const RcParams &P, const float (&x)[RC_
  * value head (Dense 32 -> 64, ReLU, Dense 64 -> 1, tanh), so the dense weights are read once
  * per 16 positions and no MFMA column is idle. */
 __device__ __forceinline__ void rc_dense_policy(const RcParams &P, const float *wpol, const float *feat16, int rows,
-                                                int pos_base, int lane) {
+                                                int pos_base, int lane, int ncols) {
   const int q = lane >> 4, c = lane & 15;
   const float *feat = feat16 + c * 96;
   f32x4 pl[6];
@@ -258,7 +258,7 @@ __device__ __forceinline__ void rc_dense_policy(const RcParams &P, const float *
   sum += __shfl_xor(sum, 32, 64);
   const float inv = 1.0f / sum;
   const int pos = pos_base + c;
-  if (pos < rows) {
+  if (pos < rows && c < ncols) { /* a workgroup of the thin kernel owns the first ncols = 8 columns of the tile only */
 #pragma unroll
     for (int to = 0; to < 6; ++to) {
       float4 p = make_float4(lg[to][0] * inv, lg[to][1] * inv, lg[to][2] * inv, lg[to][3] * inv);
@@ -268,7 +268,7 @@ __device__ __forceinline__ void rc_dense_policy(const RcParams &P, const float *
 }
 
 __device__ __forceinline__ void rc_dense_value(const RcParams &P, const float *wv1, const float *wv2, const float *feat16,
-                                               int rows, int pos_base, int lane) {
+                                               int rows, int pos_base, int lane, int ncols) {
   const int q = lane >> 4, c = lane & 15;
   const float *feat = feat16 + c * 96;
   f32x4 v1[4];
@@ -294,7 +294,7 @@ __device__ __forceinline__ void rc_dense_value(const RcParams &P, const float *w
     }
   }
   const int pos = pos_base + c;
-  if (q == 0 && pos < rows) P.eval[pos] = tanhf(v2[0] + P.bv2[0]);
+  if (q == 0 && pos < rows && c < ncols) P.eval[pos] = tanhf(v2[0] + P.bv2[0]);
 }
 
 __global__ __launch_bounds__(256, 2) void co_k_rescnn_forward(RcParams P) {
@@ -378,6 +378,7 @@ __global__ __launch_bounds__(256, 2) void co_k_rescnn_forward(RcParams P) {
  * operand sets + three weight fragment sets leave no registers for a second pair at two waves per
  * SIMD; the MFMA work per weight byte is that of NT = 2, NP = 2 again). */
 #define RC3_SMALL_ROWS 4096 /* NT = 2: batches up to this size take the small-batch kernel: <= 256 workgroups */
+#define RC6_THIN_ROWS 2048  /* NT = 3: batches up to this size take the four-wave kernel: <= 256 workgroups of 8 positions */
 #define RCS_STEM_CHUNK(NT) (512 * (NT))  /* u32: 1 k-step x 2 out tiles x NT terms x 64 lanes x 4 */
 #define RCS_CONV_CHUNK(NT) (2048 * (NT)) /* u32: 4 k-steps ... = 8 KB per term */
 #define RCS_TRUNK_WORDS(NT) (9 * RCS_STEM_CHUNK(NT) + 72 * RCS_CONV_CHUNK(NT))
@@ -421,14 +422,15 @@ __device__ __forceinline__ const uint32_t *rcs_group_ptr(const uint32_t *wtrunk,
 
 /* LDS-DMA of `words` (a multiple of 256) by the eight waves of the workgroup (lds_dma.h: the waits
  * are the kernel's own) */
-__device__ __forceinline__ void rcs_stage_words(const uint32_t *src, uint32_t lds_addr, int words, int wave, int lane) {
+__device__ __forceinline__ void rcs_stage_words(const uint32_t *src, uint32_t lds_addr, int words, int wave, int lane,
+                                                int nw = 8) {
   const int pieces = words / 256;
-  for (int p = wave; p < pieces; p += 8) co_lds_dma_1k(src + p * 256 + lane * 4, lds_addr + (uint32_t)p * 1024u);
+  for (int p = wave; p < pieces; p += nw) co_lds_dma_1k(src + p * 256 + lane * 4, lds_addr + (uint32_t)p * 1024u);
 }
 
 template <int NT>
-__device__ __forceinline__ void rcs_stage(const uint32_t *wtrunk, uint32_t lds_addr, int gi, int wave, int lane) {
-  rcs_stage_words(rcs_group_ptr<NT>(wtrunk, gi), lds_addr, gi < 3 ? 3 * RCS_STEM_CHUNK(NT) : 3 * RCS_CONV_CHUNK(NT), wave, lane);
+__device__ __forceinline__ void rcs_stage(const uint32_t *wtrunk, uint32_t lds_addr, int gi, int wave, int lane, int nw = 8) {
+  rcs_stage_words(rcs_group_ptr<NT>(wtrunk, gi), lds_addr, gi < 3 ? 3 * RCS_STEM_CHUNK(NT) : 3 * RCS_CONV_CHUNK(NT), wave, lane, nw);
 }
 
 /* (a, b) -> NT packed bf16 pairs: the values rounded to bf16, then the successive remainders (each
@@ -562,7 +564,7 @@ __device__ __forceinline__ void rcs_conv_group(f32x16 (&acc)[NP][2], const uint3
   }
 }
 
-template <int CS, int NP, int NT>
+template <int CS, int NP, int NT, int NW>
 __device__ __forceinline__ void rcs_conv3x3(f32x16 (&acc)[NP][2], const uint32_t (&p)[NT][NP][4][4], int &ch,
                                             const Rc3Params &Q, uint32_t *lds_w, uint32_t lds_w_addr, int wave, int lane) {
 #pragma unroll
@@ -576,9 +578,9 @@ __device__ __forceinline__ void rcs_conv3x3(f32x16 (&acc)[NP][2], const uint32_t
     CO_WAIT_VMCNT(0); /* group ch has landed (requested one group ago) */                                         \
     co_wg_barrier();  /* ... for every wave, and everyone has left the other buffer */                            \
     if (ch + 1 < RC3_NUM_GROUPS)                                                                                  \
-      rcs_stage<NT>(Q.wtrunk, lds_w_addr + (uint32_t)((ch + 1) & 1) * (RCS_GROUP_WORDS(NT) * 4u), ch + 1, wave, lane); \
+      rcs_stage<NT>(Q.wtrunk, lds_w_addr + (uint32_t)((ch + 1) & 1) * (RCS_GROUP_WORDS(NT) * 4u), ch + 1, wave, lane, NW); \
     else if (NT != 2) /* the head weights ride in the buffer the last group leaves idle */                        \
-      rcs_stage_words(Q.whead3, lds_w_addr + (uint32_t)((ch + 1) & 1) * (RCS_GROUP_WORDS(NT) * 4u), RCS_HEAD_WORDS(NT), wave, lane); \
+      rcs_stage_words(Q.whead3, lds_w_addr + (uint32_t)((ch + 1) & 1) * (RCS_GROUP_WORDS(NT) * 4u), RCS_HEAD_WORDS(NT), wave, lane, NW); \
     rcs_conv_group<CS, G, NP, NT>(acc, p, lds_w + (ch & 1) * RCS_GROUP_WORDS(NT), lane);                          \
     ++ch;                                                                                                         \
   }
@@ -652,7 +654,8 @@ extern "C" int ca_net_prof(unsigned long long out[8]) {
 #define RC3_STAMP(slot)
 #endif
 
-template <int NP, int NT>
+/* NW = waves per workgroup: 8 (two per SIMD), or 4 in the thin-batch kernel of NT = 3 (below) */
+template <int NP, int NT, int NW = 8>
 __device__ __forceinline__ void rcs_forward(const Rc3Params &Q) {
   const RcParams &P = Q.base;
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
@@ -662,7 +665,8 @@ __device__ __forceinline__ void rcs_forward(const Rc3Params &Q) {
   float *lds_feat = reinterpret_cast<float *>(NT == 2 ? lds_dyn + 2 * RCS_GROUP_WORDS(NT) : lds_dyn);
   const int rows = *P.d_rows;
   if (NT == 2 && (rows <= RC3_SMALL_ROWS) != (NP == 1)) return; /* the other kernel takes this batch */
-  const int row0 = blockIdx.x * (16 * NP);
+  if (NT == 3 && (rows <= RC6_THIN_ROWS) != (NW == 4)) return;
+  const int row0 = blockIdx.x * (2 * NP * NW);
   if (row0 >= rows) return;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, h = lane >> 5, p2 = (lane >> 4) & 1, c = lane & 15;
@@ -699,26 +703,26 @@ __device__ __forceinline__ void rcs_forward(const Rc3Params &Q) {
   /* weight stream, requested behind the input loads (vmcnt retires in issue order): group 0, the
    * epilogue constants and, with two terms, the head weights (the wait before the first MFMA
    * covers them) */
-  rcs_stage<NT>(Q.wtrunk, lds_w_addr, 0, wave, lane);
-  rcs_stage_words(Q.epi3, lds_epi_addr, RC3_EPI_WORDS, wave, lane);
-  if (NT == 2) rcs_stage_words(Q.whead3, lds_epi_addr + RC3_EPI_WORDS * 4u, RCS_HEAD_WORDS(NT), wave, lane);
+  rcs_stage<NT>(Q.wtrunk, lds_w_addr, 0, wave, lane, NW);
+  rcs_stage_words(Q.epi3, lds_epi_addr, RC3_EPI_WORDS, wave, lane, NW);
+  if (NT == 2) rcs_stage_words(Q.whead3, lds_epi_addr + RC3_EPI_WORDS * 4u, RCS_HEAD_WORDS(NT), wave, lane, NW);
   RC3_STAMP(0)
   f32x16 acc[NP][2];
   float y[NP][2][16];
   int ch = 0;
-  rcs_conv3x3<1, NP, NT>(acc, pk, ch, Q, lds_w, lds_w_addr, wave, lane);
+  rcs_conv3x3<1, NP, NT, NW>(acc, pk, ch, Q, lds_w, lds_w_addr, wave, lane);
   RC3_STAMP(1)
   const float *lds_epi = reinterpret_cast<const float *>(lds_epi_w);
   rc3_epilogue<false, NP>(x, acc, x, lds_epi, h);
   rcs_pack<NP, NT>(pk, x);
   RC3_STAMP(2)
   for (int b = 0; b < 4; ++b) {
-    rcs_conv3x3<4, NP, NT>(acc, pk, ch, Q, lds_w, lds_w_addr, wave, lane);
+    rcs_conv3x3<4, NP, NT, NW>(acc, pk, ch, Q, lds_w, lds_w_addr, wave, lane);
     RC3_STAMP(3)
     rc3_epilogue<false, NP>(y, acc, x, lds_epi + (1 + 2 * b) * 192, h);
     rcs_pack<NP, NT>(pk, y);
     RC3_STAMP(2)
-    rcs_conv3x3<4, NP, NT>(acc, pk, ch, Q, lds_w, lds_w_addr, wave, lane);
+    rcs_conv3x3<4, NP, NT, NW>(acc, pk, ch, Q, lds_w, lds_w_addr, wave, lane);
     RC3_STAMP(3)
     rc3_epilogue<true, NP>(x, acc, x, lds_epi + (2 + 2 * b) * 192, h);
     rcs_pack<NP, NT>(pk, x);
@@ -779,11 +783,12 @@ __device__ __forceinline__ void rcs_forward(const Rc3Params &Q) {
   /* 16 NP positions = NP column tiles: waves 0 (, 1) run their policy heads, waves 2 (, 3) their
    * value heads */
   const float *lds_dense = reinterpret_cast<const float *>(lds_head + RCS_FRAG1_WORDS(NT));
+  constexpr int ncols = NW == 4 ? 8 : 16; /* the thin kernel's workgroup is half a column tile */
   if (wave < NP)
-    rc_dense_policy(P, lds_dense, lds_feat + wave * 16 * 96, rows, row0 + wave * 16, lane);
+    rc_dense_policy(P, lds_dense, lds_feat + wave * 16 * 96, rows, row0 + wave * 16, lane, ncols);
   else if (wave >= 2 && wave < 2 + NP)
     rc_dense_value(P, lds_dense + 6144, lds_dense + 6144 + 2048, lds_feat + (wave - 2) * 16 * 96, rows,
-                   row0 + (wave - 2) * 16, lane);
+                   row0 + (wave - 2) * 16, lane, ncols);
   RC3_STAMP(5)
 #ifdef CO_PROF
   if (tid == 0) {
@@ -803,6 +808,13 @@ __global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_x3_small(Rc3Params
  * kernel's time overlapping the other pool's network launches already, tools/overlap.py.) */
 __global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_x6(Rc3Params Q) {
   rcs_forward<1, 3>(Q);
+}
+/* Thin batches (up to RC6_THIN_ROWS rows = 256 workgroups): four waves, one per SIMD, 8 positions per workgroup.  A batch
+ * that does not fill the chip is as slow as ONE workgroup's pass over the 27 weight groups; with the MFMA pipe of a SIMD
+ * to itself a wave finishes its 3456 MFMAs in half the time (the DPP operand shifts fit in their shadow).  The tail of a
+ * generation, the arena and the analysis mode run such batches every iteration. */
+__global__ __launch_bounds__(256, 1) void co_k_rescnn_forward_x6_thin(Rc3Params Q) {
+  rcs_forward<1, 3, 4>(Q);
 }
 
 /* ------------------------------------------------------------------ host */
@@ -1007,6 +1019,8 @@ struct ResCnnSplitNet : ResCnnNet {
     } else {
       RT_CHECK(hipFuncSetAttribute((const void *)co_k_rescnn_forward_x6, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    RCS_LDS_WORDS(3, 1) * 4));
+      RT_CHECK(hipFuncSetAttribute((const void *)co_k_rescnn_forward_x6_thin, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   RCS_LDS_WORDS(3, 1) * 4));
     }
     rt_sync(s);
   }
@@ -1036,7 +1050,11 @@ struct ResCnnSplitNet : ResCnnNet {
       if (rows_cap > RC3_SMALL_ROWS)
         hipLaunchKernelGGL(co_k_rescnn_forward_x3, dim3((rows_cap + 31) / 32), dim3(512), RCS_LDS_WORDS(2, 2) * 4, s, q);
     } else {
-      hipLaunchKernelGGL(co_k_rescnn_forward_x6, dim3((rows_cap + 15) / 16), dim3(512), RCS_LDS_WORDS(3, 1) * 4, s, q);
+      /* as above: both are queued, the row count on the device picks one */
+      const int thin_rows = rows_cap < RC6_THIN_ROWS ? rows_cap : RC6_THIN_ROWS;
+      hipLaunchKernelGGL(co_k_rescnn_forward_x6_thin, dim3((thin_rows + 7) / 8), dim3(256), RCS_LDS_WORDS(3, 1) * 4, s, q);
+      if (rows_cap > RC6_THIN_ROWS)
+        hipLaunchKernelGGL(co_k_rescnn_forward_x6, dim3((rows_cap + 15) / 16), dim3(512), RCS_LDS_WORDS(3, 1) * 4, s, q);
     }
     RT_CHECK(hipGetLastError());
   }

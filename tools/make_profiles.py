@@ -46,8 +46,16 @@ def counters(db):
 lines = ["# %s: kernel statistics (rocprofv3 --kernel-trace --stats), MI355X gfx950, ROCm 7.2" % tag, "",
          "Command: `%s`" % cmd, "", "| kernel | calls | total (us) | average (us) | share % |", "|---|---:|---:|---:|---:|"]
 db = db_of("stats")
+rows = {}
 for name, calls, total, avg, pct in db.execute("select name, total_calls, total_duration, average, percentage from top_kernels"):
     lines.append("| `%s` | %d | %.1f | %.3f | %.2f |" % (kname(name), calls, total, avg, pct))
+    rows[kname(name)] = (calls, total, pct)
+# a network launch queues two instances of some kernels (the row count on the device picks the one that works, the other
+# returns at once): one row per pair = what bench.py times as one launch
+for main, twin in (("co_k_rescnn_forward_x6", "co_k_rescnn_forward_x6_thin"), ("co_k_rescnn_forward_x3", "co_k_rescnn_forward_x3_small")):
+    if main in rows and twin in rows:
+        calls, total, pct = rows[main][0], rows[main][1] + rows[twin][1], rows[main][2] + rows[twin][2]
+        lines.append("| `%s` + `%s` (one network launch) | %d | %.1f | %.3f | %.2f |" % (main, twin.replace(main, ""), calls, total, total / max(calls, 1), pct))
 pmc = {"tag": tag, "command": cmd,
        "note": "rocprofv3 --pmc passes, one counter group per pass with --kernel-trace only. FETCH_SIZE / WRITE_SIZE "
                "are in KB (rocprofv3 units); HBM traffic per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 bytes "
