@@ -665,7 +665,8 @@ __device__ __forceinline__ void rcs_forward(const Rc3Params &Q) {
   float *lds_feat = reinterpret_cast<float *>(NT == 2 ? lds_dyn + 2 * RCS_GROUP_WORDS(NT) : lds_dyn);
   const int rows = *P.d_rows;
   if (NT == 2 && (rows <= RC3_SMALL_ROWS) != (NP == 1)) return; /* the other kernel takes this batch */
-  if (NT == 3 && (rows <= RC6_THIN_ROWS) != (NW == 4)) return;
+  constexpr bool thin = NT == 3 && NP == 1 && NW == 4;
+  if (NT == 3 && (rows <= RC6_THIN_ROWS) != thin) return;
   const int row0 = blockIdx.x * (2 * NP * NW);
   if (row0 >= rows) return;
   const int tid = threadIdx.x;
@@ -783,10 +784,11 @@ __device__ __forceinline__ void rcs_forward(const Rc3Params &Q) {
   /* 16 NP positions = NP column tiles: waves 0 (, 1) run their policy heads, waves 2 (, 3) their
    * value heads */
   const float *lds_dense = reinterpret_cast<const float *>(lds_head + RCS_FRAG1_WORDS(NT));
-  constexpr int ncols = NW == 4 ? 8 : 16; /* the thin kernel's workgroup is half a column tile */
-  if (wave < NP)
+  constexpr int wgpos = 2 * NP * NW, ntiles = (wgpos + 15) / 16;
+  constexpr int ncols = wgpos < 16 ? wgpos : 16; /* the thin kernel's workgroup is half a column tile */
+  if (wave < ntiles)
     rc_dense_policy(P, lds_dense, lds_feat + wave * 16 * 96, rows, row0 + wave * 16, lane, ncols);
-  else if (wave >= 2 && wave < 2 + NP)
+  else if (wave >= 2 && wave < 2 + ntiles)
     rc_dense_value(P, lds_dense + 6144, lds_dense + 6144 + 2048, lds_feat + (wave - 2) * 16 * 96, rows,
                    row0 + (wave - 2) * 16, lane, ncols);
   RC3_STAMP(5)
@@ -816,6 +818,7 @@ __global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_x6(Rc3Params Q) {
 __global__ __launch_bounds__(256, 1) void co_k_rescnn_forward_x6_thin(Rc3Params Q) {
   rcs_forward<1, 3, 4>(Q);
 }
+
 
 /* ------------------------------------------------------------------ host */
 struct ResCnnNet : CoNet {
@@ -1021,6 +1024,7 @@ struct ResCnnSplitNet : ResCnnNet {
                                    RCS_LDS_WORDS(3, 1) * 4));
       RT_CHECK(hipFuncSetAttribute((const void *)co_k_rescnn_forward_x6_thin, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    RCS_LDS_WORDS(3, 1) * 4));
+
     }
     rt_sync(s);
   }
