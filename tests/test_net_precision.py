@@ -82,12 +82,15 @@ def test_mlp12x100_bf16x6_is_float32_equivalent():
 def test_bf16x6_rows_do_not_depend_on_their_batch(kind, make):
     """SURVEY 8e invariant: a row's outputs are a function of the row only (fixed k order, no
     batch-dependent tiling), for every batch size around the kernels' tile boundaries"""
-    t = make_trainer("hip", 64, "", 1, 50, 16, 1.0, 0.25, 0, 1, False)
+    t = make_trainer("hip", 256, "", 1, 50, 16, 1.0, 0.25, 0, 1, False)
     t.set_net(kind, make())
-    states = _states(1024, 9)
+    states = _states(4096, 9)
     ev, pr = t.net_forward(states)
     assert np.all(np.abs(pr.sum(axis=1) - 1) < 1e-5)
-    for lo, hi in ((0, 1), (5, 6), (0, 15), (0, 16), (0, 17), (100, 131), (100, 228), (0, 129), (300, 1024)):
+    # ... and around 2048 rows, where the residual CNN changes from its four-wave thin-batch kernel (8 positions per
+    # workgroup) to the throughput kernel (16)
+    for lo, hi in ((0, 1), (5, 6), (0, 7), (0, 8), (0, 9), (0, 15), (0, 16), (0, 17), (100, 131), (100, 228), (0, 129), (300, 1024),
+                   (0, 2047), (0, 2048), (0, 2049), (1000, 3050), (2040, 4096)):
         e1, p1 = t.net_forward(states[lo:hi])
         assert np.array_equal(e1, ev[lo:hi]) and np.array_equal(p1, pr[lo:hi]), (lo, hi)
 
