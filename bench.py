@@ -104,9 +104,8 @@ def measured_traffic(kernel, args, net, npools):
         with open(os.path.join(ROOT, "profiles", "r02_%s_pmc.json" % net)) as f:
             k = json.load(f)["kernels"]
             t = k[kernel]["traffic_bytes_per_launch"]
-            for twin in ("_small", "_thin"):  # a network launch queues both instances of the kernel; one of them works
-                if kernel + twin in k:
-                    t += k[kernel + twin]["traffic_bytes_per_launch"]
+            if kernel + "_small" in k:  # the network launch queues both instances of the kernel; one of them works
+                t += k[kernel + "_small"]["traffic_bytes_per_launch"]
             return t
     except Exception:
         return None

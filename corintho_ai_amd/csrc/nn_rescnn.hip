@@ -665,8 +665,6 @@ __device__ __forceinline__ void rcs_forward(const Rc3Params &Q) {
   float *lds_feat = reinterpret_cast<float *>(NT == 2 ? lds_dyn + 2 * RCS_GROUP_WORDS(NT) : lds_dyn);
   const int rows = *P.d_rows;
   if (NT == 2 && (rows <= RC3_SMALL_ROWS) != (NP == 1)) return; /* the other kernel takes this batch */
-  constexpr bool thin = NT == 3 && NP == 1 && NW == 4;
-  if (NT == 3 && (rows <= RC6_THIN_ROWS) != thin) return;
   const int row0 = blockIdx.x * (2 * NP * NW);
   if (row0 >= rows) return;
   const int tid = threadIdx.x;
@@ -808,17 +806,20 @@ __global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_x3_small(Rc3Params
 /* (Capping this kernel at 168 registers so that a wave of the search kernel fits beside two of its waves on a SIMD was
  * measured: the network kernel alone 5 % slower, the generation 4 % slower -- the kernel trace shows 81 % of the search
  * kernel's time overlapping the other pool's network launches already, tools/overlap.py.) */
-__global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_x6(Rc3Params Q) {
-  rcs_forward<1, 3>(Q);
-}
 /* Thin batches (up to RC6_THIN_ROWS rows = 256 workgroups): four waves, one per SIMD, 8 positions per workgroup.  A batch
  * that does not fill the chip is as slow as ONE workgroup's pass over the 27 weight groups; with the MFMA pipe of a SIMD
  * to itself a wave finishes its 3456 MFMAs in half the time (the DPP operand shifts fit in their shadow).  The tail of a
- * generation, the arena and the analysis mode run such batches every iteration. */
-__global__ __launch_bounds__(256, 1) void co_k_rescnn_forward_x6_thin(Rc3Params Q) {
-  rcs_forward<1, 3, 4>(Q);
+ * generation, the arena and the analysis mode run such batches every iteration.  Same launch, same workgroups: the row
+ * count on the device picks the path, and waves 4..7 of a thin workgroup leave at once (a second kernel that merely
+ * returns would still queue 256 workgroups of 151 KB LDS behind the other pool's network launch). */
+__global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_x6(Rc3Params Q) {
+  if (*Q.base.d_rows <= RC6_THIN_ROWS) {
+    if (threadIdx.x >= 256) return;
+    rcs_forward<1, 3, 4>(Q);
+  } else {
+    rcs_forward<1, 3, 8>(Q);
+  }
 }
-
 
 /* ------------------------------------------------------------------ host */
 struct ResCnnNet : CoNet {
@@ -1022,8 +1023,6 @@ struct ResCnnSplitNet : ResCnnNet {
     } else {
       RT_CHECK(hipFuncSetAttribute((const void *)co_k_rescnn_forward_x6, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    RCS_LDS_WORDS(3, 1) * 4));
-      RT_CHECK(hipFuncSetAttribute((const void *)co_k_rescnn_forward_x6_thin, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   RCS_LDS_WORDS(3, 1) * 4));
 
     }
     rt_sync(s);
@@ -1054,11 +1053,10 @@ struct ResCnnSplitNet : ResCnnNet {
       if (rows_cap > RC3_SMALL_ROWS)
         hipLaunchKernelGGL(co_k_rescnn_forward_x3, dim3((rows_cap + 31) / 32), dim3(512), RCS_LDS_WORDS(2, 2) * 4, s, q);
     } else {
-      /* as above: both are queued, the row count on the device picks one */
+      /* enough workgroups for either path: 16 positions each in the throughput path, 8 in the thin one (<= 2048 rows) */
       const int thin_rows = rows_cap < RC6_THIN_ROWS ? rows_cap : RC6_THIN_ROWS;
-      hipLaunchKernelGGL(co_k_rescnn_forward_x6_thin, dim3((thin_rows + 7) / 8), dim3(256), RCS_LDS_WORDS(3, 1) * 4, s, q);
-      if (rows_cap > RC6_THIN_ROWS)
-        hipLaunchKernelGGL(co_k_rescnn_forward_x6, dim3((rows_cap + 15) / 16), dim3(512), RCS_LDS_WORDS(3, 1) * 4, s, q);
+      const int grid = (rows_cap + 15) / 16 > (thin_rows + 7) / 8 ? (rows_cap + 15) / 16 : (thin_rows + 7) / 8;
+      hipLaunchKernelGGL(co_k_rescnn_forward_x6, dim3(grid), dim3(512), RCS_LDS_WORDS(3, 1) * 4, s, q);
     }
     RT_CHECK(hipGetLastError());
   }
