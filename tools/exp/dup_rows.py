@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT)
 from corintho_ai_amd import NET_RESCNN4_X6, Trainer, nets  # noqa: E402
 
 G, SPE = int(sys.argv[1]) if len(sys.argv) > 1 else 4096, 16
-t = Trainer(G, "", 7, 400, SPE, 1.0, 0.25, 0, 1, False)
+t = Trainer(G, "", 7, 400, SPE, 1.0, 0.25, 0, 1, False, stagger=("--stagger" in sys.argv))
 t.set_net(NET_RESCNN4_X6, nets.init_rescnn4(0))
 states = np.zeros((G * SPE, 70), np.float32)
 evals = np.zeros((G * SPE,), np.float32)
