@@ -91,7 +91,37 @@ def parse():
     ap.add_argument("--pools", type=int, default=0, help="independent game pools on separate streams per GPU (0 = engine default)")
     ap.add_argument("--cpu-games", type=int, default=1024, help="games of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=6.0, help="CPU time budget of each CPU-baseline leg")
+    ap.add_argument("--engine", default="hip", choices=("hip", "emu"),
+                    help="hip = the product (libcorintho_hip.so on an MI355X).  emu = CPU rehearsal of the multi-rank path for "
+                         "the tests only: the lane-loop build of the same kernel source (tests/emu) over gloo; never a result")
     return ap.parse_args()
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, the
+    environment torch.distributed.run would give them), relay rank 0's JSON line, fail if any rank fails.
+    Runs before anything touches the GPU in this process."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               LOCAL_WORLD_SIZE=str(args.gpus), CORINTHO_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    procs = []
+    for r in range(args.gpus):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    if any(rcs):
+        raise SystemExit("bench.py --gpus %d: rank exit codes %s" % (args.gpus, rcs))
 
 
 def measured_traffic(kernel, args, net, npools):
@@ -194,8 +224,6 @@ def cpu_leg(args, G, threads, net_name, weights, budget_s, evals_per_game):
         if time.perf_counter() - t0 >= budget_s and iters >= 2:
             break
     dt = time.perf_counter() - t0
-    if net_name == "none":
-        dt -= 0.0
     return {"games_per_s": rows / dt / evals_per_game, "leaf_evals_per_s": rows / dt, "threads": threads, "net": net_name,
             "seconds": dt, "network_seconds": nn_s, "iterations": iters, "rows": rows, "finished": bool(done)}
 
@@ -215,6 +243,7 @@ def cpu_baseline(args, arch, weights_by_arch, evals_per_game):
         "unit": "games/s",
         "cores": cores,
         "kind": "port",
+        "extrapolated": not main["finished"],  # the first iterations of the generation, scaled by evaluations per game
         "cpu_model": cpu_model(),
         "sample": "oracle/ (C restatement of trainer.cpp/selfplayer.cpp/trainmc.cpp, OpenMP over games) + float32 %s on the host "
                   "(%s), %d threads: the first %d iterations of a %d-game generation of the bench workload (%d sims/move, spe %d; "
@@ -229,31 +258,40 @@ def cpu_baseline(args, arch, weights_by_arch, evals_per_game):
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            return launch_ranks(args)  # N child processes, one per GPU; this process never touches a GPU
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %s" % (args.gpus, os.environ["WORLD_SIZE"]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    emu = args.engine == "emu"
     dist = None
     torch = None
     use_dist = world > 1 or os.environ.get("CORINTHO_FORCE_DIST") == "1"  # the latter: 1-rank rehearsal of the RCCL path
+    dev = "cpu" if emu else "cuda"
     if use_dist:
         import torch
         import torch.distributed as dist
 
-        torch.cuda.set_device(local_rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        # RCCL prints a version banner on stdout when its communicator comes up; stdout carries ONE JSON line:
+        # RCCL (and gloo) print a banner on stdout when the communicator comes up; stdout carries ONE JSON line:
         # the communicator is brought up (first collective) with stdout pointing at stderr
         sys.stdout.flush()
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-            warm = torch.zeros(1, device="cuda")
-            dist.all_reduce(warm)
-            torch.cuda.synchronize()
+            if emu:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+                dist.all_reduce(torch.zeros(1))
+            else:
+                torch.cuda.set_device(local_rank)
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+                warm = torch.zeros(1, device="cuda")
+                dist.all_reduce(warm)
+                torch.cuda.synchronize()
         finally:
             sys.stdout.flush()
             os.dup2(saved_stdout, 1)
@@ -261,6 +299,12 @@ def main():
 
     import corintho_ai_amd as CA
     from corintho_ai_amd import Trainer, nets
+
+    cdll = None
+    if emu:
+        from tests.emu import emulib
+
+        cdll = emulib.load()
 
     G = args.games
     weights_by_arch = {"rescnn4": nets.init_rescnn4(0), "mlp12x100": nets.init_mlp12x100(0)}
@@ -273,14 +317,14 @@ def main():
     def make_trainer(pools):
         return Trainer(G, "", 12345, args.sims, args.spe, args.c_puct, args.epsilon, 0, 1, False, device=local_rank,
                        stagger=args.stagger, arena_units=args.arena_units, game_base=rank * G, total_games=world * G,
-                       pools=pools)
+                       pools=pools, _cdll=cdll)
 
     tr = make_trainer(args.pools)
     gatherer = None
     if use_dist:
         from corintho_ai_amd.dist import SampleGather
 
-        gatherer = SampleGather(tr, G, on_device=True)
+        gatherer = SampleGather(tr, G, on_device=not emu)
 
     STAT_KEYS = ("searches", "evals", "plies", "iterations", "mcts_ms", "nn_ms", "pack_ms", "nn_rows", "nn_launches",
                  "mcts_launches", "timed_launches", "nn_timed_rows", "mcts_timed_ms", "nn_timed_ms")
@@ -288,29 +332,36 @@ def main():
     def barrier():
         if use_dist:
             dist.barrier()
-            torch.cuda.synchronize()
+            if not emu:
+                torch.cuda.synchronize()
 
     def run_generations(trainer, net, steps, warmup, seed0, collective):
         """`warmup` untimed + `steps` timed generations of `net`; -> (seconds, totals)"""
         kind_name, arch = NETS[net][0], NETS[net][1]
         trainer.set_net(getattr(CA, kind_name), weights_by_arch[arch])
         totals = dict.fromkeys(STAT_KEYS, 0)
-        totals.update(gather_ms=0.0, samples=0, peak_arena_units=0, pools=1, gather_bytes=0, score=0.0, unfinished=0)
+        totals.update(gather_ms=0.0, samples=0, peak_arena_units=0, pools=1, gather_bytes=0, score=0.0, unfinished=0,
+                      gathered_samples=0)
 
         def one(seed, timed):
             trainer.reset(seed)
             done = trainer.run()
-            if not done:
-                raise RuntimeError("generation did not finish")
             if collective:
+                # every rank enters both collectives whatever its own generation did: a rank that raised before
+                # them would leave the others waiting in the all-gather
                 t0 = time.perf_counter()
-                gatherer.gather()  # C1: counts + one all-gather of the un-augmented samples
+                counts, _, _ = gatherer.gather()  # C1: counts + one all-gather of the un-augmented samples
                 score, unfinished = gatherer.score_and_unfinished(done)  # C2: one all-reduce of two scalars
                 if timed:
                     totals["gather_ms"] += (time.perf_counter() - t0) * 1e3
                     totals["gather_bytes"] += gatherer.bytes_moved
                     totals["score"] += score
                     totals["unfinished"] += unfinished
+                    totals["gathered_samples"] += int(counts.sum())
+                if unfinished:
+                    raise RuntimeError("generation did not finish on %d rank(s)" % unfinished)
+            elif not done:
+                raise RuntimeError("generation did not finish")
             if timed:
                 st = trainer.stats()
                 for k in STAT_KEYS:
@@ -359,15 +410,22 @@ def main():
 
     # ------------------------------------------------------------------ the timed region
     dt, totals = run_generations(tr, args.net, args.steps, args.warmup, 0, use_dist)
+    per_rank = [G * args.steps / dt]
+    ranks_seen = 1
     if use_dist:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-        agg = torch.tensor([totals["searches"], totals["evals"], totals["nn_rows"]], dtype=torch.float64, device="cuda")
+        mine = torch.tensor([dt], dtype=torch.float64, device=dev)
+        every = torch.zeros(dist.get_world_size(), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(every, mine)
+        per_rank = [G * args.steps / float(x) for x in every.tolist()]
+        ranks_seen = len(per_rank)
+        dt = float(every.max().item())  # the job takes as long as its slowest rank
+        agg = torch.tensor([totals["searches"], totals["evals"], totals["nn_rows"], totals["samples"]], dtype=torch.float64,
+                           device=dev)
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)
-        job_searches, job_evals, job_rows = [float(x) for x in agg.tolist()]
+        job_searches, job_evals, job_rows, job_samples = [float(x) for x in agg.tolist()]
     else:
         job_searches, job_evals, job_rows = float(totals["searches"]), float(totals["evals"]), float(totals["nn_rows"])
+        job_samples = float(totals["samples"])
 
     if rank == 0:
         _, arch, dtype, peak, issued, kname = NETS[args.net]
@@ -424,13 +482,19 @@ def main():
                 "mcts_GBps_algorithmic": totals["searches"] * BYTES_PER_SIM / max(mcts_s, 1e-12) / 1e9,
                 "network_TFLOPs_algorithmic": totals["nn_rows"] * flop_per_row / max(nn_s, 1e-12) / 1e12,
                 "peak_arena_units_per_tree": totals["peak_arena_units"],
+                "world_size": dist.get_world_size() if use_dist else 1,
+                "ranks_seen": ranks_seen,
+                "per_rank_games_per_s": per_rank,
+                "launched_by": "bench.py itself (one child process per GPU)" if os.environ.get("CORINTHO_BENCH_SELF_LAUNCHED")
+                               else ("torch.distributed.run / the caller's environment" if use_dist else "single process"),
             },
         }
         if use_dist:
             out["detail"]["collectives_per_step"] = {
                 "all_gather_counts": 1, "all_gather_samples": 1, "all_reduce_score_done": 1,
                 "sample_bytes_gathered_per_step": totals["gather_bytes"] / max(args.steps, 1),
-                "generation_score": totals["score"] / max(args.steps, 1), "unfinished_games": totals["unfinished"]}
+                "generation_score": totals["score"] / max(args.steps, 1), "unfinished_games": totals["unfinished"],
+                "samples_gathered": totals["gathered_samples"], "samples_of_all_shards": job_samples}
         if world == 1 and not args.no_variants:
             # the other network kinds on the same pool: the same timed loop, each with its own roofline object
             vsteps = max(1, min(args.variant_steps, args.steps))

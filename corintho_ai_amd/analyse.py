@@ -44,6 +44,10 @@ class Analyser:
     def run(self, max_iterations=0):
         return self._t.run(max_iterations)
 
+    def finish(self):
+        """DockerMC::chooseMove for the positions still searching (the reference's loop may stop on a time limit)"""
+        self._t.finish()
+
     def net_forward(self, states):
         return self._t.net_forward(states)
 

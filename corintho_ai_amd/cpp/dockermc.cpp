@@ -61,7 +61,13 @@ int32_t DockerMC::num_requests() const {
 void DockerMC::writeRequests(float *game_states) const { dcheck(ca_trainer_write_requests(impl_, game_states, -1)); }
 
 int32_t DockerMC::chooseMove() {
-  if (!finished_) throw std::runtime_error("DockerMC::chooseMove before doIteration returned true (see dockermc.h)");
+  if (!finished_) {
+    // the reference's loop also ends on its time limit (choose_move.pyx:110-117) and then chooses on the tree
+    // as it stands; so does the engine (ca_trainer_finish)
+    dcheck(ca_trainer_finish(impl_));
+    finished_ = true;
+    have_ = false;
+  }
   fetch();
   return res_[0];
 }

@@ -5,10 +5,10 @@
 // Drop-in use from the reference's Cython boundary (corintho_ai/docker/choose_move.pyx:21-42):
 //     cdef extern from "<repo>/corintho_ai_amd/cpp/dockermc.cpp":
 //         cdef cppclass DockerMC: ...           # declarations unchanged
-// Difference of protocol: the engine chooses the move itself when the search of a position is over
-// (doIteration returns true); chooseMove() reports that move.  The reference's loop stops on a time
-// limit OR on doIteration returning true (choose_move.pyx:110-117); here only the latter ends a
-// search, so give max_searches the budget the time limit stood for.  One position is one wavefront:
+// The engine chooses the move itself when the search of a position is over (doIteration returns
+// true) and chooseMove() reports that move; when the caller's loop stops earlier (the time limit of
+// choose_move.pyx:110-117), chooseMove() makes the engine choose on the tree as it stands
+// (ca_trainer_finish), as TrainMC::chooseMove does in the reference.  One position is one wavefront:
 // for throughput search many positions at once (corintho_ai_amd/analyse.py, ca_trainer_set_positions).
 #ifndef CORINTHO_AMD_DOCKERMC_H
 #define CORINTHO_AMD_DOCKERMC_H

@@ -2,6 +2,7 @@
 // replaces the reference member of the same name (trainer.cpp:18-236).
 #include "trainer.h"
 
+#include <cstdio>
 #include <stdexcept>
 
 #include "../../include/corintho_hip.h"
@@ -24,7 +25,10 @@ Trainer::Trainer(int32_t num_games, const std::string &log_folder, int32_t seed,
   cfg.c_puct = c_puct;
   cfg.epsilon = epsilon;
   cfg.num_logged = 0;  // the reference default (10) only selects which games are logged
-  (void)num_logged;
+  static bool told = false;
+  if (num_logged > 0 && !told && (told = true))
+    std::fprintf(stderr, "corintho_hip Trainer: num_logged = %d ignored -- per-game text logs (trainer.cpp:243-250) are not "
+                         "produced on the device\n", (int)num_logged);
   cfg.num_threads = num_threads;
   cfg.testing = testing ? 1 : 0;
   check(ca_trainer_create(&cfg, &impl_));

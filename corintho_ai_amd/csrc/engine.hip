@@ -70,10 +70,10 @@ template <typename T>
 struct DevBuf {
   T *p = nullptr;
   size_t n = 0;
-  void alloc(size_t count) {
+  void alloc(size_t count, rt_stream_t s) { /* zeroed, the clear queued on s (rt.h) */
     release();
     n = count;
-    rt_malloc((void **)&p, count * sizeof(T));
+    rt_malloc((void **)&p, count * sizeof(T), s);
   }
   void release() {
     if (p) rt_free(p);
@@ -171,8 +171,8 @@ struct ca_trainer {
   }
 
   template <typename T>
-  static void ensure(DevBuf<T> &b, size_t count) {
-    if (b.n < count) b.alloc(count + count / 4);
+  void ensure(DevBuf<T> &b, size_t count) {
+    if (b.n < count) b.alloc(count + count / 4, stream);
   }
 
   /* Page-lock a caller buffer (the three arrays of main.pyx:132-134 live as long as the Trainer):
@@ -224,36 +224,37 @@ struct ca_trainer {
       cap = (uint32_t)std::min<uint64_t>(nodes * 40, 0x7FFFFFF0ull);
     }
     size_t T = (size_t)2 * G;
-    games.alloc(G);
-    trees.alloc(T);
-    arena.alloc(T * ((size_t)cap + CO_ARENA_PAD));
-    pend_leaf.alloc((size_t)G * spe);
-    pend_depth.alloc((size_t)G * spe);
-    pend_n.alloc((size_t)G * spe * 4);
-    noise_raw.alloc((size_t)G * spe * CO_NUM_MOVES);
-    pend_path.alloc((size_t)G * spe * CO_PATH_MAX);
-    rng.alloc((size_t)G * CO_MT_N);
-    req.alloc((size_t)G * spe * CO_STATE_STRIDE);
-    req_offset.alloc((size_t)G + 1);
-    nn_in.alloc((size_t)G * spe * CO_STATE_STRIDE);
-    nn_in70.alloc((size_t)G * spe * CO_GAME_STATE_SIZE);
-    ctl.alloc(4);
+    games.alloc(G, stream);
+    trees.alloc(T, stream);
+    arena.alloc(T * ((size_t)cap + CO_ARENA_PAD), stream);
+    pend_leaf.alloc((size_t)G * spe, stream);
+    pend_depth.alloc((size_t)G * spe, stream);
+    pend_n.alloc((size_t)G * spe * 4, stream);
+    noise_raw.alloc((size_t)G * spe * CO_NUM_MOVES, stream);
+    pend_path.alloc((size_t)G * spe * CO_PATH_MAX, stream);
+    rng.alloc((size_t)G * CO_MT_N, stream);
+    req.alloc((size_t)G * spe * CO_STATE_STRIDE, stream);
+    req_offset.alloc((size_t)G + 1, stream);
+    nn_in.alloc((size_t)G * spe * CO_STATE_STRIDE, stream);
+    nn_in70.alloc((size_t)G * spe * CO_GAME_STATE_SIZE, stream);
+    ctl.alloc(4, stream);
     rt_host_alloc((void **)&h_ctl, 16);
-    nn_eval.alloc((size_t)G * spe);
-    nn_probs.alloc((size_t)G * spe * CO_NUM_MOVES);
-    if (!cfg.testing) samples.alloc((size_t)G * CO_MAX_PLIES * CO_SAMPLE_FLOATS);
-    if (cfg.trace) trace.alloc((size_t)G * CO_TRACE_CAP);
-    all_done.alloc(1);
-    row_counter.alloc(1);
-    pack_counter.alloc(2 * CO_MAX_POOLS);
-    arena_state.alloc(8);
+    nn_eval.alloc((size_t)G * spe, stream);
+    nn_probs.alloc((size_t)G * spe * CO_NUM_MOVES, stream);
+    if (!cfg.testing) samples.alloc((size_t)G * CO_MAX_PLIES * CO_SAMPLE_FLOATS, stream);
+    if (cfg.trace) trace.alloc((size_t)G * CO_TRACE_CAP, stream);
+    all_done.alloc(1, stream);
+    row_counter.alloc(1, stream);
+    pack_counter.alloc(2 * CO_MAX_POOLS, stream);
+    arena_state.alloc(8, stream);
     if (tourney) {
-      pcfg.alloc(host_pcfg.size());
+      pcfg.alloc(host_pcfg.size(), stream);
       rt_h2d(pcfg.p, host_pcfg.data(), host_pcfg.size() * sizeof(PlayerCfg), stream);
-      read_offset.alloc((size_t)G);
+      read_offset.alloc((size_t)G, stream);
     }
 
-    reset_games(cfg.seed);
+    /* (an analysis trainer is reset by set_positions, once the positions and their seeds are known) */
+    if (!cfg.analyse) reset_games(cfg.seed);
     memset(&P, 0, sizeof P);
     fill_params(cap, cfg.total_games > 0 ? cfg.total_games : G);
   }
@@ -372,7 +373,7 @@ struct ca_trainer {
     P.pool_row_base = 0;
     P.pack_counter = pack_counter.p;
 #ifdef CO_PROF
-    prof.alloc((size_t)G * 16 + 24);
+    prof.alloc((size_t)G * 16 + 24, stream);
     P.prof = prof.p;
 #else
     P.prof = nullptr;
@@ -421,7 +422,11 @@ struct ca_trainer {
   }
 
   /* Trainer::doIteration (trainer.cpp:164-236), compat protocol */
+  void need_positions() const {
+    if (cfg.analyse && an_pos.empty()) throw EngineError(CA_ERR_STATE, "analysis trainer: ca_trainer_set_positions first");
+  }
   bool do_iteration(const float *evals, const float *probs, int to_play) {
+    need_positions();
     if (to_play != 0 && to_play != 1) to_play = -1;
     if (iterations > 0) {
       pack(to_play); /* offsets the reference computes at entry */
@@ -648,7 +653,7 @@ struct ca_trainer {
     DevBuf<uint64_t> db;
     DevBuf<uint32_t> dm, dk;
     DevBuf<int32_t> dl;
-    db.alloc(G); dm.alloc(G); dk.alloc((size_t)G * 3); dl.alloc(G);
+    db.alloc(G, stream); dm.alloc(G, stream); dk.alloc((size_t)G * 3, stream); dl.alloc(G, stream);
     rt_h2d(db.p, hb.data(), (size_t)G * 8, stream);
     rt_h2d(dm.p, hm.data(), (size_t)G * 4, stream);
     RT_LAUNCH(co_k_rules_batch, G, CO_WAVE, stream, (const uint64_t *)db.p, (const uint32_t *)dm.p, G, dk.p, dl.p);
@@ -664,12 +669,13 @@ struct ca_trainer {
 
   void analysis(int32_t *out) {
     if (!cfg.analyse) throw EngineError(CA_ERR_STATE, "not an analysis trainer");
-    std::vector<uint32_t> rows((size_t)G * spe * CO_STATE_STRIDE);
-    rt_d2h(rows.data(), req.p, rows.size() * 4, stream);
+    /* the eight result words at the head of each slot's request area (mcts.h co_analyse_finish): one strided copy */
+    std::vector<uint32_t> rows((size_t)G * 8);
+    rt_d2h_2d(rows.data(), 32, req.p, (size_t)spe * CO_STATE_STRIDE * 4, 32, (size_t)G, stream);
     rt_sync(stream);
     fetch_games();
     for (int g = 0; g < G; ++g) {
-      const uint32_t *r = &rows[(size_t)g * spe * CO_STATE_STRIDE];
+      const uint32_t *r = &rows[(size_t)g * 8];
       int32_t *o = out + (size_t)g * 8;
       if (!host_games[g].done || r[7] != 1u) throw EngineError(CA_ERR_STATE, "analysis: search of position " + std::to_string(g) + " is not finished");
       const int res = (int)r[1];
@@ -682,6 +688,25 @@ struct ca_trainer {
       o[6] = (int32_t)r[5];
       o[7] = (int32_t)r[6];
     }
+  }
+
+  /* DockerMC::chooseMove on searches that have not ended (the reference's loop leaves on a time limit,
+   * choose_move.pyx:110-117, and then calls chooseMove unconditionally, :199): every unfinished position
+   * chooses on its tree as it stands; evaluations still pending are never received (trainmc.cpp:110-137 does
+   * not look at searched_).  Before the first iteration the root is created first, as the constructor does. */
+  void finish_analysis() {
+    if (!cfg.analyse) throw EngineError(CA_ERR_STATE, "ca_trainer_finish: not an analysis trainer");
+    if (iterations == 0) do_iteration(nullptr, nullptr, -1);
+    P.to_play = -1;
+    P.iteration = trainer_iteration;
+    P.force_choose = 1;
+    RT_LAUNCH(co_k_mcts_step, G, CO_WAVE, stream, P);
+    P.force_choose = 0;
+    ++mcts_launches;
+    scan_valid = false;
+    host_games_valid = false;
+    pack(-1);
+    check_errors();
   }
 
   /* ------------------------------------------------------------ fused mode */
@@ -872,6 +897,7 @@ struct ca_trainer {
   }
 
   bool run(int64_t max_iterations) {
+    need_positions();
     if (!nets[0]) throw EngineError(CA_ERR_STATE, "ca_trainer_run: no network set (ca_trainer_set_net)");
     if (cfg.testing && !cfg.analyse && !nets[1]) throw EngineError(CA_ERR_STATE, "arena mode needs both networks");
     if (!cfg.testing || cfg.analyse) { /* one network, every slot active: self-play training, or N position searches */
@@ -1032,6 +1058,7 @@ extern "C" int ca_trainer_set_positions(ca_trainer *t, const int32_t *boards, co
   CA_TGUARD(t->set_positions(boards, to_play, pieces, seeds))
 }
 extern "C" int ca_trainer_analysis(ca_trainer *t, int32_t *out) { CA_TGUARD(t->analysis(out)) }
+extern "C" int ca_trainer_finish(ca_trainer *t) { CA_TGUARD(t->finish_analysis()) }
 extern "C" int ca_trainer_reset(ca_trainer *t, int32_t seed) { CA_TGUARD(t->reset_games(seed)) }
 /* ------------------------------------------------------------------ Tourney C ABI */
 struct ca_tourney {
@@ -1049,6 +1076,7 @@ struct ca_tourney {
   };
   std::map<int, PendingNet> net_specs;         /* fused mode: model id -> network (ca_tourney_set_net) */
   std::map<int, std::unique_ptr<CoNet>> nets;
+  bool exact_offsets = false;                  /* ca_tourney_set_exact_offsets */
 
   /* The loop of rating/tourney.pyx:122-160 with the networks on the GPU: for every model id in
    * ascending order, pack that model's requests (Tourney::writeRequests), evaluate them, iterate
@@ -1138,6 +1166,7 @@ struct ca_tourney {
     }
     t->match_seeds = seeds;
     t->init(c);
+    if (exact_offsets) t->P.read_offset = nullptr; /* co_step_row falls back to the writeRequests rows */
     pool = std::move(t);
     return *pool;
   }
@@ -1196,6 +1225,12 @@ extern "C" int ca_tourney_set_net(ca_tourney *t, int32_t model_id, int32_t kind,
     spec.w.assign(weights, weights + n_floats);
     t->net_specs[model_id] = std::move(spec);
     t->nets.erase(model_id);
+  })
+}
+extern "C" int ca_tourney_set_exact_offsets(ca_tourney *t, int32_t on) {
+  CA_GUARD({
+    if (t->pool) throw EngineError(CA_ERR_STATE, "set_exact_offsets after the tournament has started");
+    t->exact_offsets = on != 0;
   })
 }
 extern "C" int ca_tourney_run(ca_tourney *t, int64_t max_rounds, int32_t *all_done) {
@@ -1305,7 +1340,7 @@ extern "C" int ca_trainer_net_bench(ca_trainer *t, int slot, const float *states
     for (int r = 0; r < rows; ++r)
       memcpy(&pad[(size_t)r * CO_STATE_STRIDE], states + (size_t)r * CO_GAME_STATE_SIZE, CO_GAME_STATE_SIZE * 4);
     DevBuf<int32_t> d_n;
-    d_n.alloc(1);
+    d_n.alloc(1, t->stream);
     rt_h2d(t->nn_in.p, pad.data(), pad.size() * 4, t->stream);
     rt_h2d(d_n.p, &rows, 4, t->stream);
     t->nets[slot]->forward(t->nn_in.p, rows, d_n.p, t->nn_eval.p, t->nn_probs.p, t->stream); /* warm */
@@ -1417,7 +1452,7 @@ extern "C" int ca_rules_legal_moves(int device, const uint64_t *boards, const ui
     DevBuf<uint64_t> b;
     DevBuf<uint32_t> m, mk;
     DevBuf<int32_t> ln;
-    b.alloc(n); m.alloc(n); mk.alloc((size_t)n * 3); ln.alloc(n);
+    b.alloc(n, ts.s); m.alloc(n, ts.s); mk.alloc((size_t)n * 3, ts.s); ln.alloc(n, ts.s);
     rt_h2d(b.p, boards, (size_t)n * 8, ts.s);
     rt_h2d(m.p, metas, (size_t)n * 4, ts.s);
     RT_LAUNCH(co_k_rules_batch, n, CO_WAVE, ts.s, (const uint64_t *)b.p, (const uint32_t *)m.p, n, mk.p, ln.p);
@@ -1436,7 +1471,7 @@ extern "C" int ca_rules_do_move(int device, uint64_t *boards, uint32_t *metas, c
     DevBuf<uint32_t> m;
     DevBuf<int32_t> mv;
     DevBuf<float> st;
-    b.alloc(n); m.alloc(n); mv.alloc(n); st.alloc((size_t)n * CO_STATE_STRIDE);
+    b.alloc(n, ts.s); m.alloc(n, ts.s); mv.alloc(n, ts.s); st.alloc((size_t)n * CO_STATE_STRIDE, ts.s);
     rt_h2d(b.p, boards, (size_t)n * 8, ts.s);
     rt_h2d(m.p, metas, (size_t)n * 4, ts.s);
     rt_h2d(mv.p, moves, (size_t)n * 4, ts.s);
@@ -1462,7 +1497,7 @@ extern "C" int ca_rng_draw(int device, uint32_t seed, int32_t n, int32_t chunk, 
     for (int i = 1; i < CO_MT_N; ++i) x[i] = 1812433253u * (x[i - 1] ^ (x[i - 1] >> 30)) + (uint32_t)i;
     DevBuf<uint32_t> mt, o;
     DevBuf<int32_t> idx;
-    mt.alloc(CO_MT_N); o.alloc(n); idx.alloc(1);
+    mt.alloc(CO_MT_N, ts.s); o.alloc(n, ts.s); idx.alloc(1, ts.s);
     int32_t i0 = CO_MT_N;
     rt_h2d(mt.p, x.data(), CO_MT_N * 4, ts.s);
     rt_h2d(idx.p, &i0, 4, ts.s);
@@ -1478,7 +1513,7 @@ extern "C" int ca_fp_probe(int device, const float *in, int32_t n, float *out) {
   CA_GUARD({
     TmpStream ts(device);
     DevBuf<float> di, dout;
-    di.alloc((size_t)n * 8); dout.alloc((size_t)n * 8);
+    di.alloc((size_t)n * 8, ts.s); dout.alloc((size_t)n * 8, ts.s);
     rt_h2d(di.p, in, (size_t)n * 32, ts.s);
     RT_LAUNCH(co_k_fp_probe, (n + CO_WAVE - 1) / CO_WAVE, CO_WAVE, ts.s, (const float *)di.p, n, dout.p);
     rt_d2h(out, dout.p, (size_t)n * 32, ts.s);

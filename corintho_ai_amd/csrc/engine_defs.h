@@ -114,6 +114,10 @@ struct EngineParams {
    * the root is created from gc.pos_* at depth 0, testing = true, and the slot finishes with its
    * first chooseMove; results in the slot's request area (mcts.h co_analyse_finish) */
   int32_t analyse;
+  /* analysis mode, ca_trainer_finish: this launch does not search -- every unfinished slot chooses its move on
+   * the tree as it stands (DockerMC::chooseMove called after a time limit, choose_move.pyx:110-117 + :199), the
+   * evaluations still pending are never received, as in the reference */
+  int32_t force_choose;
   /* tournament mode (Match / Tourney): per-match players [2G]; to_play then carries the MODEL id
    * whose matches run (Match::to_play, match.cpp:42-44); read_offset[G] = the reference's
    * offset table of Tourney::doIteration (tourney.cpp:55-62) */

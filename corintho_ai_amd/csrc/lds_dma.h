@@ -14,8 +14,11 @@
 //     LDS reads
 // A slot may be requested again once every wave has passed a barrier behind its last read of it
 // (a wave that reaches the barrier has issued the MFMAs that consumed those reads).
-// M0 is written by these statements only; the kernels that include this header use no other
-// instruction that reads M0.
+// M0 is written by these statements.  It cannot be named in their clobber lists (clang: "inline asm clobber
+// list contains reserved registers: m0 ... may lead to undefined behaviour" -- M0 is a reserved register that
+// the compiler never keeps live: it re-materialises M0 with an s_mov glued to each of its own instructions
+// that read it, so a write in between is not observed); the statements are volatile and clobber memory, which
+// keeps them in program order relative to each other and to the kernel's LDS accesses.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -36,7 +39,9 @@ __device__ __forceinline__ void co_lds_dma_1k(const void *g_lane_ptr, uint32_t l
 /* s_barrier without the fence of __syncthreads() (which would drain vmcnt): LDS data written by
  * DMA is ordered by the CO_WAIT_VMCNT in front of it */
 __device__ __forceinline__ void co_wg_barrier() {
-  asm volatile("" ::: "memory");
+  /* this wave's LDS reads and writes have completed before it signals (what __syncthreads adds in front
+   * of s_barrier, without its vmcnt drain): slot reuse does not rest on in-order LDS issue */
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 }

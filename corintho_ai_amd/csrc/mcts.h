@@ -59,7 +59,7 @@ struct CoWave {
   int32_t *trace;
   unsigned long long *prof;
   /* config */
-  int max_searches, spe, testing, trace_on, defer_handover, analyse;
+  int max_searches, spe, testing, trace_on, defer_handover, analyse, force_choose;
   float c_puct, epsilon;
   const PlayerCfg *pc; /* tournament match: the two players' settings, else null */
 };
@@ -1091,7 +1091,7 @@ CO_DEV int co_game_step(CoWave &w, const float *eval, const float *probs) {
     w.gc.resume = 0;
     ev = pr = (const float *)0;
   }
-  int skip_iteration = w.pc && w.pc[w.gc.to_play].random; /* match.cpp:68-70 */
+  int skip_iteration = (w.pc && w.pc[w.gc.to_play].random) /* match.cpp:68-70 */ || w.force_choose;
   int fresh_root = 0;
   for (;;) {
     if (!skip_iteration) {
@@ -1272,6 +1272,7 @@ CO_DEV void co_mcts_step_wave(const EngineParams &P, int g) {
   w.trace_on = P.trace_on && P.trace;
   w.defer_handover = P.defer_handover;
   w.analyse = P.analyse;
+  w.force_choose = P.analyse && P.force_choose;
   w.c_puct = P.c_puct;
   w.epsilon = P.epsilon;
   w.pc = P.pcfg ? P.pcfg + 2 * g : (const PlayerCfg *)0;

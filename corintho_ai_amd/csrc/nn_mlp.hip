@@ -216,10 +216,10 @@ struct MlpNet : CoNet {
     }
     for (int o = 0; o < 96; ++o) bias[(size_t)12 * MLP_PADW + o] = bp[o];
     bias[(size_t)12 * MLP_PADW + 96] = bv[0];
-    rt_malloc((void **)&d_wfrag, wf.size() * 4);
-    rt_malloc((void **)&d_bias, bias.size() * 4);
-    rt_malloc((void **)&d_a, ba.size() * 4);
-    rt_malloc((void **)&d_b, bb.size() * 4);
+    rt_malloc((void **)&d_wfrag, wf.size() * 4, s);
+    rt_malloc((void **)&d_bias, bias.size() * 4, s);
+    rt_malloc((void **)&d_a, ba.size() * 4, s);
+    rt_malloc((void **)&d_b, bb.size() * 4, s);
     rt_h2d(d_wfrag, wf.data(), wf.size() * 4, s);
     rt_h2d(d_bias, bias.data(), bias.size() * 4, s);
     rt_h2d(d_a, ba.data(), ba.size() * 4, s);

@@ -365,7 +365,7 @@ struct MlpSplitNet : CoNet {
         memcpy(&buf[(size_t)2 * l * chunk_words + 4 * step_words + o], &b, 4);
       }
     }
-    rt_malloc((void **)&d_w, buf.size() * 4);
+    rt_malloc((void **)&d_w, buf.size() * 4, s);
     rt_h2d(d_w, buf.data(), buf.size() * 4, s);
     rt_sync(s);
     if (nt == 2)

@@ -829,7 +829,7 @@ struct ResCnnNet : CoNet {
 
   float *upload(const std::vector<float> &h, rt_stream_t s) {
     float *d = nullptr;
-    rt_malloc((void **)&d, h.size() * 4);
+    rt_malloc((void **)&d, h.size() * 4, s);
     rt_h2d(d, h.data(), h.size() * 4, s);
     bufs.push_back(d);
     return d;
@@ -1006,14 +1006,14 @@ struct ResCnnSplitNet : ResCnnNet {
             for (int t = 0; t < nt; ++t)
               wh3[(((size_t)st * nt + t) * 64 + lane) * 4 + j / 2] |= (uint32_t)tv[t] << (16 * (j & 1));
           }
-    rt_malloc((void **)&d_trunk3, tr.size() * 4);
+    rt_malloc((void **)&d_trunk3, tr.size() * 4, s);
     rt_h2d(d_trunk3, tr.data(), tr.size() * 4, s);
-    rt_malloc((void **)&d_whead3, head_words * 4);
+    rt_malloc((void **)&d_whead3, head_words * 4, s);
     rt_h2d(d_whead3, wh3.data(), wh3.size() * 4, s);
     rt_d2d(d_whead3 + frag1, P.wpol, 6144 * 4, s); /* the dense weights in the base class's MFMA order */
     rt_d2d(d_whead3 + frag1 + 6144, P.wv1, 2048 * 4, s);
     rt_d2d(d_whead3 + frag1 + 6144 + 2048, P.wv2, 1024 * 4, s);
-    rt_malloc((void **)&d_epi3, (size_t)RC3_EPI_WORDS * 4); /* zero-filled: the padding is staged too */
+    rt_malloc((void **)&d_epi3, (size_t)RC3_EPI_WORDS * 4, s); /* zero-filled: the padding is staged too */
     rt_d2d(d_epi3, P.epi, (size_t)RC_NUM_CONVS * 192 * 4, s);
     if (nt == 2) {
       RT_CHECK(hipFuncSetAttribute((const void *)co_k_rescnn_forward_x3, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1075,5 +1075,5 @@ CoNet *co_rescnn_split_create(const float *weights, size_t n_floats, size_t max_
 #ifdef CO_WINOGRAD
 /* experiment, not part of the product build: the F(2x2, 3x3) formulation of the convolutions (kind 7).  Measured slower
  * than co_k_rescnn_forward_x6 on gfx950 -- DESIGN.md "Measured and rejected" has the numbers and the reasons. */
-#include "exp/nn_rescnn_wino.inc"
+#include "../../tools/exp/nn_rescnn_wino.inc"
 #endif

@@ -16,7 +16,7 @@ struct rt_event_t {
   int dummy;
 };
 inline void rt_set_device(int) {}
-inline void rt_malloc(void **p, size_t n) {
+inline void rt_malloc(void **p, size_t n, rt_stream_t) {
   *p = calloc(1, n ? n : 1);
   if (!*p) throw std::runtime_error("emu: out of memory");
 }
@@ -24,6 +24,9 @@ inline void rt_free(void *p) { free(p); }
 inline void rt_h2d(void *d, const void *h, size_t n, rt_stream_t) { memcpy(d, h, n); }
 inline void rt_d2h(void *h, const void *d, size_t n, rt_stream_t) { memcpy(h, d, n); }
 inline void rt_d2d(void *d, const void *s, size_t n, rt_stream_t) { memcpy(d, s, n); }
+inline void rt_d2h_2d(void *h, size_t hpitch, const void *d, size_t dpitch, size_t width, size_t rows, rt_stream_t) {
+  for (size_t r = 0; r < rows; ++r) memcpy((char *)h + r * hpitch, (const char *)d + r * dpitch, width);
+}
 inline void rt_memset(void *d, int v, size_t n, rt_stream_t) { memset(d, v, n); }
 inline void rt_sync(rt_stream_t) {}
 inline void rt_stream_create(rt_stream_t *s) { *s = 0; }
@@ -33,7 +36,7 @@ inline void rt_event_destroy(rt_event_t) {}
 inline void rt_event_record(rt_event_t, rt_stream_t) {}
 inline void rt_event_sync(rt_event_t) {}
 inline float rt_event_elapsed_ms(rt_event_t, rt_event_t) { return 0.0f; }
-inline void rt_host_alloc(void **p, size_t n) { rt_malloc(p, n); }
+inline void rt_host_alloc(void **p, size_t n) { rt_malloc(p, n, 0); }
 inline void rt_host_free(void *p) { free(p); }
 inline bool rt_host_register(void *, size_t) { return true; }
 inline void rt_host_unregister(void *) {}
@@ -55,12 +58,12 @@ inline void rt_check(hipError_t e, const char *what) {
 }
 #define RT_CHECK(x) rt_check((x), #x)
 inline void rt_set_device(int d) { RT_CHECK(hipSetDevice(d)); }
-inline void rt_malloc(void **p, size_t n) {
+/* zeroed device memory; the clear is queued on the caller's stream `s` (the engine's streams are
+ * non-blocking, so a clear on the null stream would not be ordered with them) and the caller's later
+ * work on `s` -- or its next rt_sync(s) before other streams touch the buffer -- is ordered behind it */
+inline void rt_malloc(void **p, size_t n, hipStream_t s) {
   RT_CHECK(hipMalloc(p, n ? n : 1));
-  /* hipMemset on device memory may return before it has run, and the engine's
-   * streams are non-blocking: finish the clear before anyone writes the buffer */
-  RT_CHECK(hipMemset(*p, 0, n ? n : 1));
-  RT_CHECK(hipDeviceSynchronize());
+  RT_CHECK(hipMemsetAsync(*p, 0, n ? n : 1, s));
 }
 inline void rt_free(void *p) {
   if (p) (void)hipFree(p);
@@ -70,6 +73,10 @@ inline void rt_h2d(void *d, const void *h, size_t n, rt_stream_t s) {
 }
 inline void rt_d2h(void *h, const void *d, size_t n, rt_stream_t s) {
   if (n) RT_CHECK(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s));
+}
+/* `rows` pieces of `width` bytes, `dpitch` apart on the device, to pieces `hpitch` apart on the host */
+inline void rt_d2h_2d(void *h, size_t hpitch, const void *d, size_t dpitch, size_t width, size_t rows, rt_stream_t s) {
+  if (rows && width) RT_CHECK(hipMemcpy2DAsync(h, hpitch, d, dpitch, width, rows, hipMemcpyDeviceToHost, s));
 }
 inline void rt_d2d(void *d, const void *s_, size_t n, rt_stream_t s) {
   if (n) RT_CHECK(hipMemcpyAsync(d, s_, n, hipMemcpyDeviceToDevice, s));

@@ -73,6 +73,10 @@ class Tourney:
         w = np.ascontiguousarray(weights, dtype=np.float32)
         _lib.check(self._L, self._L.ca_tourney_set_net(self._t, model_id, kind, _f32(w, "weights"), w.size))
 
+    def set_exact_offsets(self, on=True):
+        """diagnostic: matches read their own rows instead of the reference's offset table (tourney.cpp:55-62)"""
+        _lib.check(self._L, self._L.ca_tourney_set_exact_offsets(self._t, int(bool(on))))
+
     def run(self, max_rounds=0):
         done = C.c_int32()
         _lib.check(self._L, self._L.ca_tourney_run(self._t, max_rounds, C.byref(done)))

@@ -57,6 +57,7 @@ class Trainer:
 
     def close(self):
         if getattr(self, "_t", None) and self._t.value:
+            self.unpin()  # registrations of arrays this object still holds, before the engine goes
             self._L.ca_trainer_destroy(self._t)
             self._t = C.c_void_p()
 
@@ -121,24 +122,41 @@ class Trainer:
         """Page-lock caller arrays (the evals / probs / game_states of the play loop, main.pyx:132-134) for
         direct DMA.  They must outlive the trainer or be passed to unpin() first.  -> all pinned?"""
         ok = True
+        pinned = self.__dict__.setdefault("_pinned", {})
         for a in arrays:
             _f32(a, "array")
             got = C.c_int32()
             _lib.check(self._L, self._L.ca_trainer_pin_host(self._t, C.c_void_p(a.ctypes.data), a.nbytes, C.byref(got)))
+            if got.value:
+                # a registration outlives the caller's own reference only if we keep one: a dropped array's
+                # address could be handed to a new one, which the engine would take for the registered pages
+                pinned[a.ctypes.data] = a
             ok = ok and bool(got.value)
         return ok
 
     def unpin(self, *arrays):
-        for a in arrays:
-            _lib.check(self._L, self._L.ca_trainer_unpin_host(self._t, C.c_void_p(a.ctypes.data)))
+        """unpin the given arrays; with no argument, every array pinned through this object"""
+        pinned = self.__dict__.setdefault("_pinned", {})
+        addrs = [a.ctypes.data for a in arrays] if arrays else list(pinned)
+        for addr in addrs:
+            _lib.check(self._L, self._L.ca_trainer_unpin_host(self._t, C.c_void_p(addr)))
+            pinned.pop(addr, None)
 
     def net_forward(self, states, slot=0, out_evals=None, out_probs=None):
         """evaluate `states` with the network of `slot`; out_evals / out_probs: caller arrays to fill (their
         first len(states) rows) instead of new ones"""
         s = np.ascontiguousarray(states, dtype=np.float32)
+        if s.ndim != 2 or s.shape[1] != GAME_STATE_SIZE:
+            raise ValueError("net_forward: states must be [n][%d]" % GAME_STATE_SIZE)
         n = s.shape[0]
         ev = np.zeros(n, np.float32) if out_evals is None else out_evals
         pr = np.zeros((n, NUM_MOVES), np.float32) if out_probs is None else out_probs
+        if ev.size < n:
+            raise ValueError("net_forward: out_evals holds %d values, %d rows to write" % (ev.size, n))
+        if pr.ndim != 2 or pr.shape[1] != NUM_MOVES or pr.shape[0] < n:
+            raise ValueError("net_forward: out_probs must be [>= %d][%d], got %s" % (n, NUM_MOVES, pr.shape))
+        if n == 0:
+            return ev, pr
         _lib.check(self._L, self._L.ca_trainer_net_forward(self._t, slot, _f32(s, "states"), n, _f32(ev, "ev"),
                                                            _f32(pr, "pr")))
         return ev, pr
@@ -177,6 +195,11 @@ class Trainer:
         sd = np.ascontiguousarray(seeds, dtype=np.int32).reshape(self.num_games)
         p = lambda a: a.ctypes.data_as(_lib.i32p)  # noqa: E731
         _lib.check(self._L, self._L.ca_trainer_set_positions(self._t, p(b), p(tp), p(pc), p(sd)))
+
+    def finish(self):
+        """analysis mode: every position whose search has not ended chooses its move on its tree as it stands
+        (DockerMC::chooseMove after the time limit of choose_move.pyx:110-117)"""
+        _lib.check(self._L, self._L.ca_trainer_finish(self._t))
 
     def analysis(self):
         out = np.zeros((self.num_games, 8), np.int32)

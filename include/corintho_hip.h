@@ -123,6 +123,12 @@ int ca_trainer_set_positions(ca_trainer *t, const int32_t *boards /* [n][64] */,
  * position after the move), drawn (DockerMC::drawn), nodes (num_nodes), evaluation bits (float eval()),
  * legal-move mask of the new position [3] (getLegalMoves)}: what choose_move.pyx:206-221 reads */
 int ca_trainer_analysis(ca_trainer *t, int32_t *out /* [n][8] */);
+/* DockerMC::chooseMove (dockermc.cpp:48-50) on searches that have NOT ended: docker/choose_move.pyx:110-117 leaves
+ * its loop on a time limit as well as on doIteration returning true, and calls chooseMove either way (:199).
+ * Every position that has not finished chooses its move on its tree as it stands (TrainMC::chooseMove,
+ * trainmc.cpp:110-137; evaluations still pending are not received); afterwards ca_trainer_analysis reports all
+ * positions.  Before any iteration, the root is created first (the TrainMC constructor's createRoot). */
+int ca_trainer_finish(ca_trainer *t);
 
 /* ---------------- fused mode (no reference counterpart; opt-in) ----------------
  * The network runs on the device, so the play loop of main.pyx:123-187 never
@@ -226,6 +232,10 @@ int ca_tourney_do_iteration(ca_tourney *t, const float *evaluations, const float
  * ascending order, until every match is done or `max_rounds` rounds have run (0 = no limit). */
 int ca_tourney_set_net(ca_tourney *t, int32_t model_id, int32_t kind, const float *weights, size_t n_floats);
 int ca_tourney_run(ca_tourney *t, int64_t max_rounds, int32_t *all_done);
+/* Diagnostic (not in the reference): 1 = every match reads its evaluations at the rows Tourney::writeRequests
+ * gave it, instead of through Tourney::doIteration's own offset table (tourney.cpp:55-62, SURVEY 8a quirk 10,
+ * which hands most matches the rows of OTHER matches).  Before the first query; default 0 = the reference's table. */
+int ca_tourney_set_exact_offsets(ca_tourney *t, int32_t on);
 /* Tourney::writeScores, tourney.cpp:33-41 */
 int ca_tourney_write_scores(ca_tourney *t, const char *filename);
 int ca_tourney_num_matches(ca_tourney *t, int32_t *out);

@@ -1591,6 +1591,7 @@ struct co_tourney {
   co_mt19937 generator; /* default constructed: seed 5489 (tourney.h:43) */
   int num_threads;
   int trace_on;
+  int exact_offsets; /* co_tourney_set_exact_offsets */
 };
 
 co_tourney *co_tourney_create(int num_threads) {
@@ -1673,6 +1674,14 @@ void co_tourney_do_iteration(co_tourney *t, const float *eval, const float *prob
     if (!t->is_done[i] && match_to_play(t->matches[i]) == id) offset += match_num_requests(t->matches[i - 1]);
     offsets[i] = offset;
   }
+  if (t->exact_offsets) {
+    /* diagnostic: every match reads the rows co_tourney_write_requests gave it */
+    offset = 0;
+    for (int i = 0; i < n; ++i) {
+      offsets[i] = offset;
+      if (!t->is_done[i] && match_to_play(t->matches[i]) == id) offset += match_num_requests(t->matches[i]);
+    }
+  }
 #ifdef _OPENMP
   omp_set_num_threads(t->num_threads);
 #endif
@@ -1685,6 +1694,11 @@ void co_tourney_do_iteration(co_tourney *t, const float *eval, const float *prob
   }
   free(offsets);
 }
+
+/* Not in the reference: 1 = matches read their own rows instead of through the table above.  The reference's
+ * own tournament results (rating/results.txt) are reproduced with this switch on and not with the table of
+ * tourney.cpp:55-62 (tests/test_reference_results.py). */
+void co_tourney_set_exact_offsets(co_tourney *t, int on) { t->exact_offsets = on != 0; }
 
 /* ref: tourney.cpp:33-41: one line "id1 id2 score" per finished match */
 int co_tourney_write_scores(const co_tourney *t, const char *filename) {

@@ -128,6 +128,7 @@ int co_tourney_all_done(const co_tourney *t);
 int co_tourney_num_requests(const co_tourney *t, int id);
 void co_tourney_write_requests(const co_tourney *t, float *game_states, int id);
 void co_tourney_do_iteration(co_tourney *t, const float *eval, const float *probs, int id);
+void co_tourney_set_exact_offsets(co_tourney *t, int on); /* diagnostic, not in the reference */
 int co_tourney_write_scores(const co_tourney *t, const char *filename);
 int co_tourney_num_matches(const co_tourney *t);
 int co_tourney_match_done(const co_tourney *t, int i);

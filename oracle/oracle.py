@@ -114,6 +114,8 @@ def lib():
     L.co_tourney_write_requests.argtypes = [vp, f32p, C.c_int]
     L.co_tourney_do_iteration.argtypes = [vp, f32p, f32p, C.c_int]
     L.co_tourney_do_iteration.restype = None
+    L.co_tourney_set_exact_offsets.argtypes = [vp, C.c_int]
+    L.co_tourney_set_exact_offsets.restype = None
     L.co_tourney_write_scores.argtypes = [vp, C.c_char_p]
     L.co_tourney_write_scores.restype = C.c_int
     L.co_tourney_num_matches.argtypes = [vp]
@@ -404,6 +406,10 @@ class Tourney:
 
     def doIteration(self, evaluations, probabilities, id):
         lib().co_tourney_do_iteration(self._t, _f32(evaluations), _f32(probabilities), id)
+
+    def set_exact_offsets(self, on=True):
+        """diagnostic, not in the reference: matches read their own rows (see corintho_oracle.c)"""
+        lib().co_tourney_set_exact_offsets(self._t, int(bool(on)))
 
     def writeScores(self, filename):
         if lib().co_tourney_write_scores(self._t, str(filename).encode()) != 0:

@@ -128,3 +128,44 @@ def test_fused_analysis_equals_host_driven(engine):
         g = dict(f.results()[i])
         g.pop("evaluation", None)
         assert g == want
+
+
+@pytest.mark.parametrize("engine", ENGINES)
+def test_choose_move_after_a_time_limit(engine):
+    """docker/choose_move.pyx:110-117 leaves its loop on a TIME limit and calls chooseMove on the search as it
+    stands (:199): ca_trainer_finish after k iterations = the oracle's DockerMC::chooseMove after k iterations,
+    the evaluations still pending never received.  Positions whose search ended earlier keep their result."""
+    n, S_, spe = 24, 400, 8
+    boards, tp, pc = _positions(n, seed=11, min_plies=1)
+    seeds = np.arange(n, dtype=np.int32) * 5 + 1
+    for k in (1, 2, 7):
+        a = Analyser(boards, tp, pc, seeds, S_, spe, _cdll=cdll(engine))
+        cap = n * spe
+        evals, probs, gs = np.zeros(cap, np.float32), np.zeros((cap, 96), np.float32), np.zeros((cap, 70), np.float32)
+        for _ in range(k):
+            if a.doIteration(evals, probs):
+                break
+            m = a.num_requests()
+            a.writeRequests(gs)
+            evals[:m], probs[:m] = H.hash_net(gs[:m])
+        a.finish()
+        got = a.results()
+        for i in range(n):
+            mc = O.DockerMC(int(seeds[i]), S_, spe, 1.0, 0.25, boards[i], int(tp[i]), pc[i])
+            if mc.done():
+                assert "pre-result" in got[i]
+                continue
+            e1, p1, g1 = np.zeros(spe, np.float32), np.zeros((spe, 96), np.float32), np.zeros((spe, 70), np.float32)
+            for _ in range(k):
+                if mc.doIteration(e1, p1):
+                    break
+                m = mc.num_requests()
+                if m == 0:
+                    break
+                mc.writeRequests(g1)
+                e1[:m], p1[:m] = H.hash_net(g1[:m])
+            move = mc.chooseMove()
+            assert got[i]["move"] == move, (k, i)
+            assert got[i]["is_done"] == mc.done() and got[i]["nodes_searched"] == mc.num_nodes()
+            assert got[i]["eval_sum"] == mc.eval()
+        a.close()

@@ -62,3 +62,47 @@ def test_two_rank_sharded_generation_matches_single_trainer(tmp_path):
     assert abs(float(got["score"]) - t.score()) < 1e-6
     # the payload all-gather is sized by the largest shard, not by the 44-ply upper bound
     assert int(got["moved"]) < 2 * int(got["rows"]) * 167 * 4 * 1.5
+
+
+def _bench(args, env_extra=None, timeout=900):
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True,
+                          timeout=timeout)
+
+
+TINY = ["--engine", "emu", "--games", "6", "--sims", "24", "--spe", "8", "--steps", "1", "--warmup", "0", "--net", "mlp12x100",
+        "--cpu-games", "0", "--no-variants", "--no-unshared"]
+
+
+def test_bench_gpus_2_launches_two_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher around it (how the driver calls it): two rank processes, one
+    JSON line, n_gpus == 2, both ranks seen, the gathered sample count = the sum of the shards (emulation build
+    over gloo: the rehearsal of the RCCL path on the GPU-less machine)"""
+    import json
+
+    r = _bench(["--gpus", "2"] + TINY)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak"
+    d = out["detail"]
+    assert d["world_size"] == 2 and d["ranks_seen"] == 2 and len(d["per_rank_games_per_s"]) == 2
+    c = d["collectives_per_step"]
+    assert c["samples_gathered"] == c["samples_of_all_shards"] > 0 and c["unfinished_games"] == 0
+    assert abs(out["value"] - 12 / (out["ms_per_step"] * 1e-3)) < 1e-6 * out["value"]
+    # one rank: unchanged single-process path
+    r1 = _bench(["--gpus", "1"] + TINY)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    o1 = json.loads(r1.stdout.strip().splitlines()[-1])
+    assert o1["n_gpus"] == 1 and o1["detail"]["ranks_seen"] == 1 and "collectives_per_step" not in o1["detail"]
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    r = _bench(["--gpus", "4"] + TINY, {"WORLD_SIZE": "2", "RANK": "0"})
+    assert r.returncode != 0 and "does not match WORLD_SIZE" in r.stderr
+    r = _bench(["--gpus", "2"] + TINY, {"WORLD_SIZE": "1", "RANK": "0"})
+    assert r.returncode != 0 and "does not match WORLD_SIZE" in r.stderr

@@ -1,5 +1,5 @@
 """Experiment helper: libcorintho_hip built with -DCO_WINOGRAD (kind 7 = the Winograd variant of rescnn4x6,
-csrc/exp/nn_rescnn_wino.inc) into build_ab/, never the product library."""
+tools/exp/nn_rescnn_wino.inc) into build_ab/, never the product library."""
 import ctypes as C
 import os
 import subprocess

@@ -50,5 +50,24 @@ def main():
               (tag, name, v64.min(), v64.max(), ent, p64.max(axis=1).mean()))
 
 
+def extra_models(ids=(92, 4)):
+    """weights only (the engine's flat layout) of further checkpoints, for the replay of rating/results.txt rows
+    (tests/test_reference_results.py): tests/golden/ref_models.npz, keys model_<id>"""
+    out = {}
+    for i in ids:
+        path = os.path.join(REF, "model_%d.tflite" % i)
+        w = TI.mlp12x100_from_tflite(path)
+        m = TI.read_tflite(path)
+        roles = TI.output_roles(m)
+        states = np.load(os.path.join(OUT, "net_vectors.npz"))["states"][:64]
+        g = TI.tflite_forward_np(m, states, dtype=np.float64)
+        v2, p2 = nets.mlp12x100_forward_f64(w, states)
+        assert np.max(np.abs(v2 - g[roles["value"]][:, 0])) < 2e-6 and np.max(np.abs(p2 - g[roles["policy"]])) < 2e-6
+        out["model_%d" % i] = w
+    np.savez_compressed(os.path.join(OUT, "ref_models.npz"), **out)
+    print("ref_models.npz:", sorted(out))
+
+
 if __name__ == "__main__":
     main()
+    extra_models()
