@@ -91,6 +91,9 @@ def parse():
     ap.add_argument("--pools", type=int, default=0, help="independent game pools on separate streams per GPU (0 = engine default)")
     ap.add_argument("--cpu-games", type=int, default=1024, help="games of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=6.0, help="CPU time budget of each CPU-baseline leg")
+    ap.add_argument("--recycle-games", type=int, default=16384,
+                    help="games of the `recycled` variant: one generation of this many games on --games resident slots "
+                         "(a slot whose game ends takes the next game); 0 = skip")
     ap.add_argument("--engine", default="hip", choices=("hip", "emu"),
                     help="hip = the product (libcorintho_hip.so on an MI355X).  emu = CPU rehearsal of the multi-rank path for "
                          "the tests only: the lane-loop build of the same kernel source (tests/emu) over gloo; never a result")
@@ -314,10 +317,11 @@ def main():
         weights_by_arch["mlp12x100"] = mlp12x100_from_tflite(args.tflite)
     flop_by_arch = {"rescnn4": nets.rescnn4_flop_per_row(), "mlp12x100": MLP_FLOP}
 
-    def make_trainer(pools):
-        return Trainer(G, "", 12345, args.sims, args.spe, args.c_puct, args.epsilon, 0, 1, False, device=local_rank,
-                       stagger=args.stagger, arena_units=args.arena_units, game_base=rank * G, total_games=world * G,
-                       pools=pools, _cdll=cdll)
+    def make_trainer(pools, games=None, resident=-1):
+        n = G if games is None else games
+        return Trainer(n, "", 12345, args.sims, args.spe, args.c_puct, args.epsilon, 0, 1, False, device=local_rank,
+                       stagger=args.stagger, arena_units=args.arena_units, game_base=rank * n, total_games=world * n,
+                       pools=pools, resident=resident, _cdll=cdll)
 
     tr = make_trainer(args.pools)
     gatherer = None
@@ -325,6 +329,13 @@ def main():
         from corintho_ai_amd.dist import SampleGather
 
         gatherer = SampleGather(tr, G, on_device=not emu)
+
+    def batch_fill(totals, slots):
+        """rows per network launch against what a launch can hold (one pool's slots x searches per evaluation)"""
+        pools_ = max(int(totals.get("pools", 1)), 1)
+        cap = slots * args.spe / pools_
+        rows = totals["nn_rows"] / max(totals["nn_launches"], 1)
+        return {"rows_per_launch": rows, "capacity_rows": cap, "fill": rows / cap}
 
     STAT_KEYS = ("searches", "evals", "plies", "iterations", "mcts_ms", "nn_ms", "pack_ms", "nn_rows", "nn_launches",
                  "mcts_launches", "timed_launches", "nn_timed_rows", "mcts_timed_ms", "nn_timed_ms")
@@ -482,6 +493,7 @@ def main():
                 "mcts_GBps_algorithmic": totals["searches"] * BYTES_PER_SIM / max(mcts_s, 1e-12) / 1e9,
                 "network_TFLOPs_algorithmic": totals["nn_rows"] * flop_per_row / max(nn_s, 1e-12) / 1e12,
                 "peak_arena_units_per_tree": totals["peak_arena_units"],
+                "network_batch": batch_fill(totals, G),
                 "world_size": dist.get_world_size() if use_dist else 1,
                 "ranks_seen": ranks_seen,
                 "per_rank_games_per_s": per_rank,
@@ -510,6 +522,20 @@ def main():
                                   "mcts_GBps_algorithmic": t1["searches"] * BYTES_PER_SIM / max(t1["mcts_ms"] * 1e-3, 1e-12) / 1e9,
                                   "device_ms_per_step": {"mcts": t1["mcts_ms"] / vsteps, "network": t1["nn_ms"] / vsteps}}
             out["detail"]["variants"] = variants
+        if world == 1 and args.recycle_games > G:
+            # one generation of `recycle_games` games on G resident slots: a slot whose game ends takes the next game
+            # (ca_config.resident), so the launches stay full until the games run out instead of thinning with the
+            # generation's longest games
+            tr2 = make_trainer(args.pools, games=args.recycle_games, resident=G)
+            rsteps = max(1, min(3, args.steps))
+            d2, t2 = run_generations(tr2, args.net, rsteps, 1, 9000, False)
+            out["detail"]["recycled"] = {
+                "games_per_s": args.recycle_games * rsteps / d2, "games": args.recycle_games, "resident_slots": G,
+                "steps": rsteps, "warmup": 1, "ms_per_step": d2 * 1e3 / rsteps,
+                "network_batch": batch_fill(t2, G), "roofline": roofline_of(args.net, t2, int(t2.get("pools", 1))),
+                "iterations_per_step": t2["iterations"] / rsteps,
+                "note": "same workload per game; %d games per generation on %d slots" % (args.recycle_games, G)}
+            del tr2
         if world == 1 and args.cpu_games > 0:
             out["cpu_baseline"] = cpu_baseline(args, arch, weights_by_arch, out["detail"]["evals_per_game"])
         print(json.dumps(out))

@@ -36,6 +36,7 @@ class CaConfig(C.Structure):
         ("total_games", C.c_int32),
         ("pools", C.c_int32),
         ("analyse", C.c_int32),
+        ("resident", C.c_int32),
     ]
 
 
@@ -58,6 +59,7 @@ class CaStats(C.Structure):
         ("nn_timed_rows", C.c_int64),
         ("mcts_timed_ms", C.c_double),
         ("nn_timed_ms", C.c_double),
+        ("resident_slots", C.c_int64),
     ]
 
 

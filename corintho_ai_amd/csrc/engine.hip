@@ -104,7 +104,10 @@ struct Pool {
 
 struct ca_trainer {
   ca_config cfg;
-  int G = 0, spe = 0;
+  int G = 0, spe = 0; /* games of this trainer */
+  int R = 0;          /* slots of the pool = games resident at a time; R < G: slots are recycled (EngineParams::results) */
+  bool recycle = false;
+  uint32_t cap_units = 0;
   rt_stream_t stream;
   EngineParams P;
   DevBuf<GameCtl> games;
@@ -113,7 +116,9 @@ struct ca_trainer {
   DevBuf<uint32_t> pend_leaf, pend_path, pend_n, noise_raw, rng;
   DevBuf<int32_t> pend_depth, req_offset, trace, all_done;
   DevBuf<float> req, nn_in, nn_in70, nn_eval, nn_probs, samples;
-  DevBuf<unsigned long long> row_counter, pack_counter, prof;
+  DevBuf<unsigned long long> row_counter, pack_counter, prof, next_game;
+  DevBuf<GameCtl> results;   /* [G] finished games by index (recycling pools) */
+  DevBuf<uint32_t> seeds_dev; /* [G] per-game generator seeds (recycling pools) */
   DevBuf<int32_t> ctl;
   int32_t *h_ctl = nullptr; /* pinned: {batch rows, all done, any error, games not done} of the last scan */
   /* buffers of the host-facing calls, kept (and grown on demand) instead of allocated per call */
@@ -223,26 +228,53 @@ struct ca_trainer {
       uint64_t nodes = (uint64_t)cfg.max_searches * 14 + 64;
       cap = (uint32_t)std::min<uint64_t>(nodes * 40, 0x7FFFFFF0ull);
     }
-    size_t T = (size_t)2 * G;
-    games.alloc(G, stream);
+    cap_units = cap;
+    /* Resident slots.  The reference holds every game's trees at once and staggers the starts to bound them
+     * (trainer.cpp:184-186); here `resident` slots hold the games in play and a slot whose game ends takes the
+     * next one (training only: an arena game's trajectory depends on its batch, quirk 12).  0 = automatic: all
+     * games resident if their trees fit in 5/8 of the free device memory, else as many slots as fit. */
+    R = G;
+    const bool can_recycle = !cfg.testing && !cfg.analyse && !tourney;
+    const size_t per_slot = (size_t)2 * ((size_t)cap + CO_ARENA_PAD) * sizeof(uint4) +
+                            (size_t)spe * (CO_PATH_MAX * 4 + CO_NUM_MOVES * 4 + 2 * CO_STATE_STRIDE * 4 + CO_GAME_STATE_SIZE * 4 +
+                                           CO_NUM_MOVES * 4 + 64) + CO_MT_N * 4 + 512;
+    if (can_recycle && cfg.resident > 0 && cfg.resident < G) R = cfg.resident;
+    if (can_recycle && cfg.resident == 0) {
+      const size_t budget = rt_mem_free() / 8 * 5;
+      const size_t per_game = (size_t)CO_MAX_PLIES * CO_SAMPLE_FLOATS * 4 + sizeof(GameCtl) + 8;
+      if ((size_t)G * (per_slot + per_game) > budget) {
+        size_t fit = budget > (size_t)G * per_game ? (budget - (size_t)G * per_game) / per_slot : 0;
+        if (fit < 1) throw EngineError(CA_ERR_DEVICE, "not enough device memory for a single resident game");
+        R = (int)std::min<size_t>(fit, (size_t)G);
+        if (R >= 512) R &= ~255; /* whole workgroups of the network kernels' row tiles */
+      }
+    }
+    recycle = R < G;
+    size_t T = (size_t)2 * R;
+    games.alloc(R, stream);
     trees.alloc(T, stream);
     arena.alloc(T * ((size_t)cap + CO_ARENA_PAD), stream);
-    pend_leaf.alloc((size_t)G * spe, stream);
-    pend_depth.alloc((size_t)G * spe, stream);
-    pend_n.alloc((size_t)G * spe * 4, stream);
-    noise_raw.alloc((size_t)G * spe * CO_NUM_MOVES, stream);
-    pend_path.alloc((size_t)G * spe * CO_PATH_MAX, stream);
-    rng.alloc((size_t)G * CO_MT_N, stream);
-    req.alloc((size_t)G * spe * CO_STATE_STRIDE, stream);
-    req_offset.alloc((size_t)G + 1, stream);
-    nn_in.alloc((size_t)G * spe * CO_STATE_STRIDE, stream);
-    nn_in70.alloc((size_t)G * spe * CO_GAME_STATE_SIZE, stream);
+    pend_leaf.alloc((size_t)R * spe, stream);
+    pend_depth.alloc((size_t)R * spe, stream);
+    pend_n.alloc((size_t)R * spe * 4, stream);
+    noise_raw.alloc((size_t)R * spe * CO_NUM_MOVES, stream);
+    pend_path.alloc((size_t)R * spe * CO_PATH_MAX, stream);
+    rng.alloc((size_t)R * CO_MT_N, stream);
+    req.alloc((size_t)R * spe * CO_STATE_STRIDE, stream);
+    req_offset.alloc((size_t)R + 1, stream);
+    nn_in.alloc((size_t)R * spe * CO_STATE_STRIDE, stream);
+    nn_in70.alloc((size_t)R * spe * CO_GAME_STATE_SIZE, stream);
     ctl.alloc(4, stream);
     rt_host_alloc((void **)&h_ctl, 16);
-    nn_eval.alloc((size_t)G * spe, stream);
-    nn_probs.alloc((size_t)G * spe * CO_NUM_MOVES, stream);
-    if (!cfg.testing) samples.alloc((size_t)G * CO_MAX_PLIES * CO_SAMPLE_FLOATS, stream);
-    if (cfg.trace) trace.alloc((size_t)G * CO_TRACE_CAP, stream);
+    nn_eval.alloc((size_t)R * spe, stream);
+    nn_probs.alloc((size_t)R * spe * CO_NUM_MOVES, stream);
+    if (!cfg.testing) samples.alloc((size_t)G * CO_MAX_PLIES * CO_SAMPLE_FLOATS, stream); /* by game */
+    if (cfg.trace) trace.alloc((size_t)G * CO_TRACE_CAP, stream);                            /* by game */
+    if (recycle) {
+      results.alloc(G, stream);
+      seeds_dev.alloc(G, stream);
+    }
+    next_game.alloc(1, stream);
     all_done.alloc(1, stream);
     row_counter.alloc(1, stream);
     pack_counter.alloc(2 * CO_MAX_POOLS, stream);
@@ -250,7 +282,7 @@ struct ca_trainer {
     if (tourney) {
       pcfg.alloc(host_pcfg.size(), stream);
       rt_h2d(pcfg.p, host_pcfg.data(), host_pcfg.size() * sizeof(PlayerCfg), stream);
-      read_offset.alloc((size_t)G, stream);
+      read_offset.alloc((size_t)R, stream);
     }
 
     /* (an analysis trainer is reset by set_positions, once the positions and their seeds are known) */
@@ -264,19 +296,20 @@ struct ca_trainer {
    * generation in the same pool (ca_trainer_reset). */
   void reset_games(int32_t seed) {
     cfg.seed = seed;
-    size_t T = (size_t)2 * G;
+    size_t T = (size_t)2 * R;
     int total = cfg.total_games > 0 ? cfg.total_games : G;
     std::mt19937 gen((uint32_t)cfg.seed);
     std::vector<uint32_t> seeds(total);
     for (int i = 0; i < total; ++i) seeds[i] = (uint32_t)gen();
-    std::vector<uint32_t> st((size_t)G * CO_MT_N);
-    std::vector<GameCtl> hg(G);
+    std::vector<uint32_t> st((size_t)R * CO_MT_N);
+    std::vector<GameCtl> hg(R);
     std::vector<TreeCtl> ht(T);
-    for (int g = 0; g < G; ++g) {
+    for (int g = 0; g < R; ++g) { /* slot g starts with game g */
       uint32_t *x = &st[(size_t)g * CO_MT_N];
       x[0] = tourney ? match_seeds[g] : (cfg.analyse && !an_seed.empty()) ? an_seed[g] : seeds[cfg.game_base + g];
       for (int i = 1; i < CO_MT_N; ++i) x[i] = 1812433253u * (x[i - 1] ^ (x[i - 1] >> 30)) + (uint32_t)i;
       memset(&hg[g], 0, sizeof(GameCtl));
+      hg[g].gid = g;
       hg[g].parity = (cfg.game_base + g) % 2;
       hg[g].rng_idx = CO_MT_N;
       hg[g].pos_meta = CO_META_START; /* Match::root_ = Node{} (match.h:91): the empty board */
@@ -290,8 +323,8 @@ struct ca_trainer {
     }
     if (cfg.analyse && !an_pos.empty()) {
       /* result rows of the positions that were terminal as given */
-      std::vector<uint32_t> rows((size_t)G * spe * CO_STATE_STRIDE, 0u);
-      for (int g = 0; g < G; ++g)
+      std::vector<uint32_t> rows((size_t)R * spe * CO_STATE_STRIDE, 0u);
+      for (int g = 0; g < R; ++g)
         if (an_pre[g]) {
           uint32_t *o = &rows[(size_t)g * spe * CO_STATE_STRIDE];
           o[0] = 0xFFFFFFFFu;
@@ -310,6 +343,13 @@ struct ca_trainer {
     rt_h2d(rng.p, st.data(), st.size() * 4, stream);
     rt_h2d(games.p, hg.data(), hg.size() * sizeof(GameCtl), stream);
     rt_h2d(trees.p, ht.data(), ht.size() * sizeof(TreeCtl), stream);
+    if (recycle) {
+      /* the games behind the first R: their seeds (the Trainer stream in game order) and the counter they are taken from */
+      rt_h2d(seeds_dev.p, seeds.data() + cfg.game_base, (size_t)G * 4, stream);
+      rt_memset(results.p, 0, (size_t)G * sizeof(GameCtl), stream);
+    }
+    const unsigned long long first_unstarted = (unsigned long long)R;
+    rt_h2d(next_game.p, &first_unstarted, 8, stream);
     rt_memset(row_counter.p, 0, 8, stream);
     rt_memset(pack_counter.p, 0, 16 * CO_MAX_POOLS, stream);
     rt_memset(arena_state.p, 0, 32, stream);
@@ -327,7 +367,11 @@ struct ca_trainer {
   }
 
   void fill_params(uint32_t cap, int total) {
-    P.num_games = G;
+    P.num_games = R;
+    P.total_local = G;
+    P.results = recycle ? results.p : nullptr;
+    P.next_game = next_game.p;
+    P.seeds = recycle ? seeds_dev.p : nullptr;
     P.max_searches = cfg.max_searches;
     P.searches_per_eval = spe;
     P.c_puct = cfg.c_puct;
@@ -335,7 +379,8 @@ struct ca_trainer {
     P.testing = cfg.testing;
     size_t div = (size_t)total / (size_t)cfg.max_searches;
     if (div < 1) div = 1;
-    P.stagger_div = cfg.no_stagger ? 0 : (int32_t)div;
+    /* the staggered start bounds the reference's memory (trainer.cpp:184-186); a recycling pool is bounded by its slots */
+    P.stagger_div = (cfg.no_stagger || recycle) ? 0 : (int32_t)div;
     P.iteration = 0;
     P.to_play = -1;
     P.game_base = cfg.game_base;
@@ -369,11 +414,11 @@ struct ca_trainer {
     P.fused_pack = 0;
     P.defer_handover = 0;
     P.pool_lo = 0;
-    P.pool_n = G;
+    P.pool_n = R;
     P.pool_row_base = 0;
     P.pack_counter = pack_counter.p;
 #ifdef CO_PROF
-    prof.alloc((size_t)G * 16 + 24, stream);
+    prof.alloc((size_t)R * 16 + 24, stream);
     P.prof = prof.p;
 #else
     P.prof = nullptr;
@@ -386,7 +431,7 @@ struct ca_trainer {
     if (scan_valid && scan_valid_for == to_play) return;
     P.to_play = to_play;
     RT_LAUNCH(co_k_scan, 1, CO_WAVE, stream, P);
-    RT_LAUNCH(co_k_compact, G, CO_WAVE, stream, P);
+    RT_LAUNCH(co_k_compact, R, CO_WAVE, stream, P);
     rt_d2h(h_ctl, ctl.p, 16, stream);
     rt_sync(stream);
     last_total = h_ctl[0];
@@ -396,11 +441,29 @@ struct ca_trainer {
     scan_valid = true;
   }
 
+  /* host_games[i] = control block of GAME i of this trainer: the slot itself without recycling; else the filed
+   * result of a finished game, the slot of a game in play, or an untouched block for a game not yet started */
   void fetch_games() {
     if (host_games_valid) return;
     host_games.resize(G);
-    rt_d2h(host_games.data(), games.p, (size_t)G * sizeof(GameCtl), stream);
-    rt_sync(stream);
+    if (!recycle) {
+      rt_d2h(host_games.data(), games.p, (size_t)G * sizeof(GameCtl), stream);
+      rt_sync(stream);
+    } else {
+      std::vector<GameCtl> slots(R);
+      rt_d2h(slots.data(), games.p, (size_t)R * sizeof(GameCtl), stream);
+      rt_d2h(host_games.data(), results.p, (size_t)G * sizeof(GameCtl), stream);
+      rt_sync(stream);
+      for (int i = 0; i < G; ++i)
+        if (!host_games[i].done) {
+          memset(&host_games[i], 0, sizeof(GameCtl));
+          host_games[i].gid = i;
+        }
+      for (int sl = 0; sl < R; ++sl) {
+        const int i = slots[sl].gid;
+        if (i >= 0 && i < G && !host_games[i].done) host_games[i] = slots[sl];
+      }
+    }
     host_games_valid = true;
   }
 
@@ -436,12 +499,12 @@ struct ca_trainer {
         rt_h2d(nn_probs.p, probs, (size_t)last_total * CO_NUM_MOVES * 4, stream);
       }
     } else {
-      rt_memset(req_offset.p, 0, ((size_t)G + 1) * 4, stream);
+      rt_memset(req_offset.p, 0, ((size_t)R + 1) * 4, stream);
     }
     P.to_play = to_play;
     P.iteration = trainer_iteration;
-    RT_LAUNCH(co_k_priors, ((G) * P.searches_per_eval + CO_WAVES_PER_BLOCK - 1) / CO_WAVES_PER_BLOCK, CO_WAVE * CO_WAVES_PER_BLOCK, stream, P);
-    RT_LAUNCH(co_k_mcts_step, G, CO_WAVE, stream, P);
+    RT_LAUNCH(co_k_priors, ((R) * P.searches_per_eval + CO_WAVES_PER_BLOCK - 1) / CO_WAVES_PER_BLOCK, CO_WAVE * CO_WAVES_PER_BLOCK, stream, P);
+    RT_LAUNCH(co_k_mcts_step, R, CO_WAVE, stream, P);
     if (to_play == -1) ++trainer_iteration;
     ++iterations;
     ++mcts_launches;
@@ -481,7 +544,7 @@ struct ca_trainer {
   /* Tourney::doIteration (tourney.cpp:53-70).  `rows` = rows of the caller's two arrays: the
    * reference reads them at its own offset table (quirk 10), so the whole arrays travel. */
   void tourney_do_iteration(const float *evals, const float *probs, int32_t rows, int id) {
-    size_t cap = (size_t)G * spe;
+    size_t cap = (size_t)R * spe;
     if (rows < 0 || (size_t)rows > cap) rows = (int32_t)cap;
     P.to_play = id;
     RT_LAUNCH(co_k_scan, 1, CO_WAVE, stream, P); /* offsets at entry */
@@ -490,8 +553,8 @@ struct ca_trainer {
       rt_h2d(nn_probs.p, probs, (size_t)rows * CO_NUM_MOVES * 4, stream);
     }
     P.iteration = trainer_iteration;
-    RT_LAUNCH(co_k_priors, ((G) * P.searches_per_eval + CO_WAVES_PER_BLOCK - 1) / CO_WAVES_PER_BLOCK, CO_WAVE * CO_WAVES_PER_BLOCK, stream, P);
-    RT_LAUNCH(co_k_mcts_step, G, CO_WAVE, stream, P);
+    RT_LAUNCH(co_k_priors, ((R) * P.searches_per_eval + CO_WAVES_PER_BLOCK - 1) / CO_WAVES_PER_BLOCK, CO_WAVE * CO_WAVES_PER_BLOCK, stream, P);
+    RT_LAUNCH(co_k_mcts_step, R, CO_WAVE, stream, P);
     ++iterations;
     ++mcts_launches;
     scan_valid = false;
@@ -539,6 +602,15 @@ struct ca_trainer {
     return (float)total / (float)(size_t)G;
   }
 
+  /* ws_off = {sample offsets [G + 1], per game (plies | result << 8) [G]}: the sample kernels work by game, not by slot */
+  void upload_sample_index(const std::vector<int32_t> &off) {
+    std::vector<int32_t> idx(off);
+    idx.resize((size_t)2 * G + 1);
+    for (int g = 0; g < G; ++g) idx[(size_t)G + 1 + g] = host_games[g].n_samples | (host_games[g].result << 8);
+    rt_h2d(ws_off.p, idx.data(), idx.size() * 4, stream);
+    rt_sync(stream); /* idx is a local */
+  }
+
   void write_samples(float *gs, float *ev, float *pr) {
     if (cfg.testing) throw EngineError(CA_ERR_STATE, "writeSamples in testing mode");
     fetch_games();
@@ -546,12 +618,13 @@ struct ca_trainer {
     for (int g = 0; g < G; ++g) off[g + 1] = off[g] + host_games[g].n_samples;
     size_t n = (size_t)off[G];
     if (n == 0) return;
-    ensure(ws_off, (size_t)G + 1);
+    ensure(ws_off, (size_t)2 * G + 1);
     ensure(ws_gs, n * 8 * CO_GAME_STATE_SIZE);
     ensure(ws_ev, n * 8);
     ensure(ws_pr, n * 8 * CO_NUM_MOVES);
-    rt_h2d(ws_off.p, off.data(), off.size() * 4, stream);
-    RT_LAUNCH(co_k_write_samples, G, CO_WAVE, stream, P, (const int32_t *)ws_off.p, ws_gs.p, ws_ev.p, ws_pr.p);
+    upload_sample_index(off);
+    RT_LAUNCH(co_k_write_samples, G, CO_WAVE, stream, P, G, (const int32_t *)ws_off.p, (const int32_t *)ws_off.p + G + 1, ws_gs.p,
+              ws_ev.p, ws_pr.p);
     rt_d2h(gs, ws_gs.p, n * 8 * CO_GAME_STATE_SIZE * 4, stream);
     rt_d2h(ev, ws_ev.p, n * 8 * 4, stream);
     rt_d2h(pr, ws_pr.p, n * 8 * CO_NUM_MOVES * 4, stream);
@@ -586,9 +659,10 @@ struct ca_trainer {
     for (int g = 0; g < G; ++g) off[g + 1] = off[g] + host_games[g].n_samples;
     if (off[G] > cap_rows) throw EngineError(CA_ERR_ARG, "pack_samples: destination too small");
     if (off[G] == 0) return 0;
-    ensure(ws_off, (size_t)G + 1);
-    rt_h2d(ws_off.p, off.data(), off.size() * 4, stream);
-    RT_LAUNCH(co_k_pack_samples, G, CO_WAVE, stream, P, (const int32_t *)ws_off.p, d_state_policy, d_outcome);
+    ensure(ws_off, (size_t)2 * G + 1);
+    upload_sample_index(off);
+    RT_LAUNCH(co_k_pack_samples, G, CO_WAVE, stream, P, G, (const int32_t *)ws_off.p, (const int32_t *)ws_off.p + G + 1,
+              d_state_policy, d_outcome);
     rt_sync(stream);
     return off[G];
   }
@@ -700,7 +774,7 @@ struct ca_trainer {
     P.to_play = -1;
     P.iteration = trainer_iteration;
     P.force_choose = 1;
-    RT_LAUNCH(co_k_mcts_step, G, CO_WAVE, stream, P);
+    RT_LAUNCH(co_k_mcts_step, R, CO_WAVE, stream, P);
     P.force_choose = 0;
     ++mcts_launches;
     scan_valid = false;
@@ -712,7 +786,7 @@ struct ca_trainer {
   /* ------------------------------------------------------------ fused mode */
   void set_net(int slot, int kind, const float *weights, size_t n) {
     if (slot < 0 || slot > 1) throw EngineError(CA_ERR_ARG, "net slot must be 0 or 1");
-    nets[slot].reset(co_net_create(kind, weights, n, (size_t)G * spe, stream));
+    nets[slot].reset(co_net_create(kind, weights, n, (size_t)R * spe, stream));
     if (!nets[slot]) throw EngineError(CA_ERR_ARG, "unknown net kind or bad weight count");
   }
 
@@ -755,8 +829,8 @@ struct ca_trainer {
       for (int p = 0; p < npools; ++p) {
         Pool &q = pools[p];
         rt_stream_create(&q.st);
-        q.lo = (int)((int64_t)G * p / npools);
-        q.n = (int)((int64_t)G * (p + 1) / npools) - q.lo;
+        q.lo = (int)((int64_t)R * p / npools);
+        q.n = (int)((int64_t)R * (p + 1) / npools) - q.lo;
         q.row_base = q.lo * spe;
         for (int w = 0; w < 2; ++w) {
           for (auto &e : q.ev[w]) rt_event_create(&e);
@@ -877,7 +951,7 @@ struct ca_trainer {
     P.fused_pack = 0;
     P.defer_handover = 0;
     P.pool_lo = 0;
-    P.pool_n = G;
+    P.pool_n = R;
     P.pool_row_base = 0;
     P.pack_counter = pack_counter.p;
     host_games_valid = false;
@@ -901,9 +975,9 @@ struct ca_trainer {
     if (!nets[0]) throw EngineError(CA_ERR_STATE, "ca_trainer_run: no network set (ca_trainer_set_net)");
     if (cfg.testing && !cfg.analyse && !nets[1]) throw EngineError(CA_ERR_STATE, "arena mode needs both networks");
     if (!cfg.testing || cfg.analyse) { /* one network, every slot active: self-play training, or N position searches */
-      int npools = cfg.pools > 0 ? cfg.pools : (G >= 2048 ? 2 : 1);
+      int npools = cfg.pools > 0 ? cfg.pools : (R >= 2048 ? 2 : 1);
       if (npools > CO_MAX_POOLS) npools = CO_MAX_POOLS;
-      if (npools > G) npools = G;
+      if (npools > R) npools = R;
       return run_pools(max_iterations, npools);
     }
     /* arena (main.pyx:142-168 with is_testing): one model is served per iteration and hands over
@@ -928,15 +1002,15 @@ struct ca_trainer {
       P.scan_phase = 0;
       RT_LAUNCH(co_k_scan, 1, CO_WAVE, stream, P); /* offsets at entry (trainer.cpp:208-215) */
       if (timed) rt_event_record(ev[0], stream);
-      RT_LAUNCH(co_k_priors, ((G) * P.searches_per_eval + CO_WAVES_PER_BLOCK - 1) / CO_WAVES_PER_BLOCK, CO_WAVE * CO_WAVES_PER_BLOCK, stream, P);
-      RT_LAUNCH(co_k_mcts_step, G, CO_WAVE, stream, P);
+      RT_LAUNCH(co_k_priors, ((R) * P.searches_per_eval + CO_WAVES_PER_BLOCK - 1) / CO_WAVES_PER_BLOCK, CO_WAVE * CO_WAVES_PER_BLOCK, stream, P);
+      RT_LAUNCH(co_k_mcts_step, R, CO_WAVE, stream, P);
       if (timed) rt_event_record(ev[1], stream);
       P.scan_phase = 1;
       RT_LAUNCH(co_k_scan, 1, CO_WAVE, stream, P);
-      RT_LAUNCH(co_k_compact, G, CO_WAVE, stream, P);
+      RT_LAUNCH(co_k_compact, R, CO_WAVE, stream, P);
       if (timed) rt_event_record(ev[2], stream);
       for (int slot = 0; slot < 2; ++slot) /* get_predictions, main.pyx:74-81 */
-        nets[slot]->forward(nn_in.p, G * spe, arena_state.p + 3 + slot, nn_eval.p, nn_probs.p, stream);
+        nets[slot]->forward(nn_in.p, R * spe, arena_state.p + 3 + slot, nn_eval.p, nn_probs.p, stream);
       if (timed) rt_event_record(ev[3], stream);
       ++iterations;
       ++it;
@@ -1314,13 +1388,13 @@ extern "C" int ca_trainer_prof(ca_trainer *t, unsigned long long out[36]) {
   CA_TGUARD({
     for (int i = 0; i < 36; ++i) out[i] = 0;
     if (!t->prof.p) throw EngineError(CA_ERR_STATE, "not a -DCO_PROF build");
-    std::vector<unsigned long long> h((size_t)t->G * 16);
+    std::vector<unsigned long long> h((size_t)t->R * 16);
     rt_d2h(h.data(), t->prof.p, h.size() * 8, t->stream);
     rt_sync(t->stream);
-    for (int g = 0; g < t->G; ++g)
+    for (int g = 0; g < t->R; ++g)
       for (int i = 0; i < 16; ++i) out[i] += h[(size_t)g * 16 + i];
     unsigned long long clk[20];
-    rt_d2h(clk, t->prof.p + (size_t)t->G * 16, sizeof clk, t->stream);
+    rt_d2h(clk, t->prof.p + (size_t)t->R * 16, sizeof clk, t->stream);
     rt_sync(t->stream);
     for (int i = 0; i < 20; ++i) out[16 + i] = clk[i];
   })
@@ -1388,7 +1462,7 @@ extern "C" int ca_trainer_stats(ca_trainer *t, ca_stats *out) {
       out->nodes += t->host_games[g].nodes;
       out->plies += t->host_games[g].plies;
     }
-    std::vector<TreeCtl> ht((size_t)2 * t->G);
+    std::vector<TreeCtl> ht((size_t)2 * t->R);
     rt_d2h(ht.data(), t->trees.p, ht.size() * sizeof(TreeCtl), t->stream);
     rt_sync(t->stream);
     for (auto &x : ht) out->peak_arena_units = std::max<int64_t>(out->peak_arena_units, x.peak_units);
@@ -1400,6 +1474,7 @@ extern "C" int ca_trainer_stats(ca_trainer *t, ca_stats *out) {
     out->nn_launches = t->nn_launches;
     out->nn_rows = t->nn_rows;
     out->pools = t->pools.empty() ? 1 : (int64_t)t->pools.size();
+    out->resident_slots = t->R;
     out->timed_launches = t->timed_launches;
     out->nn_timed_rows = t->nn_timed_rows;
     out->mcts_timed_ms = t->mcts_timed_ms;

@@ -79,7 +79,10 @@ struct GameCtl {
   int32_t row_off;    /* fused mode: first row of this game's requests in the compact batch */
   int32_t resume;     /* fused mode: the new mover's first searches of a turn were deferred to the next step */
   /* tournament matches only: Match::root_, the position on the board (match.h:91) */
-  uint32_t pos_lo, pos_hi, pos_meta, pos_pad;
+  uint32_t pos_lo, pos_hi, pos_meta;
+  /* the game this slot plays (index within this trainer's games; = the slot index unless the pool recycles
+   * slots, see EngineParams::results) */
+  int32_t gid;
 };
 
 /* one side of a tournament match: Player, match.h:13-31 */
@@ -98,7 +101,7 @@ struct TreeCtl {
 
 struct EngineParams {
   /* configuration */
-  int32_t num_games;
+  int32_t num_games;   /* SLOTS of the pool: games resident at a time (= the trainer's games unless it recycles) */
   int32_t max_searches;
   int32_t searches_per_eval;
   float c_puct;
@@ -164,5 +167,15 @@ struct EngineParams {
    * pool_n) and its batch rows start at row pool_row_base of nn_in / nn_eval / nn_probs */
   int32_t pool_lo, pool_n, pool_row_base;
   unsigned long long *pack_counter; /* [2] */
+  /* Resident-slot pool (ca_config.resident < num_games, training only): the trainer's `total_local` games are
+   * played on num_games slots.  A slot whose game ends stores the game's control block in results[gid], takes
+   * the next unstarted game from next_game[0] and seeds its generator from seeds[gid] (the Trainer stream in
+   * game order, trainer.cpp:243-255) -- a game's own sequence of operations does not depend on the slot or
+   * the moment it starts (every game owns its generator).  Samples and traces are always addressed by gid.
+   * results == null: no recycling (slot = game). */
+  GameCtl *results;               /* [total_local] */
+  unsigned long long *next_game;  /* [1] */
+  const uint32_t *seeds;          /* [total_local] */
+  int32_t total_local;
   unsigned long long *prof;         /* [G][8] cycle stamps, profiling builds (-DCO_PROF) only */
 };

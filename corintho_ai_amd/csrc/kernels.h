@@ -169,18 +169,17 @@ CO_KERNEL co_k_expand_rows(const float *in70, float *out80, int rows, int nblock
   }
 }
 
-/* one wavefront per game; sample_offset[g] = number of plies of games < g */
-CO_KERNEL co_k_write_samples(EngineParams P, const int32_t *sample_offset, float *game_states, float *eval_samples,
-                             float *prob_samples) {
+/* one wavefront per GAME (not slot); sample_offset[g] = number of plies of games < g, meta[g] = plies | result << 8 */
+CO_KERNEL co_k_write_samples(EngineParams P, int n_games, const int32_t *sample_offset, const int32_t *meta, float *game_states,
+                             float *eval_samples, float *prob_samples) {
   int g = CO_BLOCK_IDX;
-  if (g >= P.num_games) return;
-  GameCtl gc = P.games[g];
-  int n = gc.n_samples;
+  if (g >= n_games) return;
+  const int n = meta[g] & 255, result = meta[g] >> 8;
   size_t off = (size_t)sample_offset[g];
   const float *smp = P.samples + (size_t)g * CO_MAX_PLIES * CO_SAMPLE_FLOATS;
   for (int i = n - 1; i >= 0; --i) {
     /* the last mover wins unless the game is drawn; sign alternates backwards */
-    float evaluation = gc.result == CO_RESULT_DRAW ? 0.0f : 1.0f;
+    float evaluation = result == CO_RESULT_DRAW ? 0.0f : 1.0f;
     if ((n - 1 - i) & 1) evaluation = (float)((double)evaluation * -1.0);
     const float *st = smp + (size_t)i * CO_SAMPLE_FLOATS;
     const float *pol = st + CO_GAME_STATE_SIZE;
@@ -200,18 +199,18 @@ CO_KERNEL co_k_write_samples(EngineParams P, const int32_t *sample_offset, float
 
 /* un-augmented (state[70], policy[96]) rows + outcome, game-major, for the
  * multi-GPU gather (the x8 expansion happens after it) */
-CO_KERNEL co_k_pack_samples(EngineParams P, const int32_t *sample_offset, float *state_policy, float *outcome) {
+CO_KERNEL co_k_pack_samples(EngineParams P, int n_games, const int32_t *sample_offset, const int32_t *meta, float *state_policy,
+                            float *outcome) {
   int g = CO_BLOCK_IDX;
-  if (g >= P.num_games) return;
-  GameCtl gc = P.games[g];
-  int n = gc.n_samples;
+  if (g >= n_games) return;
+  const int n = meta[g] & 255, result = meta[g] >> 8;
   size_t off = (size_t)sample_offset[g];
   const float *smp = P.samples + (size_t)g * CO_MAX_PLIES * CO_SAMPLE_FLOATS;
   int total = n * CO_SAMPLE_FLOATS;
   FOR_LANES {
     for (int i = lane; i < total; i += CO_WAVE) state_policy[off * CO_SAMPLE_FLOATS + i] = smp[i];
     for (int i = lane; i < n; i += CO_WAVE) {
-      float e = gc.result == CO_RESULT_DRAW ? 0.0f : 1.0f;
+      float e = result == CO_RESULT_DRAW ? 0.0f : 1.0f;
       if ((n - 1 - i) & 1) e = (float)((double)e * -1.0);
       outcome[off + i] = e;
     }

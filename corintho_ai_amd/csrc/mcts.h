@@ -1263,8 +1263,9 @@ CO_DEV void co_mcts_step_wave(const EngineParams &P, int g) {
   w.noise_raw = P.noise_raw + (size_t)g * P.searches_per_eval * CO_NUM_MOVES;
   w.noise_words = 0; /* a step consumes every pending leaf before it queues new ones */
   w.req = P.req + (size_t)g * P.searches_per_eval * CO_STATE_STRIDE;
-  w.samples = P.samples ? P.samples + (size_t)g * CO_MAX_PLIES * CO_SAMPLE_FLOATS : (float *)0;
-  w.trace = P.trace ? P.trace + (size_t)g * CO_TRACE_CAP : (int32_t *)0;
+  /* samples and traces belong to the GAME, not to the slot */
+  w.samples = P.samples ? P.samples + (size_t)gc.gid * CO_MAX_PLIES * CO_SAMPLE_FLOATS : (float *)0;
+  w.trace = P.trace ? P.trace + (size_t)gc.gid * CO_TRACE_CAP : (int32_t *)0;
   w.prof = P.prof ? P.prof + (size_t)g * 16 : (unsigned long long *)0;
   w.max_searches = P.max_searches;
   w.spe = P.searches_per_eval;
@@ -1283,8 +1284,47 @@ CO_DEV void co_mcts_step_wave(const EngineParams &P, int g) {
   unsigned long long t_real0 = __builtin_amdgcn_s_memrealtime();
 #endif
   int off = co_step_row(P, g, gc);
-  int done = co_game_step(w, P.nn_eval + off, P.nn_probs + (size_t)off * CO_NUM_MOVES);
-  if (done) w.gc.done = 1;
+  const float *step_eval = P.nn_eval + off, *step_probs = P.nn_probs + (size_t)off * CO_NUM_MOVES;
+  int done;
+  for (;;) { /* one pass, unless the slot's game ends and the pool hands it the next one */
+    done = co_game_step(w, step_eval, step_probs);
+    if (!done) break;
+    w.gc.done = 1;
+    if (!P.results) break;
+    /* resident-slot pool: file the finished game under its index, take the next unstarted one */
+    {
+      GameCtl *dst = P.results + w.gc.gid;
+      FOR_LANES {
+        if (lane == 0) *dst = w.gc;
+      }
+      WAVE_SYNC();
+    }
+    const unsigned long long next = co_atomic_add_u64(P.next_game, 1ull);
+    if (next >= (unsigned long long)P.total_local) break; /* none left: the slot is done */
+    /* Trainer::initialize for game `next` (trainer.cpp:243-255) in this slot: a fresh SelfPlayer -- own
+     * generator seeded from the Trainer stream by game index, two empty trees (the arena of the finished game
+     * is given back whole: the bump pointers return to zero), colour parity by global index */
+    const int gid = (int)next;
+    if (w.gc.to_play != 0) { /* w.me is the tree of the player to move: player 0 starts */
+      CoTree tmp = w.me;
+      w.me = w.opp;
+      w.opp = tmp;
+    }
+    GameCtl fresh;
+    fresh.to_play = 0; fresh.done = 0; fresh.result = 0; fresh.mate_turn = 0; fresh.n_samples = 0;
+    fresh.parity = (P.game_base + gid) % 2; fresh.error = 0; fresh.n_pending = 0; fresh.rng_idx = CO_MT_N;
+    fresh.plies = 0; fresh.searches = 0u; fresh.evals = 0u; fresh.nodes = 0u; fresh.trace_len = 0;
+    fresh.row_off = 0; fresh.resume = 0; fresh.pos_lo = 0u; fresh.pos_hi = 0u; fresh.pos_meta = CO_META_START;
+    fresh.gid = gid;
+    w.gc = fresh;
+    w.me.tc.root = CO_NONE; w.me.tc.searches_done = 0; w.me.tc.units_used = 0u;   /* peak_units: high-water of the slot */
+    w.opp.tc.root = CO_NONE; w.opp.tc.searches_done = 0; w.opp.tc.units_used = 0u;
+    w.noise_words = 0;
+    w.samples = P.samples ? P.samples + (size_t)gid * CO_MAX_PLIES * CO_SAMPLE_FLOATS : (float *)0;
+    w.trace = P.trace ? P.trace + (size_t)gid * CO_TRACE_CAP : (int32_t *)0;
+    co_mt_seed(w.mt, P.seeds[gid]);
+    step_eval = step_probs = (const float *)0; /* the first step of a game creates the root and asks for its evaluation */
+  }
   /* Trainer::writeRequests fused into the step: reserve rows of the compact batch (any order: a row's
    * evaluation does not depend on its position).  The atomic's round trip runs under the noise capture. */
   const int packs = P.fused_pack && !w.gc.done && !w.gc.error;

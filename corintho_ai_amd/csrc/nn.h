@@ -22,6 +22,9 @@
  * float32 value), six MFMA products -- everything down to 2^-24 of a product is kept (nn_rescnn.hip) */
 #define CO_NET_RESCNN4_X6 5
 #define CO_NET_MLP12X100_X6 6
+/* two fp16 terms per operand (22 significand bits), three MFMA products: float32-class arithmetic at the cost of bf16x3 */
+#define CO_NET_RESCNN4_H3 8
+#define CO_NET_MLP12X100_H3 9
 /* experiment (-DCO_WINOGRAD builds only): rescnn4 at the same split precision, 3x3 convolutions as Winograd F(2x2, 3x3) */
 #define CO_NET_RESCNN4_W6 7
 

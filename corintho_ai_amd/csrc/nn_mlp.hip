@@ -248,8 +248,8 @@ struct MlpNet : CoNet {
 };
 
 CoNet *co_rescnn_create(const float *weights, size_t n_floats, size_t max_rows, rt_stream_t s);
-CoNet *co_rescnn_split_create(const float *weights, size_t n_floats, size_t max_rows, rt_stream_t s, int nterms);
-CoNet *co_mlp_split_create(const float *weights, size_t n_floats, size_t max_rows, rt_stream_t s, int nterms);
+CoNet *co_rescnn_split_create(const float *weights, size_t n_floats, size_t max_rows, rt_stream_t s, int nterms, bool f16 = false);
+CoNet *co_mlp_split_create(const float *weights, size_t n_floats, size_t max_rows, rt_stream_t s, int nterms, bool f16 = false);
 #ifdef CO_WINOGRAD
 CoNet *co_rescnn_wino_create(const float *weights, size_t n_floats, size_t max_rows, rt_stream_t s);
 #endif
@@ -264,5 +264,7 @@ CoNet *co_net_create(int kind, const float *weights, size_t n_floats, size_t max
 #endif
   if (kind == CO_NET_MLP12X100_X3) return co_mlp_split_create(weights, n_floats, max_rows, s, 2);
   if (kind == CO_NET_MLP12X100_X6) return co_mlp_split_create(weights, n_floats, max_rows, s, 3);
+  if (kind == CO_NET_RESCNN4_H3) return co_rescnn_split_create(weights, n_floats, max_rows, s, 2, true);
+  if (kind == CO_NET_MLP12X100_H3) return co_mlp_split_create(weights, n_floats, max_rows, s, 2, true);
   return nullptr;
 }

@@ -51,6 +51,8 @@
 typedef float m3_f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 m3_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 m3_bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 m3_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 m3_f16x2 __attribute__((ext_vector_type(2)));
 typedef float m3_f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t m3_u32x4 __attribute__((ext_vector_type(4)));
 
@@ -77,17 +79,26 @@ __device__ __forceinline__ void m3_stage(const uint32_t *w, uint32_t lds_slot_ad
   }
 }
 
-/* (a, b) -> NT packed bf16 pairs: the values rounded to bf16, then the successive remainders */
-template <int NT>
+/* (a, b) -> NT packed 16-bit pairs: the values rounded to bf16 (F16: fp16), then the successive remainders */
+template <int NT, bool F16 = false>
 __device__ __forceinline__ void m3_split(float a, float b, uint32_t (&t)[NT]) {
   m3_f32x2 v = {a, b};
 #pragma unroll
   for (int i = 0; i < NT; ++i) {
-    m3_bf16x2 hb = __builtin_convertvector(v, m3_bf16x2);
-    t[i] = __builtin_bit_cast(uint32_t, hb);
-    if (i + 1 < NT) {
-      m3_f32x2 hf = __builtin_convertvector(hb, m3_f32x2);
-      v = (m3_f32x2){v.x - hf.x, v.y - hf.y};
+    if constexpr (F16) {
+      m3_f16x2 hb = __builtin_convertvector(v, m3_f16x2);
+      t[i] = __builtin_bit_cast(uint32_t, hb);
+      if (i + 1 < NT) {
+        m3_f32x2 hf = __builtin_convertvector(hb, m3_f32x2);
+        v = (m3_f32x2){v.x - hf.x, v.y - hf.y};
+      }
+    } else {
+      m3_bf16x2 hb = __builtin_convertvector(v, m3_bf16x2);
+      t[i] = __builtin_bit_cast(uint32_t, hb);
+      if (i + 1 < NT) {
+        m3_f32x2 hf = __builtin_convertvector(hb, m3_f32x2);
+        v = (m3_f32x2){v.x - hf.x, v.y - hf.y};
+      }
     }
   }
 }
@@ -95,7 +106,7 @@ __device__ __forceinline__ void m3_split(float a, float b, uint32_t (&t)[NT]) {
 /* K steps S0 .. S0 + NS - 1 of a layer from one chunk: acc += W x.  XT = number of terms the B
  * operand has (1 for the input layer).  Products w_i x_j, i + j <= NT - 1, j < XT, largest
  * first.  Weight fragments of step s + 1 are requested from LDS before the MFMAs of step s issue. */
-template <int NT, int S0, int NS, int XT>
+template <int NT, int S0, int NS, int XT, bool F16 = false>
 __device__ __forceinline__ void m3_steps(m3_f32x16 (&acc)[4], const uint32_t (&b)[NT][8][4], const uint32_t *wl, int lane) {
   m3_u32x4 a[2][NT][4];
 #pragma unroll
@@ -112,13 +123,11 @@ __device__ __forceinline__ void m3_steps(m3_f32x16 (&acc)[4], const uint32_t (&b
         for (int t = 0; t < NT; ++t)
           a[nxt][t][to] = *reinterpret_cast<const m3_u32x4 *>(wl + ((((s + 1) * 4 + to) * NT + t) * 64 + lane) * 4);
     }
-    m3_bf16x8 B[NT];
+    m3_u32x4 B[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      m3_u32x4 v;
 #pragma unroll
-      for (int m = 0; m < 4; ++m) v[m] = b[t][S0 + s][m];
-      B[t] = __builtin_bit_cast(m3_bf16x8, v);
+      for (int m = 0; m < 4; ++m) B[t][m] = b[t][S0 + s][m];
     }
 #pragma unroll
     for (int sum = 0; sum < NT; ++sum)
@@ -126,9 +135,14 @@ __device__ __forceinline__ void m3_steps(m3_f32x16 (&acc)[4], const uint32_t (&b
       for (int i = 0; i <= sum; ++i)
         if (sum - i < XT) {
 #pragma unroll
-          for (int to = 0; to < 4; ++to)
-            acc[to] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(m3_bf16x8, a[cur][i][to]), B[sum - i], acc[to], 0,
-                                                              0, 0);
+          for (int to = 0; to < 4; ++to) {
+            if constexpr (F16)
+              acc[to] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(m3_f16x8, a[cur][i][to]),
+                                                               __builtin_bit_cast(m3_f16x8, B[sum - i]), acc[to], 0, 0, 0);
+            else
+              acc[to] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(m3_bf16x8, a[cur][i][to]),
+                                                                __builtin_bit_cast(m3_bf16x8, B[sum - i]), acc[to], 0, 0, 0);
+          }
         }
   }
 }
@@ -163,7 +177,7 @@ __device__ __forceinline__ void m3_init_bias(m3_f32x16 (&acc)[4], const float *b
       m3_stage<NT>(wfrag, lds_base + (uint32_t)(((c) + 2) % 3) * (M3_CHUNK_WORDS(NT) * 4u), (c) + 2, wave, lane); \
   }
 
-template <int NT>
+template <int NT, bool F16 = false>
 __global__ __launch_bounds__(256, 1) void co_k_mlp_forward_split_t(const float *__restrict__ in, const int32_t *__restrict__ d_rows,
                                                                    const uint32_t *__restrict__ wfrag, float *__restrict__ eval,
                                                                    float *__restrict__ probs) {
@@ -192,13 +206,13 @@ __global__ __launch_bounds__(256, 1) void co_k_mlp_forward_split_t(const float *
       const float4 v0 = *reinterpret_cast<const float4 *>(x + 16 * s + 4 * h);
       const float4 v1 = *reinterpret_cast<const float4 *>(x + 16 * s + 8 + 4 * h);
       uint32_t t[NT];
-      m3_split<NT>(v0.x, v0.y, t);
+      m3_split<NT, F16>(v0.x, v0.y, t);
       b[0][s][0] = t[0];
-      m3_split<NT>(v0.z, v0.w, t);
+      m3_split<NT, F16>(v0.z, v0.w, t);
       b[0][s][1] = t[0];
-      m3_split<NT>(v1.x, v1.y, t);
+      m3_split<NT, F16>(v1.x, v1.y, t);
       b[0][s][2] = t[0];
-      m3_split<NT>(v1.z, v1.w, t);
+      m3_split<NT, F16>(v1.z, v1.w, t);
       b[0][s][3] = t[0];
     }
   }
@@ -213,14 +227,14 @@ __global__ __launch_bounds__(256, 1) void co_k_mlp_forward_split_t(const float *
       M3_CHUNK_HEAD(NT, c0)
       const uint32_t *wl = m3_lds + (c0 % 3) * M3_CHUNK_WORDS(NT);
       m3_init_bias(acc, reinterpret_cast<const float *>(wl + 4 * M3_STEP_WORDS(NT)), h);
-      if (l == 0) m3_steps<NT, 0, 4, 1>(acc, b, wl, lane);
-      else m3_steps<NT, 0, 4, NT>(acc, b, wl, lane);
+      if (l == 0) m3_steps<NT, 0, 4, 1, F16>(acc, b, wl, lane);
+      else m3_steps<NT, 0, 4, NT, F16>(acc, b, wl, lane);
     }
     {
       M3_CHUNK_HEAD(NT, c0 + 1)
       const uint32_t *wl = m3_lds + ((c0 + 1) % 3) * M3_CHUNK_WORDS(NT);
-      if (l == 0) m3_steps<NT, 4, M3_STEPS_L0 - 4, 1>(acc, b, wl, lane);
-      else m3_steps<NT, 4, M3_STEPS - 4, NT>(acc, b, wl, lane);
+      if (l == 0) m3_steps<NT, 4, M3_STEPS_L0 - 4, 1, F16>(acc, b, wl, lane);
+      else m3_steps<NT, 4, M3_STEPS - 4, NT, F16>(acc, b, wl, lane);
     }
     if (l + 1 < M3_NLAYERS) {
       /* ReLU, then the term operands of the next layer: step 2T + a, word m = registers
@@ -235,7 +249,7 @@ __global__ __launch_bounds__(256, 1) void co_k_mlp_forward_split_t(const float *
             v0 = v0 > 0.0f ? v0 : 0.0f;
             v1 = v1 > 0.0f ? v1 : 0.0f;
             uint32_t t[NT];
-            m3_split<NT>(v0, v1, t);
+            m3_split<NT, F16>(v0, v1, t);
 #pragma unroll
             for (int i = 0; i < NT; ++i) b[i][2 * T + a][m] = t[i];
           }
@@ -272,6 +286,8 @@ __global__ __launch_bounds__(256, 1) void co_k_mlp_forward_split_t(const float *
 }
 #define co_k_mlp_forward_x3 co_k_mlp_forward_split_t<2>
 #define co_k_mlp_forward_x6 co_k_mlp_forward_split_t<3>
+/* "f16x3": two fp16 terms per operand (22 significand bits), three MFMA products -- see nn_rescnn.hip */
+#define co_k_mlp_forward_h3 co_k_mlp_forward_split_t<2, true>
 
 /* ------------------------------------------------------------------ host */
 static inline uint16_t m3_bf16_rne(float f) {
@@ -287,11 +303,24 @@ static inline float m3_bf16_to_f(uint16_t b) {
   return f;
 }
 
+static inline uint16_t m3_f16_rne(float f) {
+  _Float16 h = (_Float16)f;
+  uint16_t u;
+  memcpy(&u, &h, 2);
+  return u;
+}
+static inline float m3_f16_to_f(uint16_t u) {
+  _Float16 h;
+  memcpy(&h, &u, 2);
+  return (float)h;
+}
+
 struct MlpSplitNet : CoNet {
   uint32_t *d_w = nullptr;
   size_t cap;
   int nt;
-  MlpSplitNet(const float *w, size_t max_rows, rt_stream_t s, int nterms) : cap(max_rows), nt(nterms) {
+  bool f16;
+  MlpSplitNet(const float *w, size_t max_rows, rt_stream_t s, int nterms, bool fp16 = false) : cap(max_rows), nt(nterms), f16(fp16) {
     /* float64 copies of the 13 dense layers with BatchNorm l folded into layer l + 1 */
     std::vector<std::vector<double>> K(M3_NLAYERS), B(M3_NLAYERS);
     std::vector<int> kin(M3_NLAYERS), kout(M3_NLAYERS);
@@ -354,8 +383,8 @@ struct MlpSplitNet : CoNet {
                 float v = k < kin[l] ? (float)K[l][(size_t)k * 128 + o] : 0.0f;
                 size_t lane = 32 * h + i;
                 for (int t = 0; t < nt; ++t) {
-                  uint16_t term = m3_bf16_rne(v);
-                  v = v - m3_bf16_to_f(term);
+                  uint16_t term = f16 ? m3_f16_rne(v) : m3_bf16_rne(v);
+                  v = v - (f16 ? m3_f16_to_f(term) : m3_bf16_to_f(term));
                   buf[off + (((size_t)to * nt + t) * 64 + lane) * 4 + j / 2] |= (uint32_t)term << (16 * (j & 1));
                 }
               }
@@ -368,20 +397,25 @@ struct MlpSplitNet : CoNet {
     rt_malloc((void **)&d_w, buf.size() * 4, s);
     rt_h2d(d_w, buf.data(), buf.size() * 4, s);
     rt_sync(s);
-    if (nt == 2)
+    if (f16)
+      RT_CHECK(hipFuncSetAttribute((const void *)co_k_mlp_forward_h3, hipFuncAttributeMaxDynamicSharedMemorySize, M3_LDS_BYTES(2)));
+    else if (nt == 2)
       RT_CHECK(hipFuncSetAttribute((const void *)co_k_mlp_forward_x3, hipFuncAttributeMaxDynamicSharedMemorySize, M3_LDS_BYTES(2)));
     else
       RT_CHECK(hipFuncSetAttribute((const void *)co_k_mlp_forward_x6, hipFuncAttributeMaxDynamicSharedMemorySize, M3_LDS_BYTES(3)));
   }
   ~MlpSplitNet() override { rt_free(d_w); }
   size_t max_rows() const override { return cap; }
-  int kind() const override { return nt == 2 ? CO_NET_MLP12X100_X3 : CO_NET_MLP12X100_X6; }
+  int kind() const override { return f16 ? CO_NET_MLP12X100_H3 : nt == 2 ? CO_NET_MLP12X100_X3 : CO_NET_MLP12X100_X6; }
   double flop_per_row() const override { return 2.0 * (70 * 100 + 11 * 100 * 100 + 100 + 100 * 96); }
   void forward(const float *d_in, int32_t rows_cap, const int32_t *d_rows, float *d_eval, float *d_probs,
                rt_stream_t s) override {
     int grid = (rows_cap + M3_ROWS_PER_WG - 1) / M3_ROWS_PER_WG;
     if (grid < 1) return;
-    if (nt == 2)
+    if (f16)
+      hipLaunchKernelGGL(co_k_mlp_forward_h3, dim3(grid), dim3(256), M3_LDS_BYTES(2), s, d_in, d_rows, (const uint32_t *)d_w, d_eval,
+                         d_probs);
+    else if (nt == 2)
       hipLaunchKernelGGL(co_k_mlp_forward_x3, dim3(grid), dim3(256), M3_LDS_BYTES(2), s, d_in, d_rows, (const uint32_t *)d_w, d_eval,
                          d_probs);
     else
@@ -391,7 +425,7 @@ struct MlpSplitNet : CoNet {
   }
 };
 
-CoNet *co_mlp_split_create(const float *weights, size_t n_floats, size_t max_rows, rt_stream_t s, int nterms) {
-  if (n_floats != (size_t)CO_MLP_NUM_WEIGHTS || (nterms != 2 && nterms != 3)) return nullptr;
-  return new MlpSplitNet(weights, max_rows, s, nterms);
+CoNet *co_mlp_split_create(const float *weights, size_t n_floats, size_t max_rows, rt_stream_t s, int nterms, bool f16) {
+  if (n_floats != (size_t)CO_MLP_NUM_WEIGHTS || (nterms != 2 && nterms != 3) || (f16 && nterms != 2)) return nullptr;
+  return new MlpSplitNet(weights, max_rows, s, nterms, f16);
 }

@@ -403,6 +403,8 @@ __global__ __launch_bounds__(256, 2) void co_k_rescnn_forward(RcParams P) {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -433,20 +435,39 @@ __device__ __forceinline__ void rcs_stage(const uint32_t *wtrunk, uint32_t lds_a
   rcs_stage_words(rcs_group_ptr<NT>(wtrunk, gi), lds_addr, gi < 3 ? 3 * RCS_STEM_CHUNK(NT) : 3 * RCS_CONV_CHUNK(NT), wave, lane, nw);
 }
 
-/* (a, b) -> NT packed bf16 pairs: the values rounded to bf16, then the successive remainders (each
- * remainder is exact in float32, so with NT = 3 the three terms add up to the float32 value) */
-template <int NT>
+/* (a, b) -> NT packed 16-bit pairs: the values rounded to bf16 (F16: to fp16), then the successive remainders
+ * (each remainder is exact in float32, so with three bf16 terms they add up to the float32 value; two fp16
+ * terms keep 2 x 11 = 22 significand bits) */
+template <int NT, bool F16 = false>
 __device__ __forceinline__ void rcs_split(float a, float b, uint32_t (&t)[NT]) {
   f32x2 v = {a, b};
 #pragma unroll
   for (int i = 0; i < NT; ++i) {
-    bf16x2 hb = __builtin_convertvector(v, bf16x2);
-    t[i] = __builtin_bit_cast(uint32_t, hb);
-    if (i + 1 < NT) {
-      f32x2 hf = __builtin_convertvector(hb, f32x2);
-      v = (f32x2){v.x - hf.x, v.y - hf.y};
+    if constexpr (F16) {
+      f16x2 hb = __builtin_convertvector(v, f16x2);
+      t[i] = __builtin_bit_cast(uint32_t, hb);
+      if (i + 1 < NT) {
+        f32x2 hf = __builtin_convertvector(hb, f32x2);
+        v = (f32x2){v.x - hf.x, v.y - hf.y};
+      }
+    } else {
+      bf16x2 hb = __builtin_convertvector(v, bf16x2);
+      t[i] = __builtin_bit_cast(uint32_t, hb);
+      if (i + 1 < NT) {
+        f32x2 hf = __builtin_convertvector(hb, f32x2);
+        v = (f32x2){v.x - hf.x, v.y - hf.y};
+      }
     }
   }
+}
+
+/* one v_mfma_f32_32x32x16 on packed 16-bit operands: bf16 terms, or fp16 terms */
+template <bool F16>
+__device__ __forceinline__ f32x16 rcs_mfma(u32x4 a, u32x4 b, f32x16 c) {
+  if constexpr (F16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
 template <int S>
@@ -518,7 +539,7 @@ __device__ __forceinline__ u32x4 rc3_tap4_sel(const uint32_t (&in)[4], int tap, 
  * (also across the tap boundary) are requested from LDS before the MFMAs of step i issue (two
  * register sets), so the LDS latency is paid once per group.  Products w_i x_j, i + j <= NT - 1,
  * largest first. */
-template <int CS, int G, int NP, int NT>
+template <int CS, int G, int NP, int NT, bool F16 = false>
 __device__ __forceinline__ void rcs_conv_group(f32x16 (&acc)[NP][2], const uint32_t (&p)[NT][NP][4][4], const uint32_t *wg,
                                                int lane) {
   /* terms the B operand has: the stem's inputs (board bits 0 / 1, reserves k / 4) are exact in bf16 */
@@ -547,9 +568,9 @@ __device__ __forceinline__ void rcs_conv_group(f32x16 (&acc)[NP][2], const uint3
     }
 #pragma unroll
     for (int np = 0; np < NP; ++np) {
-      bf16x8 B[XT];
+      u32x4 B[XT];
 #pragma unroll
-      for (int t = 0; t < XT; ++t) B[t] = __builtin_bit_cast(bf16x8, rc3_tap4_sel(p[t][np][s], 3 * G + tg, zero));
+      for (int t = 0; t < XT; ++t) B[t] = rc3_tap4_sel(p[t][np][s], 3 * G + tg, zero);
 #pragma unroll
       for (int sum = 0; sum < NT; ++sum)
 #pragma unroll
@@ -557,14 +578,13 @@ __device__ __forceinline__ void rcs_conv_group(f32x16 (&acc)[NP][2], const uint3
           if (sum - i < XT) {
 #pragma unroll
             for (int to = 0; to < 2; ++to)
-              acc[np][to] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[cur][i][to]), B[sum - i],
-                                                                    acc[np][to], 0, 0, 0);
+              acc[np][to] = rcs_mfma<F16>(a[cur][i][to], B[sum - i], acc[np][to]);
           }
     }
   }
 }
 
-template <int CS, int NP, int NT, int NW>
+template <int CS, int NP, int NT, int NW, bool F16 = false>
 __device__ __forceinline__ void rcs_conv3x3(f32x16 (&acc)[NP][2], const uint32_t (&p)[NT][NP][4][4], int &ch,
                                             const Rc3Params &Q, uint32_t *lds_w, uint32_t lds_w_addr, int wave, int lane) {
 #pragma unroll
@@ -581,7 +601,7 @@ __device__ __forceinline__ void rcs_conv3x3(f32x16 (&acc)[NP][2], const uint32_t
       rcs_stage<NT>(Q.wtrunk, lds_w_addr + (uint32_t)((ch + 1) & 1) * (RCS_GROUP_WORDS(NT) * 4u), ch + 1, wave, lane, NW); \
     else if (NT != 2) /* the head weights ride in the buffer the last group leaves idle */                        \
       rcs_stage_words(Q.whead3, lds_w_addr + (uint32_t)((ch + 1) & 1) * (RCS_GROUP_WORDS(NT) * 4u), RCS_HEAD_WORDS(NT), wave, lane, NW); \
-    rcs_conv_group<CS, G, NP, NT>(acc, p, lds_w + (ch & 1) * RCS_GROUP_WORDS(NT), lane);                          \
+    rcs_conv_group<CS, G, NP, NT, F16>(acc, p, lds_w + (ch & 1) * RCS_GROUP_WORDS(NT), lane);                          \
     ++ch;                                                                                                         \
   }
   RC3_GROUP(0) RC3_GROUP(1) RC3_GROUP(2)
@@ -589,7 +609,7 @@ __device__ __forceinline__ void rcs_conv3x3(f32x16 (&acc)[NP][2], const uint32_t
 }
 
 /* fp32 tile values -> the packed operands of the next convolution */
-template <int NP, int NT>
+template <int NP, int NT, bool F16 = false>
 __device__ __forceinline__ void rcs_pack(uint32_t (&p)[NT][NP][4][4], const float (&v)[NP][2][16]) {
 #pragma unroll
   for (int np = 0; np < NP; ++np)
@@ -600,7 +620,7 @@ __device__ __forceinline__ void rcs_pack(uint32_t (&p)[NT][NP][4][4], const floa
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
           uint32_t t[NT];
-          rcs_split<NT>(v[np][T][8 * a + 2 * m], v[np][T][8 * a + 2 * m + 1], t);
+          rcs_split<NT, F16>(v[np][T][8 * a + 2 * m], v[np][T][8 * a + 2 * m + 1], t);
 #pragma unroll
           for (int i = 0; i < NT; ++i) p[i][np][2 * T + a][m] = t[i];
         }
@@ -655,7 +675,7 @@ extern "C" int ca_net_prof(unsigned long long out[8]) {
 #endif
 
 /* NW = waves per workgroup: 8 (two per SIMD), or 4 in the thin-batch kernel of NT = 3 (below) */
-template <int NP, int NT, int NW = 8>
+template <int NP, int NT, int NW = 8, bool F16 = false>
 __device__ __forceinline__ void rcs_forward(const Rc3Params &Q) {
   const RcParams &P = Q.base;
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
@@ -698,7 +718,7 @@ __device__ __forceinline__ void rcs_forward(const Rc3Params &Q) {
     }
   }
   uint32_t pk[NT][NP][4][4];
-  rcs_pack<NP, NT>(pk, x);
+  rcs_pack<NP, NT, F16>(pk, x);
   /* weight stream, requested behind the input loads (vmcnt retires in issue order): group 0, the
    * epilogue constants and, with two terms, the head weights (the wait before the first MFMA
    * covers them) */
@@ -709,22 +729,22 @@ __device__ __forceinline__ void rcs_forward(const Rc3Params &Q) {
   f32x16 acc[NP][2];
   float y[NP][2][16];
   int ch = 0;
-  rcs_conv3x3<1, NP, NT, NW>(acc, pk, ch, Q, lds_w, lds_w_addr, wave, lane);
+  rcs_conv3x3<1, NP, NT, NW, F16>(acc, pk, ch, Q, lds_w, lds_w_addr, wave, lane);
   RC3_STAMP(1)
   const float *lds_epi = reinterpret_cast<const float *>(lds_epi_w);
   rc3_epilogue<false, NP>(x, acc, x, lds_epi, h);
-  rcs_pack<NP, NT>(pk, x);
+  rcs_pack<NP, NT, F16>(pk, x);
   RC3_STAMP(2)
   for (int b = 0; b < 4; ++b) {
-    rcs_conv3x3<4, NP, NT, NW>(acc, pk, ch, Q, lds_w, lds_w_addr, wave, lane);
+    rcs_conv3x3<4, NP, NT, NW, F16>(acc, pk, ch, Q, lds_w, lds_w_addr, wave, lane);
     RC3_STAMP(3)
     rc3_epilogue<false, NP>(y, acc, x, lds_epi + (1 + 2 * b) * 192, h);
-    rcs_pack<NP, NT>(pk, y);
+    rcs_pack<NP, NT, F16>(pk, y);
     RC3_STAMP(2)
-    rcs_conv3x3<4, NP, NT, NW>(acc, pk, ch, Q, lds_w, lds_w_addr, wave, lane);
+    rcs_conv3x3<4, NP, NT, NW, F16>(acc, pk, ch, Q, lds_w, lds_w_addr, wave, lane);
     RC3_STAMP(3)
     rc3_epilogue<true, NP>(x, acc, x, lds_epi + (2 + 2 * b) * 192, h);
-    rcs_pack<NP, NT>(pk, x);
+    rcs_pack<NP, NT, F16>(pk, x);
     RC3_STAMP(2)
   }
   if (NT != 2) {
@@ -747,19 +767,16 @@ __device__ __forceinline__ void rcs_forward(const Rc3Params &Q) {
     for (int i = 0; i < 16; ++i) h1[i] = 0.0f;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      bf16x8 B[NT];
+      u32x4 B[NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        u32x4 bw;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) bw[m] = pk[t][np][s][m];
-        B[t] = __builtin_bit_cast(bf16x8, bw);
+        for (int m = 0; m < 4; ++m) B[t][m] = pk[t][np][s][m];
       }
 #pragma unroll
       for (int sum = 0; sum < NT; ++sum)
 #pragma unroll
-        for (int i = 0; i <= sum; ++i)
-          h1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, hw[i][s]), B[sum - i], h1, 0, 0, 0);
+        for (int i = 0; i <= sum; ++i) h1 = rcs_mfma<F16>(hw[i][s], B[sum - i], h1);
     }
     const float4 b4 = *reinterpret_cast<const float4 *>(P.head_epi + 4 * h);
     const float4 a4 = *reinterpret_cast<const float4 *>(P.head_epi + 16 + 4 * h);
@@ -803,6 +820,13 @@ __device__ __forceinline__ void rcs_forward(const Rc3Params &Q) {
  * NT = 3  <1> only */
 __global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_x3(Rc3Params Q) { rcs_forward<2, 2>(Q); }
 __global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_x3_small(Rc3Params Q) { rcs_forward<1, 2>(Q); }
+/* "f16x3": the two-term kernels with fp16 terms instead of bf16 ones -- x = fp16(x) + fp16(x - fp16(x)) keeps 22
+ * significand bits per operand (bf16x3: 16), the three products w0 x0 + w0 x1 + w1 x0 drop terms of 2^-22 |w x|:
+ * float32-class arithmetic at the MFMA cost of bf16x3.  fp16's exponent range is narrower (normal from 6.1e-5,
+ * subnormal quantum 6e-8): remainders of small values lose relative, not absolute, accuracy -- measured against
+ * float64 in tests/test_net_precision.py. */
+__global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_h3(Rc3Params Q) { rcs_forward<2, 2, 8, true>(Q); }
+__global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_h3_small(Rc3Params Q) { rcs_forward<1, 2, 8, true>(Q); }
 /* (Capping this kernel at 168 registers so that a wave of the search kernel fits beside two of its waves on a SIMD was
  * measured: the network kernel alone 5 % slower, the generation 4 % slower -- the kernel trace shows 81 % of the search
  * kernel's time overlapping the other pool's network launches already, tools/overlap.py.) */
@@ -943,21 +967,35 @@ static inline float rc_bf16_to_f(uint16_t h) {
   memcpy(&f, &u, 4);
   return f;
 }
-/* v -> nt bf16 terms: bf16(v), bf16 of the remainder, ... (the device's rcs_split) */
-static inline void rc_bf16_terms(float v, int nt, uint16_t *t) {
+/* float -> IEEE binary16, round to nearest even, subnormals kept (what v_cvt_f16_f32 gives) */
+static inline uint16_t rc_f16_rne(float f) {
+  _Float16 h = (_Float16)f;
+  uint16_t u;
+  memcpy(&u, &h, 2);
+  return u;
+}
+static inline float rc_f16_to_f(uint16_t u) {
+  _Float16 h;
+  memcpy(&h, &u, 2);
+  return (float)h;
+}
+/* v -> nt 16-bit terms: bf16(v) (f16: fp16(v)), the same of the remainder, ... (the device's rcs_split) */
+static inline void rc_bf16_terms(float v, int nt, uint16_t *t, bool f16 = false) {
   for (int i = 0; i < nt; ++i) {
-    t[i] = rc_bf16_rne(v);
-    v = v - rc_bf16_to_f(t[i]);
+    t[i] = f16 ? rc_f16_rne(v) : rc_bf16_rne(v);
+    v = v - (f16 ? rc_f16_to_f(t[i]) : rc_bf16_to_f(t[i]));
   }
 }
 
 /* the split-precision kernels: NT = 2 (bf16x3) or 3 (bf16x6, float32-equivalent) */
 struct ResCnnSplitNet : ResCnnNet {
   int nt;
+  bool f16;
   uint32_t *d_trunk3 = nullptr;
   uint32_t *d_whead3 = nullptr;
   uint32_t *d_epi3 = nullptr;
-  ResCnnSplitNet(const float *w, size_t max_rows, rt_stream_t s, int nterms) : ResCnnNet(w, max_rows, s), nt(nterms) {
+  ResCnnSplitNet(const float *w, size_t max_rows, rt_stream_t s, int nterms, bool fp16 = false)
+      : ResCnnNet(w, max_rows, s), nt(nterms), f16(fp16) {
     const size_t stem_chunk = (size_t)512 * nt, conv_chunk = (size_t)2048 * nt;
     std::vector<uint32_t> tr(9 * stem_chunk + 72 * conv_chunk, 0u);
     const float *p = w;
@@ -979,7 +1017,7 @@ struct ResCnnSplitNet : ResCnnNet {
                   int ci = 32 * T + 4 * h + 8 * (2 * a + (j >> 2)) + (j & 3);
                   int co = 32 * to + i;
                   float v = ci < cin ? K[((size_t)tap * cin + ci) * 64 + co] : 0.0f;
-                  rc_bf16_terms(v, nt, tv);
+                  rc_bf16_terms(v, nt, tv, f16);
                   size_t lane = 32 * h + i;
                   for (int t = 0; t < nt; ++t) {
                     size_t wd = off + (size_t)tap * chunk + ((((size_t)st * 2 + to) * nt + t) * 64 + lane) * 4 + j / 2;
@@ -1001,7 +1039,7 @@ struct ResCnnSplitNet : ResCnnNet {
             int T = st >> 1, a = st & 1;
             int k = 32 * T + 4 * h + 8 * (2 * a + (j >> 2)) + (j & 3);
             float v = i < 4 ? pk[k * 4 + i] : i < 6 ? vk[k * 2 + (i - 4)] : 0.0f;
-            rc_bf16_terms(v, nt, tv);
+            rc_bf16_terms(v, nt, tv, f16);
             size_t lane = 32 * h + i;
             for (int t = 0; t < nt; ++t)
               wh3[(((size_t)st * nt + t) * 64 + lane) * 4 + j / 2] |= (uint32_t)tv[t] << (16 * (j & 1));
@@ -1020,6 +1058,10 @@ struct ResCnnSplitNet : ResCnnNet {
                                    RCS_LDS_WORDS(2, 2) * 4));
       RT_CHECK(hipFuncSetAttribute((const void *)co_k_rescnn_forward_x3_small, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    RCS_LDS_WORDS(2, 1) * 4));
+      RT_CHECK(hipFuncSetAttribute((const void *)co_k_rescnn_forward_h3, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   RCS_LDS_WORDS(2, 2) * 4));
+      RT_CHECK(hipFuncSetAttribute((const void *)co_k_rescnn_forward_h3_small, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   RCS_LDS_WORDS(2, 1) * 4));
     } else {
       RT_CHECK(hipFuncSetAttribute((const void *)co_k_rescnn_forward_x6, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    RCS_LDS_WORDS(3, 1) * 4));
@@ -1032,7 +1074,7 @@ struct ResCnnSplitNet : ResCnnNet {
     rt_free(d_whead3);
     rt_free(d_epi3);
   }
-  int kind() const override { return nt == 2 ? CO_NET_RESCNN4_X3 : CO_NET_RESCNN4_X6; }
+  int kind() const override { return f16 ? CO_NET_RESCNN4_H3 : nt == 2 ? CO_NET_RESCNN4_X3 : CO_NET_RESCNN4_X6; }
   void forward(const float *d_in, int32_t rows_cap, const int32_t *d_rows, float *d_eval, float *d_probs,
                rt_stream_t s) override {
     if (rows_cap < 1) return;
@@ -1049,9 +1091,11 @@ struct ResCnnSplitNet : ResCnnNet {
       /* both kernels are queued; the row count on the device decides which one works (the other's
        * workgroups return at once).  Batches that can exceed RC3_SMALL_ROWS need the throughput kernel. */
       const int small_rows = rows_cap < RC3_SMALL_ROWS ? rows_cap : RC3_SMALL_ROWS;
-      hipLaunchKernelGGL(co_k_rescnn_forward_x3_small, dim3((small_rows + 15) / 16), dim3(512), RCS_LDS_WORDS(2, 1) * 4, s, q);
+      hipLaunchKernelGGL(f16 ? co_k_rescnn_forward_h3_small : co_k_rescnn_forward_x3_small, dim3((small_rows + 15) / 16), dim3(512),
+                         RCS_LDS_WORDS(2, 1) * 4, s, q);
       if (rows_cap > RC3_SMALL_ROWS)
-        hipLaunchKernelGGL(co_k_rescnn_forward_x3, dim3((rows_cap + 31) / 32), dim3(512), RCS_LDS_WORDS(2, 2) * 4, s, q);
+        hipLaunchKernelGGL(f16 ? co_k_rescnn_forward_h3 : co_k_rescnn_forward_x3, dim3((rows_cap + 31) / 32), dim3(512),
+                           RCS_LDS_WORDS(2, 2) * 4, s, q);
     } else {
       /* enough workgroups for either path: 16 positions each in the throughput path, 8 in the thin one (<= 2048 rows) */
       const int thin_rows = rows_cap < RC6_THIN_ROWS ? rows_cap : RC6_THIN_ROWS;
@@ -1067,9 +1111,9 @@ CoNet *co_rescnn_create(const float *weights, size_t n_floats, size_t max_rows, 
   return new ResCnnNet(weights, max_rows, s);
 }
 
-CoNet *co_rescnn_split_create(const float *weights, size_t n_floats, size_t max_rows, rt_stream_t s, int nterms) {
-  if (n_floats != (size_t)RC_NUM_WEIGHTS || (nterms != 2 && nterms != 3)) return nullptr;
-  return new ResCnnSplitNet(weights, max_rows, s, nterms);
+CoNet *co_rescnn_split_create(const float *weights, size_t n_floats, size_t max_rows, rt_stream_t s, int nterms, bool f16) {
+  if (n_floats != (size_t)RC_NUM_WEIGHTS || (nterms != 2 && nterms != 3) || (f16 && nterms != 2)) return nullptr;
+  return new ResCnnSplitNet(weights, max_rows, s, nterms, f16);
 }
 
 #ifdef CO_WINOGRAD

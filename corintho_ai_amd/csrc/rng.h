@@ -19,6 +19,22 @@ CO_DEV uint32_t co_mt_temper(uint32_t y) {
   return y;
 }
 
+/* std::mt19937(seed): x[0] = seed, x[i] = 1812433253 (x[i-1] ^ (x[i-1] >> 30)) + i -- a serial recurrence, run by
+ * one lane (a slot of the resident pool starting its next game, once per game) */
+CO_DEV void co_mt_seed(uint32_t *mt, uint32_t seed) {
+  FOR_LANES {
+    if (lane == 0) {
+      uint32_t x = seed;
+      mt[0] = x;
+      for (int i = 1; i < CO_MT_N; ++i) {
+        x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)i;
+        mt[i] = x;
+      }
+    }
+  }
+  WAVE_SYNC();
+}
+
 /* mt = this game's 624 state words */
 CO_DEV void co_mt_twist(uint32_t *mt) {
   for (int c = 0; c < (CO_MT_N + CO_WAVE - 1) / CO_WAVE; ++c) {

@@ -21,6 +21,7 @@ inline void rt_malloc(void **p, size_t n, rt_stream_t) {
   if (!*p) throw std::runtime_error("emu: out of memory");
 }
 inline void rt_free(void *p) { free(p); }
+inline size_t rt_mem_free() { return (size_t)1 << 46; } /* host memory: no device budget to respect */
 inline void rt_h2d(void *d, const void *h, size_t n, rt_stream_t) { memcpy(d, h, n); }
 inline void rt_d2h(void *h, const void *d, size_t n, rt_stream_t) { memcpy(h, d, n); }
 inline void rt_d2d(void *d, const void *s, size_t n, rt_stream_t) { memcpy(d, s, n); }
@@ -67,6 +68,11 @@ inline void rt_malloc(void **p, size_t n, hipStream_t s) {
 }
 inline void rt_free(void *p) {
   if (p) (void)hipFree(p);
+}
+inline size_t rt_mem_free() {
+  size_t f = 0, t = 0;
+  RT_CHECK(hipMemGetInfo(&f, &t));
+  return f;
 }
 inline void rt_h2d(void *d, const void *h, size_t n, rt_stream_t s) {
   if (n) RT_CHECK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s));

@@ -29,6 +29,8 @@ NET_RESCNN4_X3 = 3
 NET_MLP12X100_X3 = 4
 NET_RESCNN4_X6 = 5    # float32-equivalent: three bf16 terms per operand, six MFMA products
 NET_MLP12X100_X6 = 6
+NET_RESCNN4_H3 = 8    # two fp16 terms per operand (22 significand bits), three MFMA products
+NET_MLP12X100_H3 = 9
 
 
 def _f32(a, what):
@@ -40,7 +42,7 @@ def _f32(a, what):
 class Trainer:
     def __init__(self, num_games, log_folder="", seed=0, max_searches=1600, searches_per_eval=16, c_puct=1.0,
                  epsilon=0.25, num_logged=0, num_threads=1, testing=False, *, device=0, stagger=True, arena_units=0,
-                 trace=False, game_base=0, total_games=0, pools=0, analyse=False, _cdll=None):
+                 trace=False, game_base=0, total_games=0, pools=0, analyse=False, resident=0, _cdll=None):
         self._L = _cdll if _cdll is not None else _lib.load()
         self._t = C.c_void_p()
         if num_logged:
@@ -49,7 +51,8 @@ class Trainer:
                             max_searches=max_searches, searches_per_eval=searches_per_eval, c_puct=c_puct,
                             epsilon=epsilon, num_logged=0, num_threads=num_threads, testing=int(bool(testing)),
                             device=device, no_stagger=int(not stagger), arena_units=arena_units, trace=int(bool(trace)),
-                            game_base=game_base, total_games=total_games, pools=pools, analyse=int(bool(analyse)))
+                            game_base=game_base, total_games=total_games, pools=pools, analyse=int(bool(analyse)),
+                            resident=int(resident))
         self.num_games = num_games
         self.searches_per_eval = searches_per_eval
         self.testing = bool(testing)

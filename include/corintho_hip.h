@@ -68,6 +68,13 @@ typedef struct ca_config {
   /* analysis mode (DockerMC, dockermc.h:13-51): every "game" is ONE position to search,
    * given by ca_trainer_set_positions; testing is implied; a slot is finished by its first chooseMove */
   int32_t analyse;
+  /* Resident slots (training mode only).  The reference holds the trees of all num_games games and staggers their
+   * starts to bound the memory (trainer.cpp:184-186).  Here `resident` slots hold the games in play; a slot whose
+   * game ends takes the next game (its generator seeded from the Trainer stream by game index, trainer.cpp:243-255,
+   * so no game's result depends on the slot or moment it starts), and the finished game's tree memory is given back
+   * whole.  0 = automatic (all games resident when their trees fit in 5/8 of the free device memory, else as many
+   * slots as fit); >= num_games or < 0 = all resident.  With fewer slots than games the staggered start is off. */
+  int32_t resident;
 } ca_config;
 
 const char *ca_last_error(void);
@@ -145,6 +152,12 @@ int ca_trainer_finish(ca_trainer *t);
  * evaluation = that of the fp32-MFMA kinds 1 and 2 (tests/test_net_precision.py). */
 #define CA_NET_RESCNN4_X6 5
 #define CA_NET_MLP12X100_X6 6
+/* "f16x3": both operands of every matrix product as TWO fp16 terms, x = fp16(x) + fp16(x - fp16(x)) -- 22 significand
+ * bits each -- and the three products w0 x0 + w0 x1 + w1 x0 on the fp16 matrix pipe, fp32 accumulation: the dropped
+ * terms are 2^-22 of a product.  Float32-class results at half the matrix work of bf16x6; error against float64
+ * measured beside the other kinds in tests/test_net_precision.py. */
+#define CA_NET_RESCNN4_H3 8
+#define CA_NET_MLP12X100_H3 9
 /* slot 0 = best model (training, and arena `to_play == 1`), slot 1 = new model (arena
  * `to_play == 0`), as get_predictions chooses them (main.pyx:70-83) */
 int ca_trainer_set_net(ca_trainer *t, int slot, int kind, const float *weights, size_t n_floats);
@@ -190,6 +203,7 @@ typedef struct ca_stats {
   int64_t timed_launches; /* search + network launch pairs that carried events */
   int64_t nn_timed_rows;  /* batch rows of those network launches */
   double mcts_timed_ms, nn_timed_ms;
+  int64_t resident_slots; /* slots of the pool (= num_games unless it recycles, ca_config.resident) */
 } ca_stats;
 int ca_trainer_stats(ca_trainer *t, ca_stats *out);
 /* per-game: {to_play, done, result, n_samples, n_pending, error, mate_turn, plies} */

@@ -74,7 +74,7 @@ def _bench(args, env_extra=None, timeout=900):
 
 
 TINY = ["--engine", "emu", "--games", "6", "--sims", "24", "--spe", "8", "--steps", "1", "--warmup", "0", "--net", "mlp12x100",
-        "--cpu-games", "0", "--no-variants", "--no-unshared"]
+        "--cpu-games", "0", "--no-variants", "--no-unshared", "--recycle-games", "0"]
 
 
 def test_bench_gpus_2_launches_two_ranks_itself():

@@ -552,20 +552,24 @@ def test_fused_arena_matches_oracle(engine):
 
 
 @pytest.mark.gpu
-def test_full_size_generation_properties():
+@pytest.mark.parametrize("kind_name", ["NET_RESCNN4_X6", "NET_RESCNN4_X3"])  # X6 = the bench default (float32-equivalent)
+def test_full_size_generation_properties(kind_name):
     """BASELINE configs[1] at full size (4096 games, 400 sims/move, residual CNN, fused): too big
     for the oracle, so checked through size-independent properties -- every game finished, the
     reference's sample invariants (ranges, probability sums, the 7 symmetry copies being
     permutations, selfplayer_test.cpp:63-142), alternating outcome labels, determinism of a
     re-run, a 256-game shard reproducing its slice, and the first 64 games of the same generation
     replayed on the oracle (fed by the same device network) bit for bit."""
-    from corintho_ai_amd import NET_RESCNN4_X3
+    import corintho_ai_amd as CA
 
+    NET_RESCNN4_X3 = getattr(CA, kind_name)  # (the kind under test)
     G, S_, spe = 4096, 400, 16
     w = nets.init_rescnn4(0)
     t = make_trainer("hip", G, "", 12345, S_, spe, 1.0, 0.25, 0, 1, False, stagger=False)
     t.set_net(NET_RESCNN4_X3, w)
     assert t.run()
+    st = t.stats()
+    assert st["nn_rows"] == st["evals"] > 0  # every evaluation consumed was one row of a network launch
     infos = [t.game_info(g) for g in range(0, G, 97)]
     assert all(i["done"] == 1 and i["error"] == 0 and 0 < i["n_samples"] <= 40 for i in infos)
     gs, ev, pr = H.get_samples(t)
@@ -599,6 +603,15 @@ def test_full_size_generation_properties():
     assert ogs[0::8].tobytes() == sp_all[:m, :70].tobytes()
     assert opr[0::8].tobytes() == sp_all[:m, 70:].tobytes()
     assert oev[0::8].tobytes() == oc_all[:m].tobytes()
+    # the network rows the device evaluated for those 64 games = the oracle's evaluation count (a 64-game shard of the
+    # same generation, whose games are the same games)
+    first = make_trainer("hip", 64, "", 12345, S_, spe, 1.0, 0.25, 0, 1, False, stagger=False, game_base=0, total_games=G)
+    first.set_net(NET_RESCNN4_X3, w)
+    assert first.run()
+    oc_ = o.counters()
+    fs = first.stats()
+    assert fs["nn_rows"] == fs["evals"] == oc_["leaf_evals"] and fs["searches"] == oc_["searches"]
+    assert first.export_samples()[0].tobytes() == sp_all[:m].tobytes()
 
 
 @pytest.mark.parametrize("engine", ENGINES)

@@ -1,0 +1,150 @@
+"""Resident-slot pool (ca_config.resident): a Trainer of G games played on R <= G slots.  The reference keeps the
+trees of all its games and staggers their starts to bound the memory (trainer.cpp:184-186, 243-255); here a slot
+whose game ends takes the next game, seeded from the Trainer stream by game index, and the finished game's tree
+memory is given back.  A game's sequence of operations depends on its own generator and on the network's rows only
+(training mode), so every per-game result -- samples, traces, results, the score -- must equal the run with all
+games resident, bit for bit, and the oracle's."""
+import numpy as np
+import pytest
+
+from corintho_ai_amd import nets
+from oracle import oracle as O
+from tests import harness as H
+from tests.engines import ENGINES, make_trainer
+
+
+def _generation(engine, G, S_, spe, seed, resident, pools=0, trace=True, w=None, kind=1):
+    t = make_trainer(engine, G, "", seed, S_, spe, 1.0, 0.25, 0, 1, False, stagger=False, trace=trace, resident=resident,
+                     pools=pools)
+    t.set_net(kind, w if w is not None else nets.init_mlp12x100(seed=3, bn_noise=True))
+    assert t.run()
+    return t
+
+
+def _digest(t, G):
+    gs, ev, pr = H.get_samples(t)
+    info = [tuple(sorted(t.game_info(g).items())) for g in range(G)]
+    return gs.tobytes(), ev.tobytes(), pr.tobytes(), t.score(), t.avg_mate_length(), t.num_samples(), info
+
+
+@pytest.mark.parametrize("engine", ENGINES)
+def test_recycled_slots_equal_all_games_resident(engine):
+    G, S_, spe, seed = 21, 40, 8, 77
+    full = _generation(engine, G, S_, spe, seed, resident=-1)
+    assert full.stats()["resident_slots"] == G
+    want = _digest(full, G)
+    traces = [full.trace(g) for g in range(G)]
+    for R, pools in ((1, 1), (4, 1), (6, 2), (20, 3)):
+        t = _generation(engine, G, S_, spe, seed, resident=R, pools=pools)
+        st = t.stats()
+        assert st["resident_slots"] == R
+        assert _digest(t, G) == want, (R, pools)
+        for g in range(G):
+            assert np.array_equal(t.trace(g), traces[g]), (R, g)
+        assert st["searches"] == full.stats()["searches"] and st["evals"] == full.stats()["evals"]
+        assert st["nn_rows"] == full.stats()["nn_rows"]
+        # the same pool again with another seed, then the first seed: no state of a generation survives a reset
+        t.reset(seed + 1)
+        assert t.run()
+        assert _digest(t, G) != want
+        t.reset(seed)
+        assert t.run()
+        assert _digest(t, G) == want
+
+
+@pytest.mark.parametrize("engine", ENGINES)
+def test_recycled_pool_matches_oracle_and_the_reference_protocol(engine):
+    """host-driven protocol (doIteration / num_requests / writeRequests) on 5 slots for 17 games: every game equals
+    the oracle's game of the same index (the request ORDER is by slot, a game's rows are its own)"""
+    G, S_, spe, seed = 17, 50, 16, 4242
+    t = make_trainer(engine, G, "", seed, S_, spe, 1.0, 0.25, 0, 1, False, stagger=False, trace=True, resident=5)
+    H.play_generation(t, 5, spe, H.hash_net)
+    o = O.Trainer(G, seed=seed, max_searches=S_, searches_per_eval=spe)
+    o.enable_trace()
+    o.set_stagger(False)
+    H.play_generation(o, G, spe, H.hash_net)
+    for g in range(G):
+        assert np.array_equal(t.trace(g), o.trace(g)), g
+    a, b = H.get_samples(t), H.get_samples(o)
+    assert all(x.tobytes() == y.tobytes() for x, y in zip(a, b))
+    assert t.score() == o.score() and t.avg_mate_length() == o.avg_mate_length()
+    assert t.num_samples() == o.num_samples()
+
+
+@pytest.mark.parametrize("engine", ENGINES)
+def test_sharded_recycled_pool(engine):
+    """a shard (game_base / total_games) on recycled slots: seeds and colours stay on the global index"""
+    S_, spe, seed = 30, 8, 9
+    whole = _generation(engine, 12, S_, spe, seed, resident=-1, trace=False)
+    sp_all, oc_all = whole.export_samples()
+    counts = [whole.game_info(g)["n_samples"] for g in range(12)]
+    t = make_trainer(engine, 7, "", seed, S_, spe, 1.0, 0.25, 0, 1, False, stagger=False, game_base=5, total_games=12, resident=2)
+    t.set_net(1, nets.init_mlp12x100(seed=3, bn_noise=True))
+    assert t.run()
+    sp, oc = t.export_samples()
+    lo = sum(counts[:5])
+    assert sp.tobytes() == sp_all[lo:].tobytes() and oc.tobytes() == oc_all[lo:].tobytes()
+
+
+def test_iteration_cap_leaves_unstarted_games_untouched():
+    t = make_trainer("emu", 9, "", 5, 30, 8, 1.0, 0.25, 0, 1, False, stagger=False, resident=2)
+    t.set_net(1, nets.init_mlp12x100(seed=3, bn_noise=True))
+    assert not t.run(max_iterations=6)
+    infos = [t.game_info(g) for g in range(9)]
+    assert all(i["done"] == 0 for i in infos) and all(i["plies"] == 0 for i in infos[2:])
+    assert t.run()
+    assert all(t.game_info(g)["done"] == 1 for g in range(9))
+
+
+@pytest.mark.gpu
+def test_16384_games_on_4096_slots_equal_the_unrecycled_run():
+    from corintho_ai_amd import NET_MLP12X100_X6
+
+    G, S_, spe, seed = 16384, 400, 16, 12345
+    w = nets.init_mlp12x100(0)
+    a = _generation("hip", G, S_, spe, seed, resident=-1, trace=False, w=w, kind=NET_MLP12X100_X6)
+    b = _generation("hip", G, S_, spe, seed, resident=4096, trace=False, w=w, kind=NET_MLP12X100_X6)
+    assert a.stats()["resident_slots"] == G and b.stats()["resident_slots"] == 4096
+    ga, gb = H.get_samples(a), H.get_samples(b)
+    assert all(x.tobytes() == y.tobytes() for x, y in zip(ga, gb))
+    assert a.score() == b.score() and a.num_samples() == b.num_samples()
+    assert b.stats()["peak_arena_units"] <= a.stats()["peak_arena_units"] * 1.5
+
+
+@pytest.mark.gpu
+def test_reference_production_setting_25000_games_1600_simulations():
+    """corintho_ai/toml/train.toml:2-18: 25 000 games, 1600 simulations per move, 16 per evaluation, c_puct 3.0,
+    epsilon 0.25 -- through the reference's constructor arguments alone (resident = automatic).  The reference
+    bounds its memory by the staggered start; the engine by the slots that fit in 5/8 of the device memory.  Every
+    game finishes, the sample invariants hold, and the first 64 games equal the oracle's bit for bit."""
+    import ctypes as C
+
+    from corintho_ai_amd import NET_MLP12X100_X6
+
+    G, S_, spe, seed = 25000, 1600, 16, 2023
+    t = make_trainer("hip", G, "", seed, S_, spe, 3.0, 0.25, 0, 1, False)  # stagger as the reference's default
+    st0 = t.stats()
+    R = st0["resident_slots"]
+    assert R < G
+    t.set_net(NET_MLP12X100_X6, nets.init_mlp12x100(0))
+    assert t.run()
+    st = t.stats()
+    units = st["peak_arena_units"]
+    print("25000 x 1600: %d resident slots, arena %.1f GB, high water %d units per tree" % (R, R * 2 * 899360 * 16 / 1e9, units))
+    assert R * 2 * (899200 + 160) * 16 < 200e9
+    infos = [t.game_info(g) for g in range(0, G, 37)]
+    assert all(i["done"] == 1 and i["error"] == 0 and 0 < i["n_samples"] <= 40 for i in infos)
+    n = t.num_samples()
+    assert 12 * G < n < 30 * G
+    sp, oc = t.export_samples()
+    counts = [t.game_info(g)["n_samples"] for g in range(64)]
+    m = sum(counts)
+    o = O.Trainer(64, seed=seed, max_searches=S_, searches_per_eval=spe, c_puct=3.0, epsilon=0.25, num_threads=16, game_base=0,
+                  total_games=G)
+    o.set_stagger(False)
+    H.play_generation(o, 64, spe, lambda s: t.net_forward(s))
+    ogs, oev, opr = H.get_samples(o)
+    assert ogs.shape[0] == m * 8
+    assert ogs[0::8].tobytes() == sp[:m, :70].tobytes()
+    assert opr[0::8].tobytes() == sp[:m, 70:].tobytes()
+    assert oev[0::8].tobytes() == oc[:m].tobytes()
