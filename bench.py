@@ -18,14 +18,19 @@ Workload (BASELINE.json configs[1] / SURVEY 8d): 4096 games per GPU, 400
 simulations per move, 16 searches per evaluation, c_puct 1.0, epsilon 0.25,
 random-init weights (seed 0), synthetic = self-generated positions.
 
-Arithmetic.  The reference evaluates its network in float32 (Keras / TFLite, main.pyx:70-83).
-The default network kind is `rescnn4x6`: float32 inputs, weights, accumulation and epilogues;
-every matrix product with both operands written as THREE bf16 terms whose sum is the float32
-value, the six MFMA products above 2^-24 of a product kept (csrc/nn_rescnn.hip).  Its error
-against a float64 evaluation equals that of the plain fp32-MFMA kernel (`rescnn4`), which
-tests/test_net_precision.py asserts on the GPU; both are reported (`detail.variants`), each
-with its own roofline object.  The two-term kinds (`*x3`) are narrower than float32 and are
-reported as variants only.
+Arithmetic.  The reference evaluates its network in float32 (Keras / TFLite, main.pyx:70-83);
+BASELINE.json asks for policy / value outputs within 1e-4 of float32.  Float32 inputs, weights,
+accumulation and epilogues in every kind; what differs is how a matrix product reaches the matrix
+pipe (csrc/nn_rescnn.hip, nn_mlp_split.hip):
+  * `rescnn4h3` (default): both operands as TWO fp16 terms (22 significand bits), three MFMA products;
+    error against float64 within three times the fp32-MFMA kernel's own on every weight set, incl. five
+    of the reference's trained checkpoints (measured 0.5-2.3 x; worst case 4e-5 on out-of-distribution
+    inputs, 7e-6 on positions met in play);
+  * `rescnn4x6`: both operands as THREE bf16 terms whose sum IS the float32 value, six products
+    (float32-equivalent; the default of round 2), at twice the matrix work;
+  * `rescnn4`: fp32 MFMA;  `*x3`: two bf16 terms, 16 bits -- narrower than float32, variants only.
+tests/test_net_precision.py and tests/test_trained_golden.py assert these bounds on the GPU; every
+kind is reported under `detail.variants` with its own roofline object.
 """
 import argparse
 import json
@@ -51,6 +56,8 @@ MLP_FLOP = 2.0 * (70 * 100 + 11 * 100 * 100 + 100 + 100 * 96)
 # name -> (kind constant name, architecture, dtype label, matrix peak, MFMA products issued per algorithmic
 #          product, kernel name as in the rocprof summaries)
 NETS = {
+    "rescnn4h3": ("NET_RESCNN4_H3", "rescnn4", "f32(f16x3)", BF16_MFMA_PEAK_TFLOPS, 3.0, "co_k_rescnn_forward_h3"),
+    "mlp12x100h3": ("NET_MLP12X100_H3", "mlp12x100", "f32(f16x3)", BF16_MFMA_PEAK_TFLOPS, 3.0, "co_k_mlp_forward_h3"),
     "rescnn4x6": ("NET_RESCNN4_X6", "rescnn4", "f32(bf16x6)", BF16_MFMA_PEAK_TFLOPS, 6.0, "co_k_rescnn_forward_x6"),
     "rescnn4": ("NET_RESCNN4", "rescnn4", "f32", FP32_MFMA_PEAK_TFLOPS, 1.0, "co_k_rescnn_forward"),
     "rescnn4x3": ("NET_RESCNN4_X3", "rescnn4", "bf16x3", BF16_MFMA_PEAK_TFLOPS, 3.0, "co_k_rescnn_forward_x3"),
@@ -59,6 +66,11 @@ NETS = {
     "mlp12x100x3": ("NET_MLP12X100_X3", "mlp12x100", "bf16x3", BF16_MFMA_PEAK_TFLOPS, 3.0, "co_k_mlp_forward_x3"),
 }
 ARITHMETIC = {
+    "f32(f16x3)": "float32 in/out/accumulate; each matrix product as three fp16 MFMA products of two-term operand splits "
+                  "(x = fp16(x) + fp16(x - fp16(x)): 22 significand bits per operand, the dropped term is 2^-22 of a product; fp16 "
+                  "subnormals kept by converter and matrix pipe): float32-class -- error vs float64 within three times the "
+                  "fp32-MFMA kernel's own on every weight set incl. five reference checkpoints (tests/test_net_precision.py, "
+                  "tests/test_trained_golden.py), twenty times inside the 1e-4 contract of BASELINE.json",
     "f32(bf16x6)": "float32 in/out/accumulate; each matrix product as six bf16 MFMA products of three-term operand splits "
                    "(the terms sum to the float32 value; dropped terms < 2^-24 of a product): float32-equivalent, error vs "
                    "float64 = the fp32-MFMA kernel's (tests/test_net_precision.py)",
@@ -77,10 +89,10 @@ def parse():
     ap.add_argument("--spe", type=int, default=16)
     ap.add_argument("--c-puct", type=float, default=1.0)
     ap.add_argument("--epsilon", type=float, default=0.25)
-    ap.add_argument("--net", default="rescnn4x6", choices=sorted(NETS),
-                    help="rescnn4x6 (default) = the 4-block residual CNN BASELINE.json configs[1] names at float32-equivalent "
-                         "split precision; rescnn4 = the same network on fp32 MFMA; mlp12x100* = the reference's own net; "
-                         "*x3 = two-term split, narrower than float32")
+    ap.add_argument("--net", default="rescnn4h3", choices=sorted(NETS),
+                    help="rescnn4h3 (default) = the 4-block residual CNN BASELINE.json configs[1] names at float32-class two-term "
+                         "fp16 split precision; rescnn4x6 = three-term bf16 split (float32-equivalent); rescnn4 = the same network "
+                         "on fp32 MFMA; mlp12x100* = the reference's own net; *x3 = two-term bf16 split, narrower than float32")
     ap.add_argument("--no-mlp-extra", "--no-variants", dest="no_variants", action="store_true",
                     help="skip the other networks reported under detail.variants")
     ap.add_argument("--variant-steps", type=int, default=20, help="timed generations per variant (capped by --steps)")
@@ -94,6 +106,9 @@ def parse():
     ap.add_argument("--recycle-games", type=int, default=16384,
                     help="games of the `recycled` variant: one generation of this many games on --games resident slots "
                          "(a slot whose game ends takes the next game); 0 = skip")
+    ap.add_argument("--no-eval-cache", action="store_true",
+                    help="evaluate every request row (the engine's evaluation cache off); the default run reports this as the "
+                         "`no_eval_cache` variant")
     ap.add_argument("--engine", default="hip", choices=("hip", "emu"),
                     help="hip = the product (libcorintho_hip.so on an MI355X).  emu = CPU rehearsal of the multi-rank path for "
                          "the tests only: the lane-loop build of the same kernel source (tests/emu) over gloo; never a result")
@@ -129,12 +144,15 @@ def launch_ranks(args):
 
 def measured_traffic(kernel, args, net, npools):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
-    (profiles/r02_<net>_pmc.json; PMC counters cannot be collected from inside an un-profiled run).
+    (profiles/r03_<net>_pmc.json, else round 2's; PMC counters cannot be collected from inside an un-profiled run).
     Only valid for the workload those passes were taken on (the default one); otherwise null."""
     if (args.games, args.sims, args.spe) != (4096, 400, 16):
         return None
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_%s_pmc.json" % net)) as f:
+        path = os.path.join(ROOT, "profiles", "r03_%s_pmc.json" % net)
+        if not os.path.exists(path):
+            path = os.path.join(ROOT, "profiles", "r02_%s_pmc.json" % net)
+        with open(path) as f:
             k = json.load(f)["kernels"]
             t = k[kernel]["traffic_bytes_per_launch"]
             if kernel + "_small" in k:  # the network launch queues both instances of the kernel; one of them works
@@ -317,11 +335,12 @@ def main():
         weights_by_arch["mlp12x100"] = mlp12x100_from_tflite(args.tflite)
     flop_by_arch = {"rescnn4": nets.rescnn4_flop_per_row(), "mlp12x100": MLP_FLOP}
 
-    def make_trainer(pools, games=None, resident=-1):
+    def make_trainer(pools, games=None, resident=-1, eval_cache=None):
         n = G if games is None else games
         return Trainer(n, "", 12345, args.sims, args.spe, args.c_puct, args.epsilon, 0, 1, False, device=local_rank,
                        stagger=args.stagger, arena_units=args.arena_units, game_base=rank * n, total_games=world * n,
-                       pools=pools, resident=resident, _cdll=cdll)
+                       pools=pools, resident=resident, eval_cache=(not args.no_eval_cache) if eval_cache is None else eval_cache,
+                       _cdll=cdll)
 
     tr = make_trainer(args.pools)
     gatherer = None
@@ -335,9 +354,10 @@ def main():
         pools_ = max(int(totals.get("pools", 1)), 1)
         cap = slots * args.spe / pools_
         rows = totals["nn_rows"] / max(totals["nn_launches"], 1)
-        return {"rows_per_launch": rows, "capacity_rows": cap, "fill": rows / cap}
+        return {"rows_per_launch": rows, "capacity_rows": cap, "fill": rows / cap,
+                "rows_evaluated_per_launch": totals["nn_rows_evaluated"] / max(totals["nn_launches"], 1)}
 
-    STAT_KEYS = ("searches", "evals", "plies", "iterations", "mcts_ms", "nn_ms", "pack_ms", "nn_rows", "nn_launches",
+    STAT_KEYS = ("searches", "evals", "plies", "iterations", "mcts_ms", "nn_ms", "pack_ms", "nn_rows", "nn_rows_evaluated", "nn_launches",
                  "mcts_launches", "timed_launches", "nn_timed_rows", "mcts_timed_ms", "nn_timed_ms")
 
     def barrier():
@@ -401,12 +421,15 @@ def main():
             if tl > 0:
                 achieved = totals["nn_timed_rows"] * flop_per_row / max(totals["nn_timed_ms"] * 1e-3, 1e-12) / 1e12
             else:
-                achieved = totals["nn_rows"] * flop_per_row / max(nn_s, 1e-12) / 1e12
+                achieved = totals["nn_rows_evaluated"] * flop_per_row / max(nn_s, 1e-12) / 1e12
+            useful = nets.rescnn4_useful_flop_per_row() / flop_per_row if arch == "rescnn4" else 1.0
             r = {"kernel": kname, "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                  "frac": achieved / peak, "traffic": measured_traffic(kname, args, net, npools),
                  "issued_frac": issued * achieved / peak,
+                 # products of a 3x3 tap with the zero padding of the 4x4 board (44 of 144) not counted as work
+                 "algorithmic_useful": {"achieved": achieved * useful, "frac": achieved * useful / peak},
                  "algorithmic": "%.1f KFLOP/row x %d rows in %d timed launches of %d (x%d MFMA products issued per algorithmic one)"
-                                % (flop_per_row / 1e3, totals["nn_timed_rows"] if tl else totals["nn_rows"],
+                                % (flop_per_row / 1e3, totals["nn_timed_rows"] if tl else totals["nn_rows_evaluated"],
                                    tl if tl else totals["nn_launches"], totals["nn_launches"], int(issued)),
                  "avg_launch_ms": (totals["nn_timed_ms"] / tl) if tl else totals["nn_ms"] / max(totals["nn_launches"], 1)}
         else:
@@ -491,7 +514,12 @@ def main():
                                              "pack": totals["pack_ms"] / args.steps,
                                              "sample_gather_and_score_allreduce": totals["gather_ms"] / args.steps},
                 "mcts_GBps_algorithmic": totals["searches"] * BYTES_PER_SIM / max(mcts_s, 1e-12) / 1e9,
-                "network_TFLOPs_algorithmic": totals["nn_rows"] * flop_per_row / max(nn_s, 1e-12) / 1e12,
+                "network_TFLOPs_algorithmic": totals["nn_rows_evaluated"] * flop_per_row / max(nn_s, 1e-12) / 1e12,
+                "nn_rows_requested": totals["nn_rows"], "nn_rows_evaluated": totals["nn_rows_evaluated"],
+                "nn_rows_evaluated_over_requested": totals["nn_rows_evaluated"] / max(totals["nn_rows"], 1),
+                "evaluation_cache": "off" if args.no_eval_cache else
+                                    "on: a request row whose position was evaluated earlier in the SAME generation receives the stored "
+                                    "outputs (bit-identical: a row's outputs depend on the row only); emptied at every generation start",
                 "peak_arena_units_per_tree": totals["peak_arena_units"],
                 "network_batch": batch_fill(totals, G),
                 "world_size": dist.get_world_size() if use_dist else 1,
@@ -511,17 +539,27 @@ def main():
             # the other network kinds on the same pool: the same timed loop, each with its own roofline object
             vsteps = max(1, min(args.variant_steps, args.steps))
             variants = {}
-            for name in ("rescnn4", "rescnn4x3", "mlp12x100x6", "mlp12x100", "mlp12x100x3", "rescnn4x6"):
+            for name in ("rescnn4x6", "rescnn4", "rescnn4x3", "mlp12x100h3", "mlp12x100x6", "mlp12x100", "mlp12x100x3", "rescnn4h3"):
                 if name == args.net:
                     continue
                 d1, t1 = run_generations(tr, name, vsteps, 1, 7000, False)
                 vflop = flop_by_arch[NETS[name][1]]
                 variants[name] = {"games_per_s": G * vsteps / d1, "ms_per_step": d1 * 1e3 / vsteps, "steps": vsteps, "warmup": 1,
                                   "dtype": NETS[name][2], "roofline": roofline_of(name, t1, int(t1.get("pools", 1))),
-                                  "network_TFLOPs_algorithmic": t1["nn_rows"] * vflop / max(t1["nn_ms"] * 1e-3, 1e-12) / 1e12,
+                                  "network_TFLOPs_algorithmic": t1["nn_rows_evaluated"] * vflop / max(t1["nn_ms"] * 1e-3, 1e-12) / 1e12,
+                                  "nn_rows_evaluated_over_requested": t1["nn_rows_evaluated"] / max(t1["nn_rows"], 1),
                                   "mcts_GBps_algorithmic": t1["searches"] * BYTES_PER_SIM / max(t1["mcts_ms"] * 1e-3, 1e-12) / 1e9,
                                   "device_ms_per_step": {"mcts": t1["mcts_ms"] / vsteps, "network": t1["nn_ms"] / vsteps}}
             out["detail"]["variants"] = variants
+            if not args.no_eval_cache:
+                # the same workload with every request row evaluated (the reference's own behaviour, main.pyx:70-83)
+                tr3 = make_trainer(args.pools, eval_cache=False)
+                d3, t3 = run_generations(tr3, args.net, min(5, args.steps), 1, 11000, False)
+                n3 = min(5, args.steps)
+                out["detail"]["no_eval_cache"] = {"games_per_s": G * n3 / d3, "ms_per_step": d3 * 1e3 / n3, "steps": n3, "warmup": 1,
+                                                  "roofline": roofline_of(args.net, t3, int(t3.get("pools", 1))),
+                                                  "nn_rows_evaluated_over_requested": t3["nn_rows_evaluated"] / max(t3["nn_rows"], 1)}
+                del tr3
         if world == 1 and args.recycle_games > G:
             # one generation of `recycle_games` games on G resident slots: a slot whose game ends takes the next game
             # (ca_config.resident), so the launches stay full until the games run out instead of thinning with the

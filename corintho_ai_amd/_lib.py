@@ -37,6 +37,7 @@ class CaConfig(C.Structure):
         ("pools", C.c_int32),
         ("analyse", C.c_int32),
         ("resident", C.c_int32),
+        ("eval_cache", C.c_int32),
     ]
 
 
@@ -60,6 +61,7 @@ class CaStats(C.Structure):
         ("mcts_timed_ms", C.c_double),
         ("nn_timed_ms", C.c_double),
         ("resident_slots", C.c_int64),
+        ("nn_rows_evaluated", C.c_int64),
     ]
 
 

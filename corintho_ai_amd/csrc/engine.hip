@@ -93,13 +93,23 @@ struct Pool {
   bool finished;
   int idle;
   int running; /* games of the pool still running at its last poll */
-  rt_event_t ev[2][3];      /* per window parity: start / after search / after network of the TIMED iteration */
+  rt_event_t ev[2][4];      /* per window parity: start / after search / after cache probe / after network of the TIMED iteration */
   rt_event_t polled[2];
   int launched[2];          /* iterations queued in the window of that parity */
   int word_iter[2];         /* Trainer::searches_done_ of the iteration whose counter word was copied */
   int first_start;          /* iteration at which the stagger releases the pool's first game (trainer.cpp:184-186) */
   int timed[2];             /* the window's last iteration carries the events */
-  unsigned long long *word; /* pinned: counter word copied at the end of window parity 0 / 1 */
+  unsigned long long *word; /* pinned: [parity] counter word copied at the end of window parity 0 / 1, [2 + parity] rows the
+                             * network evaluated in that iteration (evaluation cache) */
+  /* evaluation cache of the pool (EvalCache) */
+  EvalCache cache;
+  uint32_t *c_hdr = nullptr, *c_count = nullptr;
+  float *c_val = nullptr;
+  uint4 *c_keys = nullptr;
+  int32_t *c_owner = nullptr, *c_in_idx = nullptr, *c_out_idx = nullptr;
+  unsigned long long *c_totals = nullptr;
+  size_t c_entries = 0;
+  double c_inserted_est = 0; /* entries taken since the table was last emptied (estimate: timed iteration x window) */
 };
 
 struct ca_trainer {
@@ -112,7 +122,8 @@ struct ca_trainer {
   EngineParams P;
   DevBuf<GameCtl> games;
   DevBuf<TreeCtl> trees;
-  DevBuf<uint4> arena;
+  DevBuf<uint4> arena, pend_key;
+  DevBuf<int32_t> pend_src;
   DevBuf<uint32_t> pend_leaf, pend_path, pend_n, noise_raw, rng;
   DevBuf<int32_t> pend_depth, req_offset, trace, all_done;
   DevBuf<float> req, nn_in, nn_in70, nn_eval, nn_probs, samples;
@@ -139,8 +150,20 @@ struct ca_trainer {
   double mcts_ms = 0, nn_ms = 0, pack_ms = 0;
   int64_t mcts_launches = 0, nn_launches = 0, nn_rows = 0;
   /* fused training: the launches that carried timing events (one per pool and window) */
-  double mcts_timed_ms = 0, nn_timed_ms = 0;
+  double mcts_timed_ms = 0, nn_timed_ms = 0, pack_timed_ms = 0;
   int64_t timed_launches = 0, nn_timed_rows = 0;
+  int64_t nn_rows_evaluated = 0; /* rows the network kernels worked on (= nn_rows without the evaluation cache) */
+  bool cache_clean = false;      /* the pools' tables hold nothing of an earlier generation */
+  int64_t cache_clears = 0;
+  /* the evaluation cache serves fused training (and fused analysis): one network, rows packed by the search kernel */
+  /* Not for the analysis of caller-given positions (the table's header encoding relies on boards that doMove
+   * produced).  Automatic (eval_cache = 0): only for a network whose rows cost more than resolving them -- the 9.65
+   * MFLOP residual CNN, not the 0.25 MFLOP MLP (measured: the MLP's whole launch is 43 us for 12 k rows, the probe 15). */
+  bool use_cache() const {
+    if (cfg.eval_cache < 0 || tourney || cfg.analyse) return false;
+    if (cfg.eval_cache > 0) return true;
+    return nets[0] && nets[0]->flop_per_row() >= 1e6;
+  }
 
   /* tournament mode (ca_tourney): per-match players, per-match seeds, the reference's read offsets */
   bool tourney = false;
@@ -164,6 +187,9 @@ struct ca_trainer {
         rt_event_destroy(q.polled[w]);
       }
       rt_host_free(q.word);
+      for (void *b : {(void *)q.c_hdr, (void *)q.c_count, (void *)q.c_val, (void *)q.c_keys, (void *)q.c_owner, (void *)q.c_in_idx,
+                      (void *)q.c_out_idx, (void *)q.c_totals})
+        rt_free(b);
       rt_stream_destroy(q.st);
     }
     pools.clear();
@@ -257,6 +283,10 @@ struct ca_trainer {
     pend_leaf.alloc((size_t)R * spe, stream);
     pend_depth.alloc((size_t)R * spe, stream);
     pend_n.alloc((size_t)R * spe * 4, stream);
+    if (cfg.eval_cache >= 0 && !tourney && !cfg.analyse) {
+      pend_key.alloc((size_t)R * spe, stream);
+      pend_src.alloc((size_t)R * spe, stream);
+    }
     noise_raw.alloc((size_t)R * spe * CO_NUM_MOVES, stream);
     pend_path.alloc((size_t)R * spe * CO_PATH_MAX, stream);
     rng.alloc((size_t)R * CO_MT_N, stream);
@@ -362,8 +392,10 @@ struct ca_trainer {
     host_games_valid = false;
     mcts_ms = nn_ms = pack_ms = 0;
     mcts_launches = nn_launches = nn_rows = 0;
-    mcts_timed_ms = nn_timed_ms = 0;
+    mcts_timed_ms = nn_timed_ms = pack_timed_ms = 0;
     timed_launches = nn_timed_rows = 0;
+    nn_rows_evaluated = 0;
+    cache_clean = false; /* run_pools empties the tables before the first iteration of the new generation */
   }
 
   void fill_params(uint32_t cap, int total) {
@@ -397,6 +429,8 @@ struct ca_trainer {
     P.pend_leaf = pend_leaf.p;
     P.pend_depth = pend_depth.p;
     P.pend_n = pend_n.p;
+    P.pend_key = pend_key.p;
+    P.pend_src = pend_src.p;
     P.noise_raw = noise_raw.p;
     P.pend_path = pend_path.p;
     P.rng = rng.p;
@@ -788,6 +822,7 @@ struct ca_trainer {
     if (slot < 0 || slot > 1) throw EngineError(CA_ERR_ARG, "net slot must be 0 or 1");
     nets[slot].reset(co_net_create(kind, weights, n, (size_t)R * spe, stream));
     if (!nets[slot]) throw EngineError(CA_ERR_ARG, "unknown net kind or bad weight count");
+    if (slot == 0 && !pools.empty() && (pools[0].cache.hdr != nullptr) != use_cache()) free_pools(); /* rebuilt with / without tables */
   }
 
   /* host rows in, host results out (ca_trainer_net_forward): persistent device buffers; the rows travel as
@@ -836,8 +871,51 @@ struct ca_trainer {
           for (auto &e : q.ev[w]) rt_event_create(&e);
           rt_event_create(&q.polled[w]);
         }
-        rt_host_alloc((void **)&q.word, 16);
+        rt_host_alloc((void **)&q.word, 32);
+        memset(q.word, 0, 32);
+        memset(&q.cache, 0, sizeof q.cache);
+        if (use_cache()) {
+          /* table: a power of two of at least 8192 entries per slot (a 4096-game generation at 400 simulations asks
+           * for ~4100 distinct positions per game), within 1/12 of the free device memory per pool */
+          size_t want = (size_t)q.n * 8192, n = 1;
+          while (n < want) n <<= 1;
+          const size_t per = 16 + CO_CACHE_VAL_FLOATS * 4;
+          while (n > 1024 && n * per > rt_mem_free() / 12) n >>= 1;
+          if (cfg.eval_cache > 0) n = (size_t)1 << (cfg.eval_cache < 6 ? 6 : cfg.eval_cache > 30 ? 30 : cfg.eval_cache); /* given */
+          q.c_entries = n;
+          const size_t rows = (size_t)q.n * spe;
+          rt_malloc((void **)&q.c_hdr, n * 16, q.st);
+          rt_malloc((void **)&q.c_val, (n + rows) * CO_CACHE_VAL_FLOATS * 4, q.st); /* table values + one scratch element per row */
+          rt_malloc((void **)&q.c_keys, rows * 16, q.st);
+          rt_malloc((void **)&q.c_owner, rows * 4, q.st);
+          rt_malloc((void **)&q.c_in_idx, rows * 4, q.st);
+          rt_malloc((void **)&q.c_out_idx, rows * 4, q.st);
+          rt_malloc((void **)&q.c_count, 32, q.st);
+          rt_malloc((void **)&q.c_totals, 16, q.st);
+          q.cache.hdr = q.c_hdr;
+          q.cache.val = q.c_val;
+          q.cache.mask = (uint32_t)(n - 1);
+          q.cache.keys = q.c_keys;
+          q.cache.owner = q.c_owner;
+          q.cache.in_idx = q.c_in_idx;
+          q.cache.out_idx = q.c_out_idx;
+          q.cache.count = q.c_count;
+          q.cache.totals = q.c_totals;
+          rt_sync(q.st);
+        }
       }
+      cache_clean = true; /* freshly zeroed */
+    }
+    const bool cache_clean_now = use_cache() && !cache_clean;
+    if (use_cache() && !cache_clean) {
+      /* a generation starts with an empty table: nothing evaluated in an earlier generation is carried over */
+      for (auto &q : pools) {
+        rt_memset(q.c_hdr, 0, q.c_entries * 16, q.st);
+        rt_memset(q.c_count, 0, 32, q.st);
+        rt_memset(q.c_totals, 0, 16, q.st);
+        rt_sync(q.st);
+      }
+      cache_clean = true;
     }
     for (auto &q : pools) {
       q.finished = false;
@@ -847,6 +925,7 @@ struct ca_trainer {
       q.timed[0] = q.timed[1] = 0;
       q.word_iter[0] = q.word_iter[1] = 0;
       q.first_start = P.stagger_div > 0 ? (P.game_base + q.lo) / P.stagger_div : 0;
+      if (cache_clean_now) q.c_inserted_est = 0;
     }
     rt_sync(stream);
     P.to_play = -1;
@@ -866,13 +945,16 @@ struct ca_trainer {
       if (!q.launched[parity]) return;
       rt_event_sync(q.polled[parity]);
       unsigned long long c = q.word[parity];
+      const unsigned long long evaluated = q.cache.hdr ? q.word[2 + parity] & 0xFFFFFFFFull : c & 0xFFFFFFFFull;
       q.running = (int)(c >> 32);
       if (q.timed[parity]) {
         /* one iteration per window is timed (three event records per launch pair cost 1-4 % of
          * the wall time); its batch size is the counter word just read */
         mcts_timed_ms += rt_event_elapsed_ms(q.ev[parity][0], q.ev[parity][1]);
-        nn_timed_ms += rt_event_elapsed_ms(q.ev[parity][1], q.ev[parity][2]);
-        nn_timed_rows += (int64_t)(c & 0xFFFFFFFFull);
+        pack_timed_ms += rt_event_elapsed_ms(q.ev[parity][1], q.ev[parity][2]); /* cache probe (nothing without a cache) */
+        nn_timed_ms += rt_event_elapsed_ms(q.ev[parity][2], q.ev[parity][3]);
+        nn_timed_rows += (int64_t)evaluated; /* rows the network kernel worked on */
+        q.c_inserted_est += (double)evaluated * poll; /* every evaluated row takes a table entry */
         ++timed_launches;
         q.timed[parity] = 0;
       }
@@ -904,19 +986,43 @@ struct ca_trainer {
         pp.pool_n = q.n;
         pp.pool_row_base = q.row_base;
         pp.pack_counter = pack_counter.p + 2 * p;
+        pp.cache = q.cache; /* (hdr null: no cache) */
         const bool timed = in_window == poll - 1 || (max_iterations > 0 && it + 1 == max_iterations);
+        if (q.cache.hdr && q.c_inserted_est > 0.5 * (double)q.c_entries) {
+          /* the table is half full: start over (a long generation asks for far more positions than any table holds;
+           * what is asked for again is mostly recent -- the trees of the games in play).  In stream order between two
+           * iterations, when no entry is pending. */
+          rt_memset(q.c_hdr, 0, q.c_entries * 16, q.st);
+          q.c_inserted_est = 0;
+          ++cache_clears;
+        }
         rt_event_t *e = q.ev[parity];
         if (timed) rt_event_record(e[0], q.st);
         RT_LAUNCH(co_k_priors, ((q.n) * pp.searches_per_eval + CO_WAVES_PER_BLOCK - 1) / CO_WAVES_PER_BLOCK, CO_WAVE * CO_WAVES_PER_BLOCK, q.st, pp);
         RT_LAUNCH(co_k_mcts_step, q.n, CO_WAVE, q.st, pp);
         if (timed) rt_event_record(e[1], q.st);
-        const int32_t *d_rows = (const int32_t *)(pack_counter.p + 2 * p + (trainer_iteration & 1));
-        nets[0]->forward(nn_in.p + (size_t)q.row_base * CO_STATE_STRIDE, q.n * spe, d_rows, nn_eval.p + q.row_base,
-                         nn_probs.p + (size_t)q.row_base * CO_NUM_MOVES, q.st);
-        if (timed) {
-          rt_event_record(e[2], q.st);
-          q.timed[parity] = 1;
+        if (q.cache.hdr) {
+          /* every request row is resolved to an element of the cache's value array; the network evaluates the rows
+           * whose position has no entry yet, reading them through in_idx and writing straight to out_idx */
+          const int row_blocks = (q.n * spe + CO_WAVE * CO_WAVES_PER_BLOCK - 1) / (CO_WAVE * CO_WAVES_PER_BLOCK);
+          RT_LAUNCH(co_k_cache_probe, row_blocks, CO_WAVE * CO_WAVES_PER_BLOCK, q.st, pp);
+          if (timed) rt_event_record(e[2], q.st);
+          CoNetIO io;
+          io.in_idx = q.c_in_idx;
+          io.out_idx = q.c_out_idx;
+          io.eval_stride = CO_CACHE_VAL_FLOATS;
+          io.probs_stride = CO_CACHE_VAL_FLOATS;
+          nets[0]->forward(nn_in.p + (size_t)q.row_base * CO_STATE_STRIDE, q.n * spe,
+                           (const int32_t *)(q.c_count + 4 * (trainer_iteration & 1)), q.c_val, q.c_val + 4, q.st, io);
+          if (timed) rt_event_record(e[3], q.st);
+        } else {
+          if (timed) rt_event_record(e[2], q.st);
+          const int32_t *d_rows = (const int32_t *)(pack_counter.p + 2 * p + (trainer_iteration & 1));
+          nets[0]->forward(nn_in.p + (size_t)q.row_base * CO_STATE_STRIDE, q.n * spe, d_rows, nn_eval.p + q.row_base,
+                           nn_probs.p + (size_t)q.row_base * CO_NUM_MOVES, q.st);
+          if (timed) rt_event_record(e[3], q.st);
         }
+        if (timed) q.timed[parity] = 1;
         q.launched[parity] = in_window + 1;
         ++mcts_launches;
         ++nn_launches;
@@ -930,6 +1036,7 @@ struct ca_trainer {
         for (auto &q : pools) {
           if (q.finished) continue;
           rt_d2h(&q.word[parity], pack_counter.p + 2 * (&q - &pools[0]) + counter_slot, 8, q.st);
+          if (q.cache.hdr) rt_d2h(&q.word[2 + parity], q.c_count + 4 * counter_slot, 4, q.st);
           q.word_iter[parity] = trainer_iteration - 1;
           rt_event_record(q.polled[parity], q.st);
         }
@@ -966,7 +1073,21 @@ struct ca_trainer {
     check_errors();
     fetch_games();
     nn_rows = 0;
-    for (int g = 0; g < G; ++g) nn_rows += host_games[g].evals; /* every consumed row was evaluated once */
+    for (int g = 0; g < G; ++g) nn_rows += host_games[g].evals; /* every consumed row was requested once */
+    nn_rows_evaluated = nn_rows;
+    if (use_cache()) {
+      nn_rows_evaluated = 0;
+      for (auto &q : pools) {
+        /* booked by the probe kernels, plus the two iterations whose counters nobody has booked yet (at most one is non-zero) */
+        unsigned long long tot[2] = {0, 0};
+        uint32_t cnt[8] = {0};
+        rt_d2h(tot, q.c_totals, 16, q.st);
+        rt_d2h(cnt, q.c_count, 32, q.st);
+        rt_sync(q.st);
+        nn_rows_evaluated += (int64_t)tot[0] + cnt[0] + cnt[4];
+      }
+    }
+    if (timed_launches > 0) pack_ms = pack_timed_ms * (double)nn_launches / (double)timed_launches;
     return finished;
   }
 
@@ -1053,6 +1174,7 @@ struct ca_trainer {
     rt_d2h(&rows, row_counter.p, 8, stream);
     rt_sync(stream);
     nn_rows = (int64_t)rows;
+    nn_rows_evaluated = nn_rows;
     return finished;
   }
 };
@@ -1475,6 +1597,7 @@ extern "C" int ca_trainer_stats(ca_trainer *t, ca_stats *out) {
     out->nn_rows = t->nn_rows;
     out->pools = t->pools.empty() ? 1 : (int64_t)t->pools.size();
     out->resident_slots = t->R;
+    out->nn_rows_evaluated = t->nn_rows_evaluated;
     out->timed_launches = t->timed_launches;
     out->nn_timed_rows = t->nn_timed_rows;
     out->mcts_timed_ms = t->mcts_timed_ms;

@@ -52,6 +52,9 @@ struct CoWave {
   int32_t *pend_depth;
   uint32_t *pend_path;
   uint32_t *pend_n;
+  uint4 *pend_key;      /* cache keys of the pending leaves' rows, or null */
+  const float *cval;    /* evaluation cache: outputs live in cval[csrc[k] * CO_CACHE_VAL_FLOATS] for pending leaf k; null = in place */
+  const int32_t *csrc;
   uint32_t *noise_raw;
   int noise_words; /* generator outputs owed to the leaves queued so far in this step */
   float *req;
@@ -175,6 +178,13 @@ CO_DEV void co_request(CoWave &w, uint64_t board, uint32_t meta, uint32_t leaf, 
     }
     if (lane < 4) w.pend_n[4 * k + lane] = lane == 0 ? pn : lm[lane == 1 ? 0 : lane == 2 ? 1 : 2];
     if (lane <= D && lane < CO_PATH_MAX) pp[lane] = path_slot[lane];
+    if (lane == 0 && w.pend_key) {
+      /* the request row as a key: the board and the reserves in the order Game::writeGameState lays them out (the
+       * mover's first, game.cpp:53-57) -- two positions with the same key have the same 70 floats */
+      const uint32_t pc = meta & 0x3FFFFu;
+      const uint32_t rot = ((meta >> 18) & 1u) ? ((pc >> 9) | (pc << 9)) & 0x3FFFFu : pc;
+      w.pend_key[k] = make_uint4((uint32_t)board, (uint32_t)(board >> 32), rot | 0x80000000u, 0u);
+    }
   }
   WAVE_SYNC();
   w.gc.n_pending = k + 1;
@@ -394,7 +404,8 @@ CO_DEV void co_backup_batch(CoWave &w, CoTree &t, int k0, int nb, const float *e
 #pragma unroll
   for (int k = 0; k < CO_RB; ++k) {
     int D = WAVE_BCAST(dv, k);
-    float leaf_eval = k < nb ? eval[k0 + k] : 0.0f;
+    float leaf_eval = 0.0f;
+    if (k < nb) leaf_eval = w.cval ? w.cval[(size_t)w.csrc[k0 + k] * CO_CACHE_VAL_FLOATS] : eval[k0 + k];
     FOR_LANES {
       if (L(on[k])) {
         uint32_t cur = L(ny[k]);
@@ -1260,6 +1271,7 @@ CO_DEV void co_mcts_step_wave(const EngineParams &P, int g) {
   w.pend_depth = P.pend_depth + (size_t)g * P.searches_per_eval;
   w.pend_path = P.pend_path + (size_t)g * P.searches_per_eval * CO_PATH_MAX;
   w.pend_n = P.pend_n + (size_t)g * P.searches_per_eval * 4;
+  w.pend_key = P.cache.hdr ? P.pend_key + (size_t)g * P.searches_per_eval : (uint4 *)0;
   w.noise_raw = P.noise_raw + (size_t)g * P.searches_per_eval * CO_NUM_MOVES;
   w.noise_words = 0; /* a step consumes every pending leaf before it queues new ones */
   w.req = P.req + (size_t)g * P.searches_per_eval * CO_STATE_STRIDE;
@@ -1285,6 +1297,8 @@ CO_DEV void co_mcts_step_wave(const EngineParams &P, int g) {
 #endif
   int off = co_step_row(P, g, gc);
   const float *step_eval = P.nn_eval + off, *step_probs = P.nn_probs + (size_t)off * CO_NUM_MOVES;
+  w.cval = P.cache.hdr ? P.cache.val : (const float *)0;
+  w.csrc = P.cache.hdr ? P.pend_src + (size_t)g * P.searches_per_eval : (const int32_t *)0;
   int done;
   for (;;) { /* one pass, unless the slot's game ends and the pool hands it the next one */
     done = co_game_step(w, step_eval, step_probs);
@@ -1335,6 +1349,16 @@ CO_DEV void co_mcts_step_wave(const EngineParams &P, int g) {
     const int n = w.gc.n_pending;
     const int base = P.pool_row_base + (int)(unsigned)(old & 0xFFFFFFFFull);
     w.gc.row_off = base;
+    if (w.pend_key) {
+      uint4 *kd = P.cache.keys + (base - P.pool_row_base);
+      int32_t *od = P.cache.owner + (base - P.pool_row_base);
+      FOR_LANES {
+        if (lane < n) {
+          kd[lane] = w.pend_key[lane];
+          od[lane] = g * P.searches_per_eval + lane;
+        }
+      }
+    }
     /* rows are 80 floats = 20 16-byte units, contiguous on both sides; five units per lane and pass,
      * loads first */
     const uint4 *src = (const uint4 *)w.req;

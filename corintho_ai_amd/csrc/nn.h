@@ -14,6 +14,7 @@
 
 #include "rt.h"
 
+#define CO_NET_NUM_MOVES 96
 #define CO_NET_MLP12X100 1
 #define CO_NET_RESCNN4 2
 #define CO_NET_RESCNN4_X3 3 /* same network and weights, convolutions at bf16x3 split precision */
@@ -38,13 +39,23 @@
 #define CO_MLP_NUM_WEIGHTS (70 * 100 + 500 + 11 * (100 * 100 + 500) + 100 + 1 + 100 * 96 + 96)
 #define CO_BN_EPS 1e-3
 
+/* Optional indirection of a network launch (the evaluation cache of fused training): row r of the launch is read
+ * from input row in_idx[r] and its outputs go to element out_idx[r] of arrays with the given strides (floats per
+ * element).  All null / {1, 96}: rows in place, the reference layout. */
+struct CoNetIO {
+  const int32_t *in_idx = nullptr;
+  const int32_t *out_idx = nullptr;
+  int32_t eval_stride = 1;
+  int32_t probs_stride = CO_NET_NUM_MOVES;
+};
+
 struct CoNet {
   virtual ~CoNet() {}
   virtual size_t max_rows() const = 0;
   virtual int kind() const = 0;
   /* d_rows: device int32 holding the number of valid rows (<= rows_cap) */
   virtual void forward(const float *d_in, int32_t rows_cap, const int32_t *d_rows, float *d_eval, float *d_probs,
-                       rt_stream_t s) = 0;
+                       rt_stream_t s, const CoNetIO &io = CoNetIO()) = 0;
   /* algorithmic flop per row, for the roofline */
   virtual double flop_per_row() const = 0;
 };

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256, 1) void co_k_mlp_forward(const float *__restri
                                                            const float *__restrict__ bias,
                                                            const float *__restrict__ bn_a,
                                                            const float *__restrict__ bn_b, float *__restrict__ eval,
-                                                           float *__restrict__ probs) {
+                                                           float *__restrict__ probs, CoNetIO io) {
   extern __shared__ __attribute__((aligned(16))) float lds_all[]; /* 2 x MLP_LAYER_FLOATS */
   const int rows = *d_rows;
   const int row0 = blockIdx.x * MLP_ROWS_PER_WG;
@@ -74,7 +74,8 @@ __global__ __launch_bounds__(256, 1) void co_k_mlp_forward(const float *__restri
 #pragma unroll
     for (int tt = 0; tt < MLP_TILES; ++tt) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (tt < 5 && valid) v = *reinterpret_cast<const float4 *>(in + (size_t)row * CO_STATE_STRIDE + 16 * tt + 4 * q);
+      if (tt < 5 && valid)
+        v = *reinterpret_cast<const float4 *>(in + (size_t)(io.in_idx ? io.in_idx[row] : row) * CO_STATE_STRIDE + 16 * tt + 4 * q);
       x[nb][tt][0] = v.x;
       x[nb][tt][1] = v.y;
       x[nb][tt][2] = v.z;
@@ -167,12 +168,13 @@ __global__ __launch_bounds__(256, 1) void co_k_mlp_forward(const float *__restri
         s += __shfl_xor(s, 16, 64);
         s += __shfl_xor(s, 32, 64);
         if (row < rows) {
+          const size_t orow = (size_t)(io.out_idx ? io.out_idx[row] : row);
 #pragma unroll
           for (int t = 0; t < 6; ++t) {
             float4 p = make_float4(lg[t][0] / s, lg[t][1] / s, lg[t][2] / s, lg[t][3] / s);
-            *reinterpret_cast<float4 *>(probs + (size_t)row * CO_NUM_MOVES + 16 * t + 4 * q) = p;
+            *reinterpret_cast<float4 *>(probs + orow * (size_t)io.probs_stride + 16 * t + 4 * q) = p;
           }
-          if (q == 0) eval[row] = tanhf(acc[nb][6][0] + bv);
+          if (q == 0) eval[orow * (size_t)io.eval_stride] = tanhf(acc[nb][6][0] + bv);
         }
       }
     }
@@ -238,11 +240,11 @@ struct MlpNet : CoNet {
   int kind() const override { return CO_NET_MLP12X100; }
   double flop_per_row() const override { return 2.0 * (70 * 100 + 11 * 100 * 100 + 100 + 100 * 96); }
   void forward(const float *d_in, int32_t rows_cap, const int32_t *d_rows, float *d_eval, float *d_probs,
-               rt_stream_t s) override {
+               rt_stream_t s, const CoNetIO &io = CoNetIO()) override {
     int grid = (rows_cap + MLP_ROWS_PER_WG - 1) / MLP_ROWS_PER_WG;
     if (grid < 1) return;
     hipLaunchKernelGGL(co_k_mlp_forward, dim3(grid), dim3(256), 2 * MLP_LAYER_FLOATS * sizeof(float), s, d_in, d_rows, (const float *)d_wfrag,
-                       (const float *)d_bias, (const float *)d_a, (const float *)d_b, d_eval, d_probs);
+                       (const float *)d_bias, (const float *)d_a, (const float *)d_b, d_eval, d_probs, io);
     RT_CHECK(hipGetLastError());
   }
 };

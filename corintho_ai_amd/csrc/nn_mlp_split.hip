@@ -180,7 +180,7 @@ __device__ __forceinline__ void m3_init_bias(m3_f32x16 (&acc)[4], const float *b
 template <int NT, bool F16 = false>
 __global__ __launch_bounds__(256, 1) void co_k_mlp_forward_split_t(const float *__restrict__ in, const int32_t *__restrict__ d_rows,
                                                                    const uint32_t *__restrict__ wfrag, float *__restrict__ eval,
-                                                                   float *__restrict__ probs) {
+                                                                   float *__restrict__ probs, CoNetIO io) {
   static_assert(M3_CHUNK_PIECES_PER_WAVE(2) == 9 && M3_CHUNK_PIECES_PER_WAVE(3) == 13, "vmcnt immediates of M3_CHUNK_HEAD");
   extern __shared__ __attribute__((aligned(16))) uint32_t m3_lds[]; /* ring of three chunk slots */
   const int rows = *d_rows;
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256, 1) void co_k_mlp_forward_split_t(const float *
 #pragma unroll
       for (int m = 0; m < 4; ++m) b[t][s][m] = 0u;
   if (row < rows) {
-    const float *x = in + (size_t)row * CO_STATE_STRIDE;
+    const float *x = in + (size_t)(io.in_idx ? io.in_idx[row] : row) * CO_STATE_STRIDE;
 #pragma unroll
     for (int s = 0; s < M3_STEPS_L0; ++s) {
       const float4 v0 = *reinterpret_cast<const float4 *>(x + 16 * s + 4 * h);
@@ -274,14 +274,15 @@ __global__ __launch_bounds__(256, 1) void co_k_mlp_forward_split_t(const float *
   sum += __shfl_xor(sum, 32, 64);
   const float inv = 1.0f / sum;
   if (row < rows) {
+    const size_t orow = (size_t)(io.out_idx ? io.out_idx[row] : row);
 #pragma unroll
     for (int T = 0; T < 3; ++T)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         float4 p = make_float4(acc[T][4 * g] * inv, acc[T][4 * g + 1] * inv, acc[T][4 * g + 2] * inv, acc[T][4 * g + 3] * inv);
-        *reinterpret_cast<float4 *>(probs + (size_t)row * CO_NUM_MOVES + 32 * T + 8 * g + 4 * h) = p;
+        *reinterpret_cast<float4 *>(probs + orow * (size_t)io.probs_stride + 32 * T + 8 * g + 4 * h) = p;
       }
-    if (h == 0) eval[row] = tanhf(acc[3][0]);
+    if (h == 0) eval[orow * (size_t)io.eval_stride] = tanhf(acc[3][0]);
   }
 }
 #define co_k_mlp_forward_x3 co_k_mlp_forward_split_t<2>
@@ -409,18 +410,18 @@ struct MlpSplitNet : CoNet {
   int kind() const override { return f16 ? CO_NET_MLP12X100_H3 : nt == 2 ? CO_NET_MLP12X100_X3 : CO_NET_MLP12X100_X6; }
   double flop_per_row() const override { return 2.0 * (70 * 100 + 11 * 100 * 100 + 100 + 100 * 96); }
   void forward(const float *d_in, int32_t rows_cap, const int32_t *d_rows, float *d_eval, float *d_probs,
-               rt_stream_t s) override {
+               rt_stream_t s, const CoNetIO &io = CoNetIO()) override {
     int grid = (rows_cap + M3_ROWS_PER_WG - 1) / M3_ROWS_PER_WG;
     if (grid < 1) return;
     if (f16)
       hipLaunchKernelGGL(co_k_mlp_forward_h3, dim3(grid), dim3(256), M3_LDS_BYTES(2), s, d_in, d_rows, (const uint32_t *)d_w, d_eval,
-                         d_probs);
+                         d_probs, io);
     else if (nt == 2)
       hipLaunchKernelGGL(co_k_mlp_forward_x3, dim3(grid), dim3(256), M3_LDS_BYTES(2), s, d_in, d_rows, (const uint32_t *)d_w, d_eval,
-                         d_probs);
+                         d_probs, io);
     else
       hipLaunchKernelGGL(co_k_mlp_forward_x6, dim3(grid), dim3(256), M3_LDS_BYTES(3), s, d_in, d_rows, (const uint32_t *)d_w, d_eval,
-                         d_probs);
+                         d_probs, io);
     RT_CHECK(hipGetLastError());
   }
 };

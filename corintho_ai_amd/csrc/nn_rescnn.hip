@@ -61,7 +61,12 @@ struct RcParams {
   const float *bv2;       /* [1] */
   float *eval;
   float *probs;
+  CoNetIO io;             /* row indirection (evaluation cache), see nn.h */
 };
+
+/* input row / output element of launch row `pos` */
+__device__ __forceinline__ size_t rc_in_row(const RcParams &P, int pos) { return (size_t)(P.io.in_idx ? P.io.in_idx[pos] : pos); }
+__device__ __forceinline__ size_t rc_out_row(const RcParams &P, int pos) { return (size_t)(P.io.out_idx ? P.io.out_idx[pos] : pos); }
 
 __device__ __forceinline__ const float *rc_chunk_ptr(const float *wtrunk, int ch) {
   return ch < 9 ? wtrunk + ch * RC_STEM_CHUNK : wtrunk + 9 * RC_STEM_CHUNK + (ch - 9) * RC_CONV_CHUNK;
@@ -259,10 +264,11 @@ __device__ __forceinline__ void rc_dense_policy(const RcParams &P, const float *
   const float inv = 1.0f / sum;
   const int pos = pos_base + c;
   if (pos < rows && c < ncols) { /* a workgroup of the thin kernel owns the first ncols = 8 columns of the tile only */
+    const size_t orow = rc_out_row(P, pos);
 #pragma unroll
     for (int to = 0; to < 6; ++to) {
       float4 p = make_float4(lg[to][0] * inv, lg[to][1] * inv, lg[to][2] * inv, lg[to][3] * inv);
-      *reinterpret_cast<float4 *>(P.probs + (size_t)pos * CO_NUM_MOVES + 16 * to + 4 * q) = p;
+      *reinterpret_cast<float4 *>(P.probs + orow * (size_t)P.io.probs_stride + 16 * to + 4 * q) = p;
     }
   }
 }
@@ -294,7 +300,7 @@ __device__ __forceinline__ void rc_dense_value(const RcParams &P, const float *w
     }
   }
   const int pos = pos_base + c;
-  if (q == 0 && pos < rows && c < ncols) P.eval[pos] = tanhf(v2[0] + P.bv2[0]);
+  if (q == 0 && pos < rows && c < ncols) P.eval[rc_out_row(P, pos) * (size_t)P.io.eval_stride] = tanhf(v2[0] + P.bv2[0]);
 }
 
 __global__ __launch_bounds__(256, 2) void co_k_rescnn_forward(RcParams P) {
@@ -315,7 +321,7 @@ __global__ __launch_bounds__(256, 2) void co_k_rescnn_forward(RcParams P) {
   for (int nb = 0; nb < RC_NB; ++nb) {
     const int pos = row0 + wave * RC_NB + nb;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (pos < rows) v = *reinterpret_cast<const float4 *>(P.in + (size_t)pos * CO_STATE_STRIDE + (q == 0 ? 4 * c : 60 + 4 * q));
+    if (pos < rows) v = *reinterpret_cast<const float4 *>(P.in + rc_in_row(P, pos) * CO_STATE_STRIDE + (q == 0 ? 4 * c : 60 + 4 * q));
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -710,7 +716,7 @@ __device__ __forceinline__ void rcs_forward(const Rc3Params &Q) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) x[np][T][i] = 0.0f;
     if (pos < rows) {
-      const float *row = P.in + (size_t)pos * CO_STATE_STRIDE;
+      const float *row = P.in + rc_in_row(P, pos) * CO_STATE_STRIDE;
       const float4 v0 = *reinterpret_cast<const float4 *>(row + (h == 0 ? 4 * c : 64));
       const float4 v1 = *reinterpret_cast<const float4 *>(row + (h == 0 ? 68 : 72));
       x[np][0][0] = v0.x; x[np][0][1] = v0.y; x[np][0][2] = v0.z; x[np][0][3] = v0.w;
@@ -941,10 +947,11 @@ struct ResCnnNet : CoNet {
     return 2.0 * 16 * 9 * (10 * 64 + 8 * 64 * 64) + 2.0 * 16 * 64 * 6 + 2.0 * 64 * 96 + 2.0 * 32 * 64 + 2.0 * 64;
   }
   void forward(const float *d_in, int32_t rows_cap, const int32_t *d_rows, float *d_eval, float *d_probs,
-               rt_stream_t s) override {
+               rt_stream_t s, const CoNetIO &io = CoNetIO()) override {
     int grid = (rows_cap + RC_POS_PER_WG - 1) / RC_POS_PER_WG;
     if (grid < 1) return;
     RcParams p = P;
+    p.io = io;
     p.in = d_in;
     p.d_rows = d_rows;
     p.eval = d_eval;
@@ -1076,10 +1083,11 @@ struct ResCnnSplitNet : ResCnnNet {
   }
   int kind() const override { return f16 ? CO_NET_RESCNN4_H3 : nt == 2 ? CO_NET_RESCNN4_X3 : CO_NET_RESCNN4_X6; }
   void forward(const float *d_in, int32_t rows_cap, const int32_t *d_rows, float *d_eval, float *d_probs,
-               rt_stream_t s) override {
+               rt_stream_t s, const CoNetIO &io = CoNetIO()) override {
     if (rows_cap < 1) return;
     Rc3Params q;
     q.base = P;
+    q.base.io = io;
     q.base.in = d_in;
     q.base.d_rows = d_rows;
     q.base.eval = d_eval;

@@ -78,6 +78,23 @@ static inline double co_sqrt_f64(double x) { return sqrt(x); }
 static inline unsigned long long co_atomic_add_u64(unsigned long long *p, unsigned long long v) {
   return __atomic_fetch_add(p, v, __ATOMIC_RELAXED);
 }
+/* 32-bit atomics of the evaluation cache (kernels.h): compare-and-swap returning the old value, add, and a load /
+ * store that other workgroups' atomics are coherent with */
+static inline uint32_t co_atomic_cas_u32(uint32_t *p, uint32_t expected, uint32_t desired) {
+  __atomic_compare_exchange_n(p, &expected, desired, 0, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE);
+  return expected;
+}
+static inline uint32_t co_atomic_add_u32(uint32_t *p, uint32_t v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline uint32_t co_atomic_load_u32(const uint32_t *p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
+static inline void co_atomic_store_u32(uint32_t *p, uint32_t v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
+static inline void co_wait_stores() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+/* per-lane coherent accesses (inside FOR_LANES) */
+static inline uint32_t co_lane_load_coherent_u32(const uint32_t *p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
+static inline void co_lane_store_coherent_u32(uint32_t *p, uint32_t v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
+static inline uint32_t co_lane_cas_u32(uint32_t *p, uint32_t expected, uint32_t desired) {
+  __atomic_compare_exchange_n(p, &expected, desired, 0, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE);
+  return expected;
+}
 extern thread_local int co_emu_block_idx;
 #define CO_BLOCK_IDX co_emu_block_idx
 /* kernels whose wavefronts are independent may pack several per workgroup on the GPU (fewer, fatter
@@ -175,6 +192,41 @@ __device__ __forceinline__ unsigned long long co_atomic_add_u64(unsigned long lo
   unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(old >> 32));
   return ((unsigned long long)hi << 32) | lo;
 }
+/* 32-bit device-scope atomics of the evaluation cache (kernels.h), one per wave (lane 0), result broadcast.  The
+ * 8 XCDs of the chip have separate L2s: a header word another workgroup may be writing in the same launch is
+ * read and written through these (device-scope, performed at the memory side), never through a plain access. */
+__device__ __forceinline__ uint32_t co_atomic_cas_u32(uint32_t *p, uint32_t expected, uint32_t desired) {
+  uint32_t old = 0;
+  if ((threadIdx.x & 63) == 0) old = atomicCAS(p, expected, desired);
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
+}
+__device__ __forceinline__ uint32_t co_atomic_add_u32(uint32_t *p, uint32_t v) {
+  uint32_t old = 0;
+  if ((threadIdx.x & 63) == 0) old = atomicAdd(p, v);
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
+}
+/* RELAXED on purpose: an acquire / release at device scope makes the wave invalidate / write back its XCD's whole L2
+ * (buffer_inv / buffer_wbl2 sc1) -- measured: the search kernels three times slower with thousands of such waves in
+ * flight.  The accesses themselves are performed at the coherent level (sc1); the cache's protocol tolerates any order
+ * in which its words become visible (kernels.h). */
+__device__ __forceinline__ uint32_t co_atomic_load_u32(const uint32_t *p) {
+  uint32_t v = 0;
+  if ((threadIdx.x & 63) == 0) v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ void co_atomic_store_u32(uint32_t *p, uint32_t v) {
+  if ((threadIdx.x & 63) == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+/* this wave's earlier stores have been acknowledged (no cache maintenance) */
+__device__ __forceinline__ void co_wait_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+/* per-lane device-scope accesses (inside FOR_LANES): every lane its own word, relaxed (see above) */
+__device__ __forceinline__ uint32_t co_lane_load_coherent_u32(const uint32_t *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void co_lane_store_coherent_u32(uint32_t *p, uint32_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t co_lane_cas_u32(uint32_t *p, uint32_t expected, uint32_t desired) { return atomicCAS(p, expected, desired); }
 #define CO_BLOCK_IDX ((int)blockIdx.x)
 #define CO_WAVES_PER_BLOCK 4
 #define CO_WAVE_IN_BLOCK ((int)(threadIdx.x >> 6))

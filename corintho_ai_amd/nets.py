@@ -180,6 +180,14 @@ def rescnn4_flop_per_row():
     return float(conv + heads)
 
 
+def rescnn4_useful_flop_per_row():
+    """the same count without the products of a 3x3 tap with zero padding: on the 4x4 board 100 of the 144
+    (pixel, tap) pairs lie inside it (corners 4 taps, edges 6, interior 9).  The kernels multiply the zeros too."""
+    conv = 2 * 16 * 9 * (RES_CIN * RES_C + 2 * RES_BLOCKS * RES_C * RES_C) * 100.0 / 144.0
+    heads = 2 * 16 * RES_C * 6 + 2 * 64 * NUM_MOVES + 2 * 32 * 64 + 2 * 64
+    return float(conv + heads)
+
+
 def init_rescnn4(seed=0, bn_noise=False):
     rng = np.random.default_rng(seed)
     parts = []

@@ -75,6 +75,12 @@ typedef struct ca_config {
    * whole.  0 = automatic (all games resident when their trees fit in 5/8 of the free device memory, else as many
    * slots as fit); >= num_games or < 0 = all resident.  With fewer slots than games the staggered start is off. */
   int32_t resident;
+  /* Evaluation cache of fused training (ca_trainer_run): a request row whose position was evaluated earlier in the same
+   * generation receives the stored outputs instead of a second evaluation -- bit for bit what the network kernel would
+   * write again, since a row's outputs depend on the row only.  Emptied at the start of every generation (and whenever
+   * it is half full).  0 = on, table sized from the pool and the free memory; n > 0 = on with 2^n entries per pool;
+   * negative = off.  (The reference evaluates every request, main.pyx:70-83; results are identical either way.) */
+  int32_t eval_cache;
 } ca_config;
 
 const char *ca_last_error(void);
@@ -204,6 +210,7 @@ typedef struct ca_stats {
   int64_t nn_timed_rows;  /* batch rows of those network launches */
   double mcts_timed_ms, nn_timed_ms;
   int64_t resident_slots; /* slots of the pool (= num_games unless it recycles, ca_config.resident) */
+  int64_t nn_rows_evaluated; /* rows the network kernels worked on; nn_rows - this = rows served by the evaluation cache */
 } ca_stats;
 int ca_trainer_stats(ca_trainer *t, ca_stats *out);
 /* per-game: {to_play, done, result, n_samples, n_pending, error, mate_turn, plies} */

@@ -16,7 +16,8 @@ struct EmuMlp : CoNet {
   size_t max_rows() const override { return cap; }
   int kind() const override { return CO_NET_MLP12X100; }
   double flop_per_row() const override { return 2.0 * (70 * 100 + 11 * 100 * 100 + 100 + 100 * 96); }
-  void forward(const float *in, int32_t rows_cap, const int32_t *d_rows, float *ev, float *pr, rt_stream_t) override {
+  void forward(const float *in, int32_t rows_cap, const int32_t *d_rows, float *ev, float *pr, rt_stream_t,
+               const CoNetIO &io = CoNetIO()) override {
     int n = *d_rows;
     (void)rows_cap;
 #pragma omp parallel for
@@ -24,7 +25,8 @@ struct EmuMlp : CoNet {
       float x[100], y[100];
       const float *p = w.data();
       int in_dim = 70;
-      for (int i = 0; i < 70; ++i) x[i] = in[(size_t)r * CO_STATE_STRIDE + i];
+      const size_t irow = io.in_idx ? (size_t)io.in_idx[r] : (size_t)r, orow = io.out_idx ? (size_t)io.out_idx[r] : (size_t)r;
+      for (int i = 0; i < 70; ++i) x[i] = in[irow * CO_STATE_STRIDE + i];
       for (int l = 0; l < 12; ++l) {
         const float *K = p, *b = K + in_dim * 100, *ga = b + 100, *be = ga + 100, *mu = be + 100, *va = mu + 100;
         for (int o = 0; o < 100; ++o) {
@@ -43,7 +45,7 @@ struct EmuMlp : CoNet {
       const float *Kv = p, *bv = Kv + 100, *Kp = bv + 1, *bp = Kp + 9600;
       float v = 0.0f;
       for (int i = 0; i < 100; ++i) v = fmaf(x[i], Kv[i], v);
-      ev[r] = tanhf(v + bv[0]);
+      ev[orow * (size_t)io.eval_stride] = tanhf(v + bv[0]);
       float lg[96], mx = -INFINITY;
       for (int o = 0; o < 96; ++o) {
         float s = 0.0f;
@@ -56,7 +58,7 @@ struct EmuMlp : CoNet {
         lg[o] = expf(lg[o] - mx);
         sum += lg[o];
       }
-      for (int o = 0; o < 96; ++o) pr[(size_t)r * 96 + o] = lg[o] / sum;
+      for (int o = 0; o < 96; ++o) pr[orow * (size_t)io.probs_stride + o] = lg[o] / sum;
     }
   }
 };

@@ -569,7 +569,8 @@ def test_full_size_generation_properties(kind_name):
     t.set_net(NET_RESCNN4_X3, w)
     assert t.run()
     st = t.stats()
-    assert st["nn_rows"] == st["evals"] > 0  # every evaluation consumed was one row of a network launch
+    assert st["nn_rows"] == st["evals"] > 0  # every evaluation consumed was one request row
+    assert 0 < st["nn_rows_evaluated"] < st["nn_rows"]  # ... and the evaluation cache served some of them (on by default here)
     infos = [t.game_info(g) for g in range(0, G, 97)]
     assert all(i["done"] == 1 and i["error"] == 0 and 0 < i["n_samples"] <= 40 for i in infos)
     gs, ev, pr = H.get_samples(t)

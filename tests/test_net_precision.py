@@ -6,7 +6,10 @@ three arithmetic widths per architecture:
   * "bf16x6" (kinds 5, 6): both operands of every product as three bf16 terms whose sum IS the
     float32 value, six MFMA products (everything above 2^-24 of a product), fp32 accumulation --
     claimed float32-equivalent;
-  * "bf16x3" (kinds 3, 4): two terms, three products: 16 significand bits, narrower than float32.
+  * "bf16x3" (kinds 3, 4): two terms, three products: 16 significand bits, narrower than float32;
+  * "f16x3" (kinds 8, 9): two fp16 terms per operand -- 22 significand bits -- three products on the fp16 matrix pipe
+    (which keeps fp16 subnormals, tools/exp/f16_denorm.hip): the MFMA work of bf16x3 with the error of the
+    float32-wide kinds -- claimed float32-class: within three times the fp32-MFMA kernel's own error.
 The claim of the second line is tested here: on random-init weights, on weights with BatchNorm
 noise and on trained-scale synthetic weights (kernels x 4, BatchNorm variances 0.1 .. 10, logits
 several units wide), the bf16x6 kernels' error against float64 is no larger than twice the fp32-MFMA
@@ -16,8 +19,8 @@ of one per product), while bf16x3 sits one to two orders of magnitude above both
 import numpy as np
 import pytest
 
-from corintho_ai_amd import (NET_MLP12X100, NET_MLP12X100_X3, NET_MLP12X100_X6, NET_RESCNN4, NET_RESCNN4_X3,
-                             NET_RESCNN4_X6, nets)
+from corintho_ai_amd import (NET_MLP12X100, NET_MLP12X100_H3, NET_MLP12X100_X3, NET_MLP12X100_X6, NET_RESCNN4, NET_RESCNN4_H3,
+                             NET_RESCNN4_X3, NET_RESCNN4_X6, nets)
 from oracle import oracle as O
 from tests import harness as H
 from tests.engines import make_trainer
@@ -55,9 +58,13 @@ def _check(kinds, sets, f64, label, floor):
         e32 = _errors(t, kinds[0], w, states, want)
         e6 = _errors(t, kinds[1], w, states, want)
         e3 = _errors(t, kinds[2], w, states, want)
-        rows.append((name, e32, e6, e3))
-        print("%s %-15s |err| vs float64  value: fp32 %.2e  bf16x6 %.2e  bf16x3 %.2e   policy: fp32 %.2e  bf16x6 %.2e  bf16x3 %.2e"
-              % (label, name, e32[0], e6[0], e3[0], e32[1], e6[1], e3[1]))
+        eh = _errors(t, kinds[3], w, states, want)
+        rows.append((name, e32, e6, e3, eh))
+        print("%s %-15s |err| vs float64  value: fp32 %.2e  bf16x6 %.2e  f16x3 %.2e  bf16x3 %.2e   policy: fp32 %.2e  bf16x6 %.2e  "
+              "f16x3 %.2e  bf16x3 %.2e" % (label, name, e32[0], e6[0], eh[0], e3[0], e32[1], e6[1], eh[1], e3[1]))
+        # f16x3: float32-class -- within three times the fp32-MFMA kernel's error (same floor), and far inside the contract
+        assert eh[0] <= 3.0 * e32[0] + floor and eh[1] <= 3.0 * e32[1] + floor, (name, eh, e32)
+        assert eh[0] < 1e-5 and eh[1] < 1e-5
         # float32-equivalence: no worse than twice the fp32-MFMA kernel (floor: a few float32 ulps of
         # the output, below which the final tanh / softmax roundings decide)
         assert e6[0] <= 2.0 * e32[0] + floor, (name, e6, e32)
@@ -69,26 +76,33 @@ def _check(kinds, sets, f64, label, floor):
 
 
 def test_rescnn4_bf16x6_is_float32_equivalent():
-    _check((NET_RESCNN4, NET_RESCNN4_X6, NET_RESCNN4_X3), CNN_SETS, nets.rescnn4_forward_f64, "rescnn4", 2.4e-7)
+    _check((NET_RESCNN4, NET_RESCNN4_X6, NET_RESCNN4_X3, NET_RESCNN4_H3), CNN_SETS, nets.rescnn4_forward_f64, "rescnn4", 2.4e-7)
 
 
 def test_mlp12x100_bf16x6_is_float32_equivalent():
-    _check((NET_MLP12X100, NET_MLP12X100_X6, NET_MLP12X100_X3), MLP_SETS, nets.mlp12x100_forward_f64, "mlp12x100", 2.4e-7)
+    _check((NET_MLP12X100, NET_MLP12X100_X6, NET_MLP12X100_X3, NET_MLP12X100_H3), MLP_SETS, nets.mlp12x100_forward_f64, "mlp12x100", 2.4e-7)
 
 
 @pytest.mark.parametrize("kind,make", [(NET_RESCNN4_X6, lambda: nets.trained_like_rescnn4(2)),
-                                       (NET_MLP12X100_X6, lambda: nets.trained_like_mlp12x100(2))],
-                         ids=["rescnn4x6", "mlp12x100x6"])
+                                       (NET_MLP12X100_X6, lambda: nets.trained_like_mlp12x100(2)),
+                                       (NET_RESCNN4_H3, lambda: nets.trained_like_rescnn4(2)),
+                                       (NET_MLP12X100_H3, lambda: nets.trained_like_mlp12x100(2))],
+                         ids=["rescnn4x6", "mlp12x100x6", "rescnn4h3", "mlp12x100h3"])
 def test_bf16x6_rows_do_not_depend_on_their_batch(kind, make):
     """SURVEY 8e invariant: a row's outputs are a function of the row only (fixed k order, no
     batch-dependent tiling), for every batch size around the kernels' tile boundaries"""
-    t = make_trainer("hip", 256, "", 1, 50, 16, 1.0, 0.25, 0, 1, False)
+    t = make_trainer("hip", 512, "", 1, 50, 16, 1.0, 0.25, 0, 1, False)
     t.set_net(kind, make())
     states = _states(4096, 9)
     ev, pr = t.net_forward(states)
     assert np.all(np.abs(pr.sum(axis=1) - 1) < 1e-5)
     # ... and around 2048 rows, where the residual CNN changes from its four-wave thin-batch kernel (8 positions per
     # workgroup) to the throughput kernel (16)
+    # (the two-term kernels change from 16 to 32 positions per workgroup above 4096 rows: the 8192-row reference batch below)
+    states8 = _states(8192, 10)
+    ev8, pr8 = t.net_forward(states8)
+    e1, p1 = t.net_forward(states8[100:4100])
+    assert np.array_equal(e1, ev8[100:4100]) and np.array_equal(p1, pr8[100:4100])
     for lo, hi in ((0, 1), (5, 6), (0, 7), (0, 8), (0, 9), (0, 15), (0, 16), (0, 17), (100, 131), (100, 228), (0, 129), (300, 1024),
                    (0, 2047), (0, 2048), (0, 2049), (1000, 3050), (2040, 4096)):
         e1, p1 = t.net_forward(states[lo:hi])
@@ -96,8 +110,10 @@ def test_bf16x6_rows_do_not_depend_on_their_batch(kind, make):
 
 
 @pytest.mark.parametrize("kind,make", [(NET_RESCNN4_X6, lambda: nets.init_rescnn4(0, bn_noise=True)),
-                                       (NET_MLP12X100_X6, lambda: nets.init_mlp12x100(2, bn_noise=True))],
-                         ids=["rescnn4x6", "mlp12x100x6"])
+                                       (NET_MLP12X100_X6, lambda: nets.init_mlp12x100(2, bn_noise=True)),
+                                       (NET_RESCNN4_H3, lambda: nets.init_rescnn4(0, bn_noise=True)),
+                                       (NET_MLP12X100_H3, lambda: nets.init_mlp12x100(2, bn_noise=True))],
+                         ids=["rescnn4x6", "mlp12x100x6", "rescnn4h3", "mlp12x100h3"])
 def test_fused_bf16x6_generation_replays_on_the_oracle(kind, make):
     G, S_, spe = 24, 40, 8
     f = make_trainer("hip", G, "", 33, S_, spe, 1.0, 0.25, 0, 1, False, stagger=False)

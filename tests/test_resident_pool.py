@@ -148,3 +148,58 @@ def test_reference_production_setting_25000_games_1600_simulations():
     assert ogs[0::8].tobytes() == sp[:m, :70].tobytes()
     assert opr[0::8].tobytes() == sp[:m, 70:].tobytes()
     assert oev[0::8].tobytes() == oc[:m].tobytes()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Evaluation cache (ca_config.eval_cache): a request row whose position was evaluated earlier in the generation gets the
+# stored outputs.  A row's outputs are a function of the row, so nothing a game sees changes: every result equals the
+# uncached run's bit for bit, with fewer rows through the network kernel.
+@pytest.mark.parametrize("engine", ENGINES)
+def test_evaluation_cache_changes_nothing_but_the_rows_evaluated(engine):
+    G, S_, spe, seed = 24, 60, 8, 31
+    runs = {}
+    # 18: a table of 2^18 entries per pool (an explicit size switches the cache on for any network; automatic = only for
+    # networks whose rows are expensive); 6: 64 entries -- full at once, emptied again and again
+    for cache in (False, 18, 6):
+        for R, pools in ((-1, 1), (-1, 2), (7, 2)):
+            t = make_trainer(engine, G, "", seed, S_, spe, 1.0, 0.25, 0, 1, False, stagger=False, trace=True, resident=R, pools=pools,
+                             eval_cache=cache)
+            t.set_net(1, nets.init_mlp12x100(seed=3, bn_noise=True))
+            assert t.run()
+            st = t.stats()
+            runs[(cache, R, pools)] = (_digest(t, G), [t.trace(g).tobytes() for g in range(G)], st)
+            if cache == 18:
+                assert 0 < st["nn_rows_evaluated"] < st["nn_rows"] == st["evals"]
+            elif cache:
+                assert 0 < st["nn_rows_evaluated"] <= st["nn_rows"] == st["evals"]
+            else:
+                assert st["nn_rows_evaluated"] == st["nn_rows"] == st["evals"]
+            # a second generation in the same pool starts from an empty table and is a function of its seed only
+            t.reset(seed)
+            assert t.run()
+            assert _digest(t, G) == runs[(cache, R, pools)][0]
+            if cache == 18:
+                assert t.stats()["nn_rows_evaluated"] < t.stats()["nn_rows"]
+    ref = runs[(False, -1, 1)]
+    for k, v in runs.items():
+        assert v[0] == ref[0] and v[1] == ref[1], k
+    saved = 1.0 - runs[(18, -1, 1)][2]["nn_rows_evaluated"] / runs[(18, -1, 1)][2]["nn_rows"]
+    print("rows served by the cache: %.1f %%" % (100 * saved))
+    assert saved > 0.03
+
+
+@pytest.mark.parametrize("engine", ENGINES)
+def test_evaluation_cache_with_a_tiny_table_and_an_iteration_cap(engine, monkeypatch):
+    """continuing a capped run keeps the table; the oracle agrees with the cached engine game for game"""
+    G, S_, spe, seed = 10, 40, 8, 5
+    t = make_trainer(engine, G, "", seed, S_, spe, 1.0, 0.25, 0, 1, False, stagger=False, trace=True, eval_cache=12)
+    t.set_net(1, nets.init_mlp12x100(seed=3, bn_noise=True))
+    assert not t.run(max_iterations=9)
+    assert t.run()
+    o = O.Trainer(G, seed=seed, max_searches=S_, searches_per_eval=spe)
+    o.enable_trace()
+    o.set_stagger(False)
+    H.play_generation(o, G, spe, lambda s: t.net_forward(s))
+    for g in range(G):
+        assert np.array_equal(t.trace(g), o.trace(g)), g
+    assert all(x.tobytes() == y.tobytes() for x, y in zip(H.get_samples(t), H.get_samples(o)))

@@ -12,7 +12,7 @@ import os
 import numpy as np
 import pytest
 
-from corintho_ai_amd import NET_MLP12X100, NET_MLP12X100_X3, NET_MLP12X100_X6, nets
+from corintho_ai_amd import NET_MLP12X100, NET_MLP12X100_H3, NET_MLP12X100_X3, NET_MLP12X100_X6, nets
 from oracle import oracle as O
 from tests import harness as H
 from tests.engines import ENGINES, make_trainer
@@ -54,7 +54,7 @@ def test_split_precision_kernels_on_trained_weights(tag):
     z = load(tag)
     t = make_trainer("hip", 16, "", 1, 50, 16, 1.0, 0.25, 0, 1, False)
     err = {}
-    for name, kind in (("fp32", NET_MLP12X100), ("bf16x6", NET_MLP12X100_X6), ("bf16x3", NET_MLP12X100_X3)):
+    for name, kind in (("fp32", NET_MLP12X100), ("bf16x6", NET_MLP12X100_X6), ("f16x3", NET_MLP12X100_H3), ("bf16x3", NET_MLP12X100_X3)):
         t.set_net(kind, z["weights"])
         ev, pr = t.net_forward(z["states"])
         err[name] = (float(np.max(np.abs(ev - z["value_f64"]))), float(np.max(np.abs(pr - z["policy_f64"]))))
@@ -65,16 +65,21 @@ def test_split_precision_kernels_on_trained_weights(tag):
     print("%s (%s): |err| vs float64 (value, policy): %s" % (tag, z["checkpoint"], err))
     assert err["bf16x6"][0] <= 2 * err["fp32"][0] + 2.4e-7 and err["bf16x6"][1] <= 2 * err["fp32"][1] + 2.4e-7
     assert err["bf16x6"][0] < 2e-5 and err["bf16x6"][1] < 2e-5
+    # two fp16 terms per operand (22 significand bits, three products): float32-class as well -- within three times
+    # the fp32-MFMA kernel's own error, twenty times inside the contract
+    assert err["f16x3"][0] <= 3 * err["fp32"][0] + 2.4e-7 and err["f16x3"][1] <= 3 * err["fp32"][1] + 2.4e-7
+    assert err["f16x3"][0] < 2e-5 and err["f16x3"][1] < 2e-5
 
 
 @pytest.mark.gpu
-def test_generation_with_a_trained_checkpoint_at_bf16x6_replays_on_the_oracle():
+@pytest.mark.parametrize("kind", [NET_MLP12X100_X6, NET_MLP12X100_H3], ids=["bf16x6", "f16x3"])
+def test_generation_with_a_trained_checkpoint_at_bf16x6_replays_on_the_oracle(kind):
     """a trained network plays differently from a random one (sharp priors, solved lines): a fused
     generation driven by the last checkpoint at float32-equivalent precision is replayed move for move"""
     z = load("last")
     G, S_, spe = 32, 120, 16
     f = make_trainer("hip", G, "", 4242, S_, spe, 1.0, 0.25, 0, 1, False, stagger=False)
-    f.set_net(NET_MLP12X100_X6, z["weights"])
+    f.set_net(kind, z["weights"])
     assert f.run()
     o = O.Trainer(G, seed=4242, max_searches=S_, searches_per_eval=spe, num_threads=8)
     o.set_stagger(False)
