@@ -29,9 +29,22 @@ CO_CONST uint32_t CO_GAMMA_BITS[CO_NUM_GAMMA] = CO_GAMMA_BITS_INIT;
   do {                                                            \
     if ((w).prof && (threadIdx.x & 63) == 0) (w).prof[slot] += (v); \
   } while (0)
+/* phases of one simulation (slots 8..13): scan, slot stores, expansion, block fetch of the descent (waited for),
+ * terminal handling, request */
+#define CO_PH(slot)                               \
+  do {                                            \
+    unsigned long long now_ = CO_CLK();           \
+    CO_PROF_ADD(w, slot, now_ - tph_);            \
+    tph_ = now_;                                  \
+  } while (0)
+#define CO_PH_START() unsigned long long tph_ = CO_CLK()
+#define CO_PH_DRAIN() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
 #else
 #define CO_CLK() 0ull
 #define CO_PROF_ADD(w, slot, v) ((void)0)
+#define CO_PH(slot) ((void)0)
+#define CO_PH_START() ((void)0)
+#define CO_PH_DRAIN() ((void)0)
 #endif
 
 struct CoTree {
@@ -536,6 +549,7 @@ CO_DEV void co_root_load(CoTree &t, CoRoot &rc) {
   rc.valid = 1;
 }
 
+
 /* single-lane store of a stat slot, mirrored into the root copy when it is one of the root's edge slots */
 CO_DEV void co_store_slot(uint4 *A, uint32_t slot, uint4 v, CoRoot &rc) {
   const uint32_t idx = slot - rc.e0; /* unsigned: anything outside the root's edges is >= ne */
@@ -574,6 +588,7 @@ CO_DEV void co_search(CoWave &w, CoTree &t, CoRoot &rc) {
     }
   }
   WAVE_SYNC();
+  CO_PH_START();
   while (!co_res_terminal(co_slot_result(cs))) {
     int n = (int)CO_META_NEDGES(h0.z);
     float denom = co_u2f(h1.y);
@@ -621,6 +636,7 @@ CO_DEV void co_search(CoWave &w, CoTree &t, CoRoot &rc) {
         best_slot = WAVE_BCAST(ev, le);
       }
     }
+    CO_PH(8);
     /* ---- visit the current node (virtual loss on every node of the path) */
     cs = co_slot_set_visits(cs, visits + 1);
     cs.y = co_f2u(co_u2f(cs.y) + 1.0f);
@@ -649,6 +665,7 @@ CO_DEV void co_search(CoWave &w, CoTree &t, CoRoot &rc) {
       return;
     }
     uint32_t child_slot = cur + 2u + (uint32_t)best_e;
+    CO_PH(9);
     if (best_slot.x == CO_NONE) {
       /* kNew: expand (Node ctor from parent, node.cpp:31-39) */
       uint64_t board = (uint64_t)h0.x | ((uint64_t)h0.y << 32);
@@ -660,6 +677,7 @@ CO_DEV void co_search(CoWave &w, CoTree &t, CoRoot &rc) {
       unsigned long long te = CO_CLK();
       uint32_t nb = co_create_node(w, t, board, meta, depth, cur, child_slot, &res, &leaf_n, leaf_lm);
       CO_PROF_ADD(w, 3, CO_CLK() - te);
+      CO_PH(10);
       if (nb == CO_NONE) return;
       if (w.analyse) {
         /* Node::countNodes (node.cpp:179-187) without a traversal: word z of unit b + 1 counts the
@@ -690,6 +708,8 @@ CO_DEV void co_search(CoWave &w, CoTree &t, CoRoot &rc) {
     h0 = co_load_unit(A, cur);
     h1 = co_load_unit(A, cur + 1);
     FOR_LANES { L(ev) = A[cur + 2 + lane]; }
+    CO_PH_DRAIN();
+    CO_PH(11);
     ++D;
     FOR_LANES {
       if (lane == 0) {
@@ -718,12 +738,14 @@ CO_DEV void co_search(CoWave &w, CoTree &t, CoRoot &rc) {
     }
     WAVE_SYNC();
     rc.valid = 0;
+    CO_PH(12);
   } else {
     /* trainmc.cpp:684-692: default +1 evaluation, queue the leaf */
     cs.y = co_f2u(1.0f);
     co_store_slot(A, cur_slot, cs, rc);
     uint64_t board = (uint64_t)h0.x | ((uint64_t)h0.y << 32);
     co_request(w, board, h0.z, cur, leaf_n, leaf_lm, D, path_slot);
+    CO_PH(13);
   }
 }
 
@@ -775,6 +797,7 @@ CO_DEV int co_mc_do_iteration(CoWave &w, CoTree &t, const float *eval, const flo
   for (;;) {
     if (!(w.gc.n_pending < w.spe && t.tc.searches_done < w.max_searches)) break;
     if (!rc.valid) co_root_load(t, rc);
+
     if (co_res_known(co_slot_result(rc.cs)) || co_slot_all_visited(rc.cs)) break;
     if (w.gc.error) break;
     unsigned long long t0 = CO_CLK();

@@ -16,7 +16,8 @@ net = sys.argv[3] if len(sys.argv) > 3 else "rescnn4x3"
 G = int(sys.argv[4]) if len(sys.argv) > 4 else 4096
 reps = int(sys.argv[5]) if len(sys.argv) > 5 else 3
 pools = int(sys.argv[6]) if len(sys.argv) > 6 else 1
-kind = {"mlp12x100": NET_MLP12X100, "mlp12x100x3": 4, "rescnn4": NET_RESCNN4, "rescnn4x3": NET_RESCNN4_X3}[net]
+kind = {"mlp12x100": NET_MLP12X100, "mlp12x100x3": 4, "rescnn4": NET_RESCNN4, "rescnn4x3": NET_RESCNN4_X3, "rescnn4h3": 8, "mlp12x100h3": 9,
+        "rescnn4x6": 5, "mlp12x100x6": 6}[net]
 w = nets.init_mlp12x100(0) if net.startswith("mlp12x100") else nets.init_rescnn4(0)
 ts = []
 for path in libs:

@@ -18,7 +18,7 @@ L = _lib.declare(C.CDLL(out))
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 t = Trainer(G, "", 12345, S, 16, 1.0, 0.25, 0, 1, False, stagger=False, _cdll=L)
-t.set_net(1, nets.init_mlp12x100(0))
+t.set_net(9, nets.init_mlp12x100(0))
 t.run()
 st = t.stats()
 p = (C.c_ulonglong * 36)()
@@ -33,7 +33,8 @@ wave_total = int(p[7])
 print("whole wave-step: %.0f cycles avg; clock of game 1's steps: %.0f MHz" % (wave_total / max(steps, 1), 100.0 * int(p[16]) / max(int(p[17]), 1)))
 print("launch avg %.1f us -> %.0f cycles at that clock" % (1e3 * st["mcts_ms"] / st["iterations"], 1e3 * st["mcts_ms"] / st["iterations"] * int(p[16]) / max(int(p[17]), 1) * 100))
 print("max wave-step %d cycles; histogram of wave-step cycles (50k buckets): %s" % (int(p[18]), [int(x) for x in p[20:36]]))
-print('receive phases per leaf (cycles): A %.0f B %.0f C %.0f D %.0f F %.0f G %.0f' % tuple(int(p[i]) / max(nrecv, 1) for i in range(8, 14)))
+print('phases of a simulation (cycles per search): PUCT scans %.0f, slot stores %.0f, expansion %.0f, descent block fetch (waited for) %.0f, '
+      'terminal leaves %.0f, request %.0f' % tuple(int(p[i]) / max(nsearch, 1) for i in range(8, 14)))
 tot = rec + srch + choose
 print("share: receive %.1f%%  search %.1f%%  choose %.1f%%;  stamped cycles per wave-step %.0f" %
       (100 * rec / tot, 100 * srch / tot, 100 * choose / tot, tot / max(steps, 1)))
