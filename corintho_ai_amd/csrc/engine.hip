@@ -88,21 +88,22 @@ struct DevBuf {
 
 /* one independent slice of the games in fused training (run_pools) */
 struct Pool {
-  rt_stream_t st;
-  int lo, n, row_base;
-  bool finished;
-  int idle;
-  int running; /* games of the pool still running at its last poll */
-  rt_event_t ev[2][4];      /* per window parity: start / after search / after cache probe / after network of the TIMED iteration */
-  rt_event_t polled[2];
-  int launched[2];          /* iterations queued in the window of that parity */
-  int word_iter[2];         /* Trainer::searches_done_ of the iteration whose counter word was copied */
-  int first_start;          /* iteration at which the stagger releases the pool's first game (trainer.cpp:184-186) */
-  int timed[2];             /* the window's last iteration carries the events */
-  unsigned long long *word; /* pinned: [parity] counter word copied at the end of window parity 0 / 1, [2 + parity] rows the
+  /* (every handle starts null: a pool whose set-up failed half way is torn down like any other) */
+  rt_stream_t st = {};
+  int lo = 0, n = 0, row_base = 0;
+  bool finished = false;
+  int idle = 0;
+  int running = 0; /* games of the pool still running at its last poll */
+  rt_event_t ev[2][4] = {}; /* per window parity: start / after search / after cache probe / after network of the TIMED iteration */
+  rt_event_t polled[2] = {};
+  int launched[2] = {0, 0};  /* iterations queued in the window of that parity */
+  int word_iter[2] = {0, 0}; /* Trainer::searches_done_ of the iteration whose counter word was copied */
+  int first_start = 0;       /* iteration at which the stagger releases the pool's first game (trainer.cpp:184-186) */
+  int timed[2] = {0, 0};     /* the window's last iteration carries the events */
+  unsigned long long *word = nullptr; /* pinned: [parity] counter word copied at the end of window parity 0 / 1, [2 + parity] rows the
                              * network evaluated in that iteration (evaluation cache) */
   /* evaluation cache of the pool (EvalCache) */
-  EvalCache cache;
+  EvalCache cache = {};
   uint32_t *c_hdr = nullptr, *c_count = nullptr;
   float *c_val = nullptr;
   uint4 *c_keys = nullptr;
@@ -118,7 +119,7 @@ struct ca_trainer {
   int R = 0;          /* slots of the pool = games resident at a time; R < G: slots are recycled (EngineParams::results) */
   bool recycle = false;
   uint32_t cap_units = 0;
-  rt_stream_t stream;
+  rt_stream_t stream = {};
   EngineParams P;
   DevBuf<GameCtl> games;
   DevBuf<TreeCtl> trees;
@@ -881,7 +882,12 @@ struct ca_trainer {
           while (n < want) n <<= 1;
           const size_t per = 16 + CO_CACHE_VAL_FLOATS * 4;
           while (n > 1024 && n * per > rt_mem_free() / 12) n >>= 1;
-          if (cfg.eval_cache > 0) n = (size_t)1 << (cfg.eval_cache < 6 ? 6 : cfg.eval_cache > 30 ? 30 : cfg.eval_cache); /* given */
+          if (cfg.eval_cache > 0) { /* given */
+            n = (size_t)1 << (cfg.eval_cache < 6 ? 6 : cfg.eval_cache > 30 ? 30 : cfg.eval_cache);
+            if (n * per > rt_mem_free() / 2)
+              throw EngineError(CA_ERR_ARG, "ca_config.eval_cache: a table of 2^" + std::to_string(cfg.eval_cache) +
+                                                " entries per pool does not fit in the free device memory");
+          }
           q.c_entries = n;
           const size_t rows = (size_t)q.n * spe;
           rt_malloc((void **)&q.c_hdr, n * 16, q.st);

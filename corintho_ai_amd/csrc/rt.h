@@ -92,9 +92,13 @@ inline void rt_memset(void *d, int v, size_t n, rt_stream_t s) {
 }
 inline void rt_sync(rt_stream_t s) { RT_CHECK(hipStreamSynchronize(s)); }
 inline void rt_stream_create(rt_stream_t *s) { RT_CHECK(hipStreamCreateWithFlags(s, hipStreamNonBlocking)); }
-inline void rt_stream_destroy(rt_stream_t s) { (void)hipStreamDestroy(s); }
+inline void rt_stream_destroy(rt_stream_t s) {
+  if (s) (void)hipStreamDestroy(s);
+}
 inline void rt_event_create(rt_event_t *e) { RT_CHECK(hipEventCreate(e)); }
-inline void rt_event_destroy(rt_event_t e) { (void)hipEventDestroy(e); }
+inline void rt_event_destroy(rt_event_t e) {
+  if (e) (void)hipEventDestroy(e);
+}
 inline void rt_event_record(rt_event_t e, rt_stream_t s) { RT_CHECK(hipEventRecord(e, s)); }
 inline void rt_event_sync(rt_event_t e) { RT_CHECK(hipEventSynchronize(e)); }
 inline float rt_event_elapsed_ms(rt_event_t a, rt_event_t b) {
