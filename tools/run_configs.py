@@ -11,10 +11,11 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from corintho_ai_amd import NET_MLP12X100, NET_RESCNN4_X3, NET_RESCNN4_X6, Tourney, Trainer, nets  # noqa: E402
+from corintho_ai_amd import NET_MLP12X100, NET_RESCNN4_H3, NET_RESCNN4_X3, NET_RESCNN4_X6, Tourney, Trainer, nets  # noqa: E402
 
 which = sys.argv[1:] or ["cfg1", "cfg4", "cfg5", "tourney", "compat"]
-net_kind, net_name = (NET_RESCNN4_X3, "rescnn4x3") if "x3" in which else (NET_RESCNN4_X6, "rescnn4x6")
+net_kind, net_name = ((NET_RESCNN4_X3, "rescnn4x3") if "x3" in which else (NET_RESCNN4_X6, "rescnn4x6") if "x6" in which
+                      else (NET_RESCNN4_H3, "rescnn4h3"))
 w0, w1 = nets.init_rescnn4(0), nets.init_rescnn4(1)
 
 
