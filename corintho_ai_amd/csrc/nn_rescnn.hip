@@ -832,7 +832,16 @@ __global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_x3_small(Rc3Params
  * subnormal quantum 6e-8): remainders of small values lose relative, not absolute, accuracy -- measured against
  * float64 in tests/test_net_precision.py. */
 __global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_h3(Rc3Params Q) { rcs_forward<2, 2, 8, true>(Q); }
-__global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_h3_small(Rc3Params Q) { rcs_forward<1, 2, 8, true>(Q); }
+/* (_small, batches up to RC3_SMALL_ROWS rows; up to RC6_THIN_ROWS of them on the four-wave path described at
+ * co_k_rescnn_forward_x6 below: one wave per SIMD, 8 positions per workgroup, waves 4..7 leave at once) */
+__global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_h3_small(Rc3Params Q) {
+  if (*Q.base.d_rows <= RC6_THIN_ROWS) {
+    if (threadIdx.x >= 256) return;
+    rcs_forward<1, 2, 4, true>(Q);
+  } else {
+    rcs_forward<1, 2, 8, true>(Q);
+  }
+}
 /* (Capping this kernel at 168 registers so that a wave of the search kernel fits beside two of its waves on a SIMD was
  * measured: the network kernel alone 5 % slower, the generation 4 % slower -- the kernel trace shows 81 % of the search
  * kernel's time overlapping the other pool's network launches already, tools/overlap.py.) */
@@ -1099,7 +1108,10 @@ struct ResCnnSplitNet : ResCnnNet {
       /* both kernels are queued; the row count on the device decides which one works (the other's
        * workgroups return at once).  Batches that can exceed RC3_SMALL_ROWS need the throughput kernel. */
       const int small_rows = rows_cap < RC3_SMALL_ROWS ? rows_cap : RC3_SMALL_ROWS;
-      hipLaunchKernelGGL(f16 ? co_k_rescnn_forward_h3_small : co_k_rescnn_forward_x3_small, dim3((small_rows + 15) / 16), dim3(512),
+      /* enough workgroups for either path of the f16 kernel: 16 positions each, or 8 on its thin path (<= RC6_THIN_ROWS rows) */
+      const int thin_rows = rows_cap < RC6_THIN_ROWS ? rows_cap : RC6_THIN_ROWS;
+      const int small_grid = f16 && (thin_rows + 7) / 8 > (small_rows + 15) / 16 ? (thin_rows + 7) / 8 : (small_rows + 15) / 16;
+      hipLaunchKernelGGL(f16 ? co_k_rescnn_forward_h3_small : co_k_rescnn_forward_x3_small, dim3(small_grid), dim3(512),
                          RCS_LDS_WORDS(2, 1) * 4, s, q);
       if (rows_cap > RC3_SMALL_ROWS)
         hipLaunchKernelGGL(f16 ? co_k_rescnn_forward_h3 : co_k_rescnn_forward_x3, dim3((rows_cap + 31) / 32), dim3(512),
