@@ -970,6 +970,11 @@ typedef struct {
   int trace_on;
   int32_t *trace;
   int n_trace, cap_trace;
+  /* per-game text log (selfplayer.h:99-102): the file, and whether writeEval has switched the stream to
+   * std::fixed << std::setprecision(6) yet -- the manipulators stick to the stream, so every float written
+   * afterwards, also the ones printed with plain operator<<, comes out in that format */
+  FILE *log;
+  int log_fixed;
 } selfplayer_t;
 
 static void sp_init(selfplayer_t *sp, uint32_t seed, int max_searches, int spe, float c_puct, float epsilon,
@@ -985,6 +990,7 @@ static void sp_init(selfplayer_t *sp, uint32_t seed, int max_searches, int spe, 
 }
 
 static void sp_free(selfplayer_t *sp) {
+  if (sp->log) fclose(sp->log);
   mc_free(&sp->players[0]);
   mc_free(&sp->players[1]);
   free(sp->to_eval);
@@ -1025,11 +1031,174 @@ static void trace_root(selfplayer_t *sp) {
   }
 }
 
+/* ---- per-game text logs: selfplayer.cpp:124-204, node.cpp:197-254, game.cpp:98-139, move.cpp:56-78, util.cpp:5-25.
+ * A C++ ostream prints a float with operator<< as printf's %g would (precision 6) until a manipulator changes
+ * the stream; writeEval's std::fixed << std::setprecision(6) does, for good. */
+static void log_float(selfplayer_t *sp, float v) { fprintf(sp->log, sp->log_fixed ? "%.6f" : "%g", (double)v); }
+
+static const char *str_result(int r) { /* util.cpp:5-25 */
+  switch (r) {
+    case kResultLoss: return "L";
+    case kResultDraw: return "D";
+    case kResultWin: return "W";
+    case kDeducedLoss: return "DL";
+    case kDeducedDraw: return "DD";
+    case kDeducedWin: return "DW";
+    default: return "N";
+  }
+}
+
+static void log_move(FILE *f, int id) { /* move.cpp:56-78 */
+  move_t m = decode_move(id);
+  if (m.is_place) {
+    fprintf(f, "%c%c%d", m.piece == 0 ? 'B' : m.piece == 1 ? 'C' : 'A', 'a' + m.c1, 4 - m.r1);
+  } else {
+    char d = m.c1 < m.c0 ? 'L' : m.c1 > m.c0 ? 'R' : m.r1 < m.r0 ? 'U' : 'D';
+    fprintf(f, "%c%d%c", 'a' + m.c0, 4 - m.r0, d);
+  }
+}
+
+static void log_game(FILE *f, const game_t *g) { /* game.cpp:98-139 */
+  for (int row = 0; row < 4; ++row) {
+    for (int col = 0; col < 4; ++col) {
+      fputc(g_board(g, row, col, 0) ? 'B' : ' ', f);
+      fputc(g_board(g, row, col, 1) ? 'C' : ' ', f);
+      fputc(g_board(g, row, col, 2) ? 'A' : ' ', f);
+      fputc(g_board(g, row, col, 3) ? '#' : ' ', f);
+      if (col < 3) fputc('|', f);
+    }
+    if (row < 3) fputs("\n-------------------\n", f);
+  }
+  fputc('\n', f);
+  for (int player = 0; player < 2; ++player)
+    fprintf(f, "Player %d: B: %d C: %d A: %d\n", player + 1, (int)g->pieces[player * 3 + 0], (int)g->pieces[player * 3 + 1],
+            (int)g->pieces[player * 3 + 2]);
+  fprintf(f, "Player %d to play", g->to_play + 1);
+}
+
+/* selfplayer.cpp:124-134 */
+static void log_eval(selfplayer_t *sp, const node_t *n) {
+  if (n->result != kResultNone) {
+    fputs(str_result(n->result), sp->log);
+    return;
+  }
+  sp->log_fixed = 1;
+  log_float(sp, n->evaluation / (float)n->visits);
+}
+
+/* node.cpp:197-240: the line of most-visited children (a lost child ends the choice at once) */
+static void log_main_line(selfplayer_t *sp, const node_t *n) {
+  const node_t *cur = n->first_child, *best = NULL;
+  int max_visits = 0, edge_index = 0;
+  float max_eval = 0.0f, prob = 0.0f;
+  while (cur != NULL) {
+    if (n_move_id(n, edge_index) == cur->child_id) {
+      if (cur->result == kDeducedLoss || cur->result == kResultLoss) {
+        best = cur;
+        max_visits = cur->visits;
+        prob = n_probability(n, edge_index);
+        break;
+      }
+      if (cur->visits > max_visits || (cur->visits == max_visits && cur->evaluation > max_eval)) {
+        best = cur;
+        max_visits = cur->visits;
+        max_eval = cur->evaluation;
+        prob = n_probability(n, edge_index);
+      }
+      cur = cur->next_sibling;
+    }
+    ++edge_index;
+  }
+  if (best != NULL) {
+    fprintf(sp->log, "%d. ", (int)best->depth);
+    log_move(sp->log, best->child_id);
+    fprintf(sp->log, " V: %d E: ", max_visits);
+    if (best->result != kResultNone) fputs(str_result(best->result), sp->log);
+    else log_float(sp, max_eval / (float)max_visits);
+    fputs(" p: ", sp->log);
+    log_float(sp, prob);
+    fputc('\t', sp->log);
+    log_main_line(sp, best);
+  }
+}
+
+typedef struct {
+  int visits;
+  float evaluation, probability;
+  int move;
+  const node_t *node;
+} log_move_data;
+
+static int log_move_cmp(const void *pa, const void *pb) { /* selfplayer.cpp:164-173 */
+  const log_move_data *a = (const log_move_data *)pa, *b = (const log_move_data *)pb;
+  if (a->visits != b->visits) return a->visits > b->visits ? -1 : 1;
+  if (a->evaluation != b->evaluation) return a->evaluation > b->evaluation ? -1 : 1;
+  if (a->probability != b->probability) return a->probability > b->probability ? -1 : 1;
+  return a->move < b->move ? -1 : a->move > b->move ? 1 : 0;
+}
+
+/* selfplayer.cpp:136-183 */
+static void log_moves(selfplayer_t *sp) {
+  const node_t *root = sp->players[sp->to_play].root;
+  fputs("LEGAL MOVES:\n", sp->log);
+  log_main_line(sp, root);
+  fputc('\n', sp->log);
+  log_move_data moves[CO_NUM_MOVES];
+  int n = 0, edge_index = 0;
+  for (const node_t *cur = root->first_child; cur != NULL;) {
+    if (cur->child_id == n_move_id(root, edge_index)) {
+      moves[n].visits = cur->visits;
+      moves[n].evaluation = cur->evaluation / (float)cur->visits;
+      moves[n].probability = n_probability(root, edge_index);
+      moves[n].move = cur->child_id;
+      moves[n].node = cur;
+      ++n;
+      cur = cur->next_sibling;
+    }
+    ++edge_index;
+  }
+  qsort(moves, (size_t)n, sizeof moves[0], log_move_cmp); /* (a total order: std::sort gives the same sequence) */
+  for (int i = 1; i < n; ++i) { /* the first one is in the main line already */
+    log_move(sp->log, moves[i].move);
+    fprintf(sp->log, " V: %d E: ", moves[i].visits);
+    log_eval(sp, moves[i].node);
+    fputs(" P: ", sp->log);
+    log_float(sp, moves[i].probability);
+    fputc('\t', sp->log);
+  }
+  fputc('\n', sp->log);
+}
+
+/* selfplayer.cpp:185-197 */
+static void log_pre_move(selfplayer_t *sp) {
+  const node_t *root = sp->players[sp->to_play].root;
+  fprintf(sp->log, "TURN %d\nPLAYER %d TO PLAY\nVISITS: %d\n", (int)root->depth, sp->to_play + 1, (int)root->visits);
+  fputs("POSITION EVALUATION: ", sp->log);
+  log_eval(sp, root);
+  fputc('\n', sp->log);
+  log_moves(sp);
+}
+
+/* selfplayer.cpp:199-204 */
+static void log_move_choice(selfplayer_t *sp, int choice) {
+  fputs("CHOSE MOVE ", sp->log);
+  log_move(sp->log, choice);
+  fputs("\nNEW POSITION:\n", sp->log);
+  log_game(sp->log, &sp->players[sp->to_play].root->game);
+  fputs("\n\n", sp->log);
+}
+
 /* ref: selfplayer.cpp:206-232 */
 static void sp_end_game(selfplayer_t *sp) {
   if (sp->players[sp->to_play].root->result == kResultDraw) sp->result = kResultDraw;
   else if (sp->to_play == 1) sp->result = kResultLoss;
   else sp->result = kResultWin;
+  if (sp->log) {
+    if (sp->result == kResultDraw) fputs("GAME IS DRAWN.\n", sp->log);
+    else fprintf(sp->log, "PLAYER %d WON!\n", sp->to_play + 1);
+    fclose(sp->log);
+    sp->log = NULL;
+  }
   mc_null_root(&sp->players[0]);
   mc_null_root(&sp->players[1]);
   free(sp->to_eval);
@@ -1060,8 +1229,10 @@ static int sp_choose_move(selfplayer_t *sp) {
 static int sp_choose_move_and_continue(selfplayer_t *sp) {
   int need_eval = 0;
   while (!need_eval) {
+    if (sp->log) log_pre_move(sp);
     if (n_known(sp->players[sp->to_play].root) && sp->mate_turn == 0) sp->mate_turn = sp->n_samples + 1;
     int choice = sp_choose_move(sp);
+    if (sp->log) log_move_choice(sp, choice);
     if (n_terminal(sp->players[sp->to_play].root)) {
       sp_end_game(sp);
       return 1;
@@ -1161,6 +1332,22 @@ co_trainer *co_trainer_create_slice(int total_games, int first, int num_games, i
     sp_init(&t->games[i], mt_next(&t->generator), max_searches, searches_per_eval, c_puct, epsilon, testing,
             (first + i) % 2);
   return t;
+}
+
+/* ref: trainer.cpp:243-250: the first num_logged games write `<log_folder>/game_<i>.txt` (a file that cannot be
+ * opened is no error there either: an unopened ofstream swallows its output).  Call before the first iteration;
+ * returns the number of files opened. */
+int co_trainer_set_logging(co_trainer *t, const char *log_folder, int num_logged) {
+  int opened = 0;
+  if (t->searches_done > 0 || num_logged < 0 || num_logged > t->num_games) return -1;
+  for (int i = 0; i < num_logged; ++i) {
+    char path[4096];
+    snprintf(path, sizeof path, "%s/game_%d.txt", log_folder, t->game_base + i);
+    t->games[i].log = fopen(path, "w");
+    t->games[i].log_fixed = 0;
+    opened += t->games[i].log != NULL;
+  }
+  return opened;
 }
 
 void co_trainer_destroy(co_trainer *t) {

@@ -69,6 +69,8 @@ co_trainer *co_trainer_create(int num_games, int seed, int max_searches,
  * slice the multi-GPU tests replay a shard on */
 co_trainer *co_trainer_create_slice(int total_games, int first, int num_games, int seed, int max_searches,
                                     int searches_per_eval, float c_puct, float epsilon, int num_threads, int testing);
+/* per-game text logs of the first num_logged games, as Trainer::initialize sets them up (trainer.cpp:243-250) */
+int co_trainer_set_logging(co_trainer *t, const char *log_folder, int num_logged);
 void co_trainer_destroy(co_trainer *t);
 int co_trainer_num_requests(const co_trainer *t, int to_play);
 int co_trainer_num_samples(const co_trainer *t);

@@ -83,6 +83,8 @@ def lib():
         fn.argtypes = [C.c_void_p, C.c_int]
         fn.restype = C.c_int
     L.co_trainer_enable_trace.argtypes = [C.c_void_p, C.c_int]
+    L.co_trainer_set_logging.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    L.co_trainer_set_logging.restype = C.c_int
     L.co_trainer_trace.argtypes = [C.c_void_p, C.c_int, i32p, C.c_int]
     L.co_trainer_trace.restype = C.c_int
     L.co_trainer_counters.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
@@ -250,6 +252,8 @@ class Trainer:
                                                 searches_per_eval, c_puct, epsilon, num_threads, int(bool(testing)))
         if not self._t:
             raise ValueError("bad Trainer arguments")
+        if num_logged:  # the reference's constructor arguments: the first num_logged games write <log_folder>/game_<i>.txt
+            self.set_logging(log_folder, min(num_logged, num_games))
 
     def __del__(self):
         try:
@@ -258,6 +262,13 @@ class Trainer:
                 self._t = None
         except Exception:
             pass
+
+    def set_logging(self, log_folder, num_logged):
+        """per-game text logs of the first num_logged games (trainer.cpp:243-250); -> files opened"""
+        n = lib().co_trainer_set_logging(self._t, str(log_folder).encode(), int(num_logged))
+        if n < 0:
+            raise ValueError("set_logging: before the first iteration, 0 <= num_logged <= num_games")
+        return n
 
     def set_stagger(self, on):
         lib().co_trainer_set_stagger(self._t, int(on))

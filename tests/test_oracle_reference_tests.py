@@ -3,6 +3,8 @@
  * the property sweeps of selfplayer_test.cpp / trainer_test.cpp,
  * the reference probe counts recorded in BASELINE.md section 2 (outputs of the
    compiled reference: host iterations, leaf evaluations, plies)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -118,3 +120,52 @@ def test_reference_probe_counts(cfg, want):
     # printed as an integer there (634 / 5 291 / 5 535: rounding not stated)
     assert want[1] in (int(total[0] / G), round(total[0] / G))
     assert round(t.num_samples() / G, 1) == want[2]
+
+
+def test_per_game_text_logs(tmp_path):
+    """Trainer(num_games, log_folder, ..., num_logged): the first num_logged games write `game_<i>.txt`
+    (trainer.cpp:243-250; selfplayer.cpp:124-204, node.cpp:197-254, game.cpp:98-139, move.cpp:56-78).  The reference
+    holds no log to compare with (its tests only pass the arguments, trainer_test.cpp:28-30), so the restatement is
+    checked against the game it describes: one TURN block per ply, the chosen moves and the side to move of the
+    trace, the position after every move, the result line; and C++'s sticky stream format (plain `<<` floats turn
+    to six fixed decimals once writeEval has run)."""
+    import re
+
+    G, S_, spe, logged = 4, 60, 8, 3
+    o = O.Trainer(G, str(tmp_path), 11, S_, spe, 1.0, 0.25, logged, 2, False)
+    o.enable_trace()
+    o.set_stagger(False)
+    H.play_generation(o, G, spe, H.hash_net)
+    assert sorted(os.listdir(tmp_path)) == ["game_%d.txt" % i for i in range(logged)]
+    for g in range(logged):
+        txt = (tmp_path / ("game_%d.txt" % g)).read_text()
+        turns = re.findall(r"^TURN (\d+)\nPLAYER (\d) TO PLAY\nVISITS: (\d+)\nPOSITION EVALUATION: (\S+)\nLEGAL MOVES:$", txt, re.M)
+        chosen = re.findall(r"^CHOSE MOVE (\S+)\nNEW POSITION:$", txt, re.M)
+        # the trace: per ply {to_play, depth, visits, result, eval bits, n children, 5 words per child, chosen move}
+        tr = o.trace(g)
+        i, plies = 0, []
+        while i < len(tr):
+            n = int(tr[i + 5])
+            plies.append((int(tr[i]), int(tr[i + 1]), int(tr[i + 2]), int(tr[i + 6 + 5 * n])))
+            i += 7 + 5 * n
+        assert len(turns) == len(chosen) == len(plies) == o.game_num_samples(g)
+        game = O.Game()
+        boards = re.findall(r"NEW POSITION:\n((?:.*\n){7})Player 1: B: (\d) C: (\d) A: (\d)\nPlayer 2: B: (\d) C: (\d) A: (\d)\nPlayer (\d) to play", txt)
+        for k, ((turn, player, visits, ev), mv, (tp, depth, vis, move)) in enumerate(zip(turns, chosen, plies)):
+            assert (int(turn), int(player) - 1, int(visits)) == (depth, tp, vis)
+            assert mv == O.move_str(move)
+            assert re.fullmatch(r"-?\d+\.\d{6}|N|L|D|W|DL|DD|DW", ev)
+            game.do_move(move)
+            rows = boards[k][0].split("\n")
+            for r in range(4):
+                cells = rows[2 * r].split("|")
+                for c in range(4):
+                    want = "".join(ch if (game.board >> (r * 16 + c * 4 + b)) & 1 else " " for b, ch in enumerate("BCA#"))
+                    assert cells[c] == want
+            assert tuple(int(x) for x in boards[k][1:7]) == tuple(game.pieces) and int(boards[k][7]) - 1 == game.to_play
+        res = o.game_result(g)
+        last = txt.strip().split("\n")[-1]
+        assert last == ("GAME IS DRAWN." if res == 2 else "PLAYER %d WON!" % (plies[-1][0] + 1))
+        # every float of the file has six decimals once the first evaluation was written in fixed format
+        floats = re.findall(r"(?:E|p|P): (-?[\d.]+(?:e-?\d+)?)", txt)
+        assert floats and all(re.fullmatch(r"-?\d+\.\d{6}", f) for f in floats)
