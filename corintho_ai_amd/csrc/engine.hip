@@ -106,8 +106,7 @@ struct Pool {
   EvalCache cache = {};
   uint32_t *c_hdr = nullptr, *c_count = nullptr;
   float *c_val = nullptr;
-  uint4 *c_keys = nullptr;
-  int32_t *c_owner = nullptr, *c_in_idx = nullptr, *c_out_idx = nullptr;
+  int32_t *c_in_idx = nullptr, *c_out_idx = nullptr;
   unsigned long long *c_totals = nullptr;
   size_t c_entries = 0;
   double c_inserted_est = 0; /* entries taken since the table was last emptied (estimate: timed iteration x window) */
@@ -188,7 +187,7 @@ struct ca_trainer {
         rt_event_destroy(q.polled[w]);
       }
       rt_host_free(q.word);
-      for (void *b : {(void *)q.c_hdr, (void *)q.c_count, (void *)q.c_val, (void *)q.c_keys, (void *)q.c_owner, (void *)q.c_in_idx,
+      for (void *b : {(void *)q.c_hdr, (void *)q.c_count, (void *)q.c_val, (void *)q.c_in_idx,
                       (void *)q.c_out_idx, (void *)q.c_totals})
         rt_free(b);
       rt_stream_destroy(q.st);
@@ -539,7 +538,7 @@ struct ca_trainer {
     P.to_play = to_play;
     P.iteration = trainer_iteration;
     RT_LAUNCH(co_k_priors, ((R) * P.searches_per_eval + CO_WAVES_PER_BLOCK - 1) / CO_WAVES_PER_BLOCK, CO_WAVE * CO_WAVES_PER_BLOCK, stream, P);
-    RT_LAUNCH(co_k_mcts_step, R, CO_WAVE, stream, P);
+    RT_LAUNCH(co_k_mcts_step, ((R) + CO_K3_WAVES - 1) / CO_K3_WAVES, CO_WAVE * CO_K3_WAVES, stream, P);
     if (to_play == -1) ++trainer_iteration;
     ++iterations;
     ++mcts_launches;
@@ -589,7 +588,7 @@ struct ca_trainer {
     }
     P.iteration = trainer_iteration;
     RT_LAUNCH(co_k_priors, ((R) * P.searches_per_eval + CO_WAVES_PER_BLOCK - 1) / CO_WAVES_PER_BLOCK, CO_WAVE * CO_WAVES_PER_BLOCK, stream, P);
-    RT_LAUNCH(co_k_mcts_step, R, CO_WAVE, stream, P);
+    RT_LAUNCH(co_k_mcts_step, ((R) + CO_K3_WAVES - 1) / CO_K3_WAVES, CO_WAVE * CO_K3_WAVES, stream, P);
     ++iterations;
     ++mcts_launches;
     scan_valid = false;
@@ -809,7 +808,7 @@ struct ca_trainer {
     P.to_play = -1;
     P.iteration = trainer_iteration;
     P.force_choose = 1;
-    RT_LAUNCH(co_k_mcts_step, R, CO_WAVE, stream, P);
+    RT_LAUNCH(co_k_mcts_step, ((R) + CO_K3_WAVES - 1) / CO_K3_WAVES, CO_WAVE * CO_K3_WAVES, stream, P);
     P.force_choose = 0;
     ++mcts_launches;
     scan_valid = false;
@@ -892,8 +891,6 @@ struct ca_trainer {
           const size_t rows = (size_t)q.n * spe;
           rt_malloc((void **)&q.c_hdr, n * 16, q.st);
           rt_malloc((void **)&q.c_val, (n + rows) * CO_CACHE_VAL_FLOATS * 4, q.st); /* table values + one scratch element per row */
-          rt_malloc((void **)&q.c_keys, rows * 16, q.st);
-          rt_malloc((void **)&q.c_owner, rows * 4, q.st);
           rt_malloc((void **)&q.c_in_idx, rows * 4, q.st);
           rt_malloc((void **)&q.c_out_idx, rows * 4, q.st);
           rt_malloc((void **)&q.c_count, 32, q.st);
@@ -901,8 +898,6 @@ struct ca_trainer {
           q.cache.hdr = q.c_hdr;
           q.cache.val = q.c_val;
           q.cache.mask = (uint32_t)(n - 1);
-          q.cache.keys = q.c_keys;
-          q.cache.owner = q.c_owner;
           q.cache.in_idx = q.c_in_idx;
           q.cache.out_idx = q.c_out_idx;
           q.cache.count = q.c_count;
@@ -1005,13 +1000,12 @@ struct ca_trainer {
         rt_event_t *e = q.ev[parity];
         if (timed) rt_event_record(e[0], q.st);
         RT_LAUNCH(co_k_priors, ((q.n) * pp.searches_per_eval + CO_WAVES_PER_BLOCK - 1) / CO_WAVES_PER_BLOCK, CO_WAVE * CO_WAVES_PER_BLOCK, q.st, pp);
-        RT_LAUNCH(co_k_mcts_step, q.n, CO_WAVE, q.st, pp);
+        RT_LAUNCH(co_k_mcts_step, ((q.n) + CO_K3_WAVES - 1) / CO_K3_WAVES, CO_WAVE * CO_K3_WAVES, q.st, pp);
         if (timed) rt_event_record(e[1], q.st);
         if (q.cache.hdr) {
-          /* every request row is resolved to an element of the cache's value array; the network evaluates the rows
-           * whose position has no entry yet, reading them through in_idx and writing straight to out_idx */
-          const int row_blocks = (q.n * spe + CO_WAVE * CO_WAVES_PER_BLOCK - 1) / (CO_WAVE * CO_WAVES_PER_BLOCK);
-          RT_LAUNCH(co_k_cache_probe, row_blocks, CO_WAVE * CO_WAVES_PER_BLOCK, q.st, pp);
+          /* the search kernel has resolved every request row to an element of the cache's value array; the network
+           * evaluates the rows whose position has no entry yet, reading them through in_idx and writing straight to
+           * out_idx */
           if (timed) rt_event_record(e[2], q.st);
           CoNetIO io;
           io.in_idx = q.c_in_idx;
@@ -1130,7 +1124,7 @@ struct ca_trainer {
       RT_LAUNCH(co_k_scan, 1, CO_WAVE, stream, P); /* offsets at entry (trainer.cpp:208-215) */
       if (timed) rt_event_record(ev[0], stream);
       RT_LAUNCH(co_k_priors, ((R) * P.searches_per_eval + CO_WAVES_PER_BLOCK - 1) / CO_WAVES_PER_BLOCK, CO_WAVE * CO_WAVES_PER_BLOCK, stream, P);
-      RT_LAUNCH(co_k_mcts_step, R, CO_WAVE, stream, P);
+      RT_LAUNCH(co_k_mcts_step, ((R) + CO_K3_WAVES - 1) / CO_K3_WAVES, CO_WAVE * CO_K3_WAVES, stream, P);
       if (timed) rt_event_record(ev[1], stream);
       P.scan_phase = 1;
       RT_LAUNCH(co_k_scan, 1, CO_WAVE, stream, P);
@@ -1318,7 +1312,7 @@ struct ca_tourney {
           ++p.nn_launches;
         }
         RT_LAUNCH(co_k_priors, ((p.G) * p.P.searches_per_eval + CO_WAVES_PER_BLOCK - 1) / CO_WAVES_PER_BLOCK, CO_WAVE * CO_WAVES_PER_BLOCK, p.stream, p.P);
-        RT_LAUNCH(co_k_mcts_step, p.G, CO_WAVE, p.stream, p.P);
+        RT_LAUNCH(co_k_mcts_step, ((p.G) + CO_K3_WAVES - 1) / CO_K3_WAVES, CO_WAVE * CO_K3_WAVES, p.stream, p.P);
         ++p.mcts_launches;
         ++p.iterations;
       }

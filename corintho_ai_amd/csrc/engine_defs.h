@@ -99,7 +99,7 @@ struct TreeCtl {
   uint32_t peak_units;
 };
 
-/* Evaluation cache of a pool in fused training (kernels.h co_k_cache_probe): a network's outputs are a function of
+/* Evaluation cache of a pool in fused training (mcts.h co_cache_resolve): a network's outputs are a function of
  * the request row alone, and a generation asks for the same positions again and again (the two players' trees of a
  * game overlap, thousands of games leave the same opening: 29 % of the rows of a 4096-game generation with
  * random-init weights, 44 % with a trained checkpoint, tools/exp/dup_rows.py).  The outputs of every evaluated row
@@ -114,8 +114,6 @@ struct EvalCache {
   uint32_t *hdr;       /* [mask + 1][4]; null = no cache */
   float *val;          /* [mask + 1 + pool rows][CO_CACHE_VAL_FLOATS] */
   uint32_t mask;
-  uint4 *keys;         /* [pool rows] {board lo, board hi, reserves (mover's first) | 1 << 31, 0} of the request rows, by K3 */
-  int32_t *owner;      /* [pool rows] (slot of the pool's game) * spe + k of request row r, by K3: where its element goes */
   int32_t *in_idx;     /* [pool rows] request rows the network evaluates this iteration, compact ... */
   int32_t *out_idx;    /* ... and the element of val each one writes */
   uint32_t *count;     /* [2][4] by iteration parity: {rows to evaluate, 0, 0, 0} */
@@ -164,8 +162,8 @@ struct EngineParams {
   int32_t *pend_depth;  /* [G][spe] */
   uint32_t *pend_path;  /* [G][spe][CO_PATH_MAX] */
   uint4 *pend_key;      /* [G][spe] cache keys of the pending leaves' request rows (fused training with the evaluation cache) */
-  int32_t *pend_src;    /* [G][spe] element of the cache's value array that holds the outputs of pending leaf k (by K8): K2b
-                         * and K3 fetch it with the leaf's other words, not behind the row number */
+  int32_t *pend_src;    /* [G][spe] element of the cache's value array that holds the outputs of pending leaf k (resolved at
+                         * the end of the step that queued the leaf): K2b and K3 fetch it with the leaf's other words */
   uint32_t *pend_n;     /* [G][spe][4] {(first noise word of the leaf << 8) | legal moves of the leaf, legal-move mask [3]}:
                          * everything co_k_priors needs to fetch the leaf's priors without walking the tree first */
   uint32_t *noise_raw;  /* [G][spe * CO_NUM_MOVES] generator outputs (untempered state words) reserved for the pending

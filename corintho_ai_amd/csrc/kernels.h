@@ -12,9 +12,18 @@
 CO_CONST int32_t CO_SPACE_SYM[8][16] = CO_SPACE_SYM_INIT;
 CO_CONST int32_t CO_MOVE_SYM[8][96] = CO_MOVE_SYM_INIT;
 
+#ifdef CO_EMU
+#define CO_K3_WAVES 1
+#define CO_K3_WAVE_IN_BLOCK 0
+#else
+#define CO_K3_WAVES CO_K3_WPB
+/* wave-uniform by construction: tell the compiler, or the game index and everything derived from it live in vector registers */
+#define CO_K3_WAVE_IN_BLOCK (CO_K3_WPB > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0)
+#endif
 CO_KERNEL co_k_mcts_step(EngineParams P) {
-  int g = P.pool_lo + CO_BLOCK_IDX;
-  if (CO_BLOCK_IDX < P.pool_n && g < P.num_games) co_mcts_step_wave(P, g);
+  const int i = CO_BLOCK_IDX * CO_K3_WAVES + CO_K3_WAVE_IN_BLOCK;
+  const int g = P.pool_lo + i;
+  if (i < P.pool_n && g < P.num_games) co_mcts_step_wave(P, g);
 }
 
 /* K2b: the priors of every pending leaf whose evaluation this launch consumes -- one wavefront per
@@ -39,102 +48,6 @@ CO_KERNEL co_k_priors(EngineParams P) {
   const float *row_probs = P.cache.hdr ? P.cache.val + (size_t)src * CO_CACHE_VAL_FLOATS + 4 : P.nn_probs + (size_t)row * CO_NUM_MOVES;
   co_prior_leaf(A, leaf, (int)(pn.x & 255u), pn.y, pn.z, pn.w, row_probs,
                 P.noise_raw + (size_t)g * spe * CO_NUM_MOVES + (pn.x >> 8), eps);
-}
-
-/* ---- evaluation cache (engine_defs.h EvalCache), fused training.  Between the search kernel and the network:
- * co_k_cache_probe resolves every request row of the iteration's batch to an element of `val`, ONE LANE per row:
- *   the position has an entry (evaluated in an earlier iteration, or claimed by another row of this batch, whose
- *   outputs this iteration's network launch writes)          -> that entry;
- *   no entry, an empty slot in the probe window               -> the lane claims it, the row is evaluated into it;
- *   neither (the window is full)                              -> the row is evaluated into its scratch element.
- * Rows to evaluate are numbered with one atomic per wavefront.  Correctness does not depend on who wins a race:
- * every path resolves a row to the network kernel's outputs for exactly its position (rows are evaluated
- * independently of their batch; keys are compared in full; an entry is never moved or reused before the
- * table is emptied as a whole, between two iterations).  Header words are accessed with relaxed device-scope
- * atomics only: the XCDs' L2s are not coherent with each other within a launch, and an acquire / release would
- * invalidate / write back a whole L2 per wave. */
-CO_DEV uint32_t co_cache_hash(uint32_t k0, uint32_t k1, uint32_t k2) {
-  uint32_t h = k0 * 0x9E3779B1u;
-  h = (h ^ (h >> 15)) + k1 * 0x85EBCA77u;
-  h = (h ^ (h >> 13)) + k2 * 0xC2B2AE3Du;
-  h ^= h >> 16;
-  h *= 0x27D4EB2Fu;
-  return h ^ (h >> 15);
-}
-
-CO_KERNEL co_k_cache_probe(EngineParams P) {
-  const EvalCache &C = P.cache;
-  const int par = P.iteration & 1;
-  const int rows = (int)(uint32_t)(P.pack_counter[par] & 0xFFFFFFFFull);
-  const int wave = CO_BLOCK_IDX * CO_WAVES_PER_BLOCK + CO_WAVE_IN_BLOCK;
-  if (wave == 0) {
-    /* the other parity's counter was the previous iteration's (its network launch is over): book it, clear it */
-    FOR_LANES {
-      if (lane == 0) {
-        C.totals[0] += C.count[4 * (par ^ 1)];
-        C.count[4 * (par ^ 1)] = 0u;
-      }
-    }
-  }
-  if (wave * CO_WAVE >= rows) return;
-  LV(int, slot);
-  LV(int, need);
-  FOR_LANES {
-    const int r = wave * CO_WAVE + lane;
-    int sl = -1, nd = 0;
-    if (r < rows) {
-      const uint4 key = C.keys[r];
-      const uint32_t h = co_cache_hash(key.x, key.y, key.z);
-      nd = 1;
-      /* Header = {board lo ^ X, board hi ^ X, reserves | 1 << 31}; X sets the frozen bit of every cell, which no
-       * position has (at most one cell is frozen, game.cpp:66-71): a header word that has not been written yet (0)
-       * never equals a stored word, so the three words of an entry may become visible in any order -- a reader
-       * takes an entry for its position only when all three are there.  The third word is the claim: empty = 0. */
-      const uint32_t x0 = key.x ^ 0x88888888u, x1 = key.y ^ 0x88888888u;
-      for (int probe = 0; probe < CO_CACHE_PROBES; ++probe) {
-        const uint32_t s = (h + (uint32_t)probe) & C.mask;
-        uint32_t *H = C.hdr + (size_t)s * 4;
-        uint32_t e0 = co_lane_load_coherent_u32(H + 0), e1 = co_lane_load_coherent_u32(H + 1), e2 = co_lane_load_coherent_u32(H + 2);
-        if (e2 == 0u) {
-          e2 = co_lane_cas_u32(H + 2, 0u, key.z);
-          if (e2 == 0u) {
-            co_lane_store_coherent_u32(H + 0, x0);
-            co_lane_store_coherent_u32(H + 1, x1);
-            sl = (int)s; /* ours: this row is evaluated into the entry */
-            break;
-          }
-          if (e2 == key.z) { /* taken this instant, perhaps for the same position: look again */
-            e0 = co_lane_load_coherent_u32(H + 0);
-            e1 = co_lane_load_coherent_u32(H + 1);
-          }
-        }
-        if (e2 == key.z && e0 == x0 && e1 == x1) {
-          sl = (int)s;
-          nd = 0;
-          break;
-        }
-      }
-    }
-    L(slot) = sl;
-    L(need) = nd;
-  }
-  const uint64_t nm = WAVE_BALLOT(need);
-  const uint32_t n = (uint32_t)co_popc64(nm);
-  uint32_t base = 0u;
-  if (n) base = co_atomic_add_u32(C.count + 4 * par, n);
-  FOR_LANES {
-    const int r = wave * CO_WAVE + lane;
-    if (r < rows) {
-      int src = L(slot);
-      if (L(need)) {
-        const uint32_t m = base + (uint32_t)co_popc64(nm & ((1ull << lane) - 1ull));
-        if (src < 0) src = (int)(C.mask + 1u + m); /* scratch element m of this iteration */
-        C.in_idx[m] = r;
-        C.out_idx[m] = src;
-      }
-      P.pend_src[C.owner[r]] = src;
-    }
-  }
 }
 
 /* is game g part of the batch of model `tp` (trainer.cpp:42-46, 84-98)? */

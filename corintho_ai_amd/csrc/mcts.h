@@ -1260,12 +1260,106 @@ CO_DEV int co_step_row(const EngineParams &P, int g, const GameCtl &gc) {
   return P.fused_pack ? gc.row_off : P.read_offset ? P.read_offset[g] : P.req_offset[g];
 }
 
+/* ---- evaluation cache (engine_defs.h EvalCache), fused training: the tail of a game's step resolves its new request
+ * rows to elements of the cache's value array, ONE LANE per row:
+ *   the position has an entry (evaluated in an earlier iteration, or claimed by another row of this batch, whose
+ *   outputs this iteration's network launch writes)            -> that entry;
+ *   no entry, an empty slot in the probe window                -> the lane claims it, the row is evaluated into it;
+ *   neither (the window is full)                               -> the row is evaluated into its scratch element.
+ * Rows to evaluate are numbered with one atomic per game.  Correctness does not depend on who wins a race: every
+ * path resolves a row to the network kernel's outputs for exactly its position (rows are evaluated independently
+ * of their batch; keys are compared in full; an entry is never moved or reused before the table is
+ * emptied as a whole, between two iterations).  Header words are accessed with relaxed device-scope atomics only:
+ * the XCDs' L2s are not coherent with each other within a launch, and an acquire / release would invalidate /
+ * write back a whole L2 per wave.  (Round 3 first had this as a kernel of its own between the search and the
+ * network: 36 us per launch beside the other pool's network kernel, most of it waiting for a SIMD.) */
+CO_DEV uint32_t co_cache_hash(uint32_t k0, uint32_t k1, uint32_t k2) {
+  uint32_t h = k0 * 0x9E3779B1u;
+  h = (h ^ (h >> 15)) + k1 * 0x85EBCA77u;
+  h = (h ^ (h >> 13)) + k2 * 0xC2B2AE3Du;
+  h ^= h >> 16;
+  h *= 0x27D4EB2Fu;
+  return h ^ (h >> 15);
+}
+
+/* rows [row0, row0 + n) of the pool's batch = the pending leaves 0 .. n - 1 of game g (keys in w.pend_key) */
+CO_DEV void co_cache_resolve(const EngineParams &P, CoWave &w, int g, int n, int row0) {
+  const EvalCache &C = P.cache;
+  const int par = P.iteration & 1;
+  LV(int, slot);
+  LV(int, need);
+  FOR_LANES {
+    int sl = -1, nd = 0;
+    if (lane < n) {
+      const uint4 key = w.pend_key[lane];
+      const uint32_t h = co_cache_hash(key.x, key.y, key.z);
+      nd = 1;
+      /* Header = {board lo ^ X, board hi ^ X, reserves | 1 << 31}; X sets the frozen bit of every cell, which no
+       * position has (at most one cell is frozen, game.cpp:66-71): a header word that has not been written yet (0)
+       * never equals a stored word, so the three words of an entry may become visible in any order -- a reader
+       * takes an entry for its position only when all three are there.  The third word is the claim: empty = 0. */
+      const uint32_t x0 = key.x ^ 0x88888888u, x1 = key.y ^ 0x88888888u;
+      for (int probe = 0; probe < CO_CACHE_PROBES; ++probe) {
+        const uint32_t s = (h + (uint32_t)probe) & C.mask;
+        uint32_t *H = C.hdr + (size_t)s * 4;
+        uint32_t e0 = co_lane_load_coherent_u32(H + 0), e1 = co_lane_load_coherent_u32(H + 1), e2 = co_lane_load_coherent_u32(H + 2);
+        if (e2 == 0u) {
+          e2 = co_lane_cas_u32(H + 2, 0u, key.z);
+          if (e2 == 0u) {
+            co_lane_store_coherent_u32(H + 0, x0);
+            co_lane_store_coherent_u32(H + 1, x1);
+            sl = (int)s; /* ours: this row is evaluated into the entry */
+            break;
+          }
+          if (e2 == key.z) { /* taken this instant, perhaps for the same position: look again */
+            e0 = co_lane_load_coherent_u32(H + 0);
+            e1 = co_lane_load_coherent_u32(H + 1);
+          }
+        }
+        if (e2 == key.z && e0 == x0 && e1 == x1) {
+          sl = (int)s;
+          nd = 0;
+          break;
+        }
+      }
+    }
+    L(slot) = sl;
+    L(need) = nd;
+  }
+  const uint64_t nm = WAVE_BALLOT(need);
+  const uint32_t cnt = (uint32_t)co_popc64(nm);
+  uint32_t base = 0u;
+  if (cnt) base = co_atomic_add_u32(C.count + 4 * par, cnt);
+  int32_t *psrc = P.pend_src + (size_t)g * P.searches_per_eval;
+  FOR_LANES {
+    if (lane < n) {
+      int src = L(slot);
+      if (L(need)) {
+        const uint32_t m = base + (uint32_t)co_popc64(nm & ((1ull << lane) - 1ull));
+        if (src < 0) src = (int)(C.mask + 1u + m); /* scratch element m of this iteration */
+        C.in_idx[m] = row0 + lane;
+        C.out_idx[m] = src;
+      }
+      psrc[lane] = src;
+    }
+  }
+}
+
 /* Trainer::doIteration for game g (trainer.cpp:164-236): the body of the
  * `omp parallel for`, one wavefront per game. */
 CO_DEV void co_mcts_step_wave(const EngineParams &P, int g) {
   if (P.fused_pack && g == P.pool_lo) {
     FOR_LANES {
-      if (lane == 0) P.pack_counter[(P.iteration + 1) & 1] = 0ull;
+      if (lane == 0) {
+        P.pack_counter[(P.iteration + 1) & 1] = 0ull;
+        if (P.cache.hdr) {
+          /* the other parity's counter of rows to evaluate was the previous iteration's (its network launch is
+           * over): book it, clear it for the next iteration */
+          const int op = (P.iteration & 1) ^ 1;
+          P.cache.totals[0] += P.cache.count[4 * op];
+          P.cache.count[4 * op] = 0u;
+        }
+      }
     }
   }
   GameCtl gc = P.games[g];
@@ -1372,16 +1466,7 @@ CO_DEV void co_mcts_step_wave(const EngineParams &P, int g) {
     const int n = w.gc.n_pending;
     const int base = P.pool_row_base + (int)(unsigned)(old & 0xFFFFFFFFull);
     w.gc.row_off = base;
-    if (w.pend_key) {
-      uint4 *kd = P.cache.keys + (base - P.pool_row_base);
-      int32_t *od = P.cache.owner + (base - P.pool_row_base);
-      FOR_LANES {
-        if (lane < n) {
-          kd[lane] = w.pend_key[lane];
-          od[lane] = g * P.searches_per_eval + lane;
-        }
-      }
-    }
+    if (w.pend_key) co_cache_resolve(P, w, g, n, base - P.pool_row_base);
     /* rows are 80 floats = 20 16-byte units, contiguous on both sides; five units per lane and pass,
      * loads first */
     const uint4 *src = (const uint4 *)w.req;

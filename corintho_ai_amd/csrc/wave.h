@@ -112,8 +112,21 @@ extern thread_local int co_emu_block_idx;
 #define L(x) x
 #define LAT(x, i) x
 #define FOR_LANES for (int lane = (int)(threadIdx.x & 63), _co_once = 1; _co_once; _co_once = 0)
-#define WAVE_SHARED(T, x, n) __shared__ T x[n]
-// one wave per workgroup: a wave barrier orders LDS traffic of the wave
+/* Wavefronts of the search kernel per workgroup.  A game is one wavefront whatever this is; what it changes is where
+ * the dispatcher puts them: single-wave workgroups spread a launch of 2048 games over all 1024 SIMDs at two waves
+ * each, CO_K3_WPB = 16 packs them onto half of the CUs at four waves per SIMD and leaves the other CUs to the
+ * network kernel of the other pool (whose waves take a SIMD's whole register file). */
+#ifndef CO_K3_WPB
+#define CO_K3_WPB 16 /* measured (round 3, rescnn4h3, two pools): 1 -> 466.7 ms, 4 -> 463.6, 16 -> 455.6 per generation; the MLP: +-0 */
+#endif
+#if CO_K3_WPB == 1
+#define WAVE_SHARED(T, name_, n) __shared__ T name_[n]
+#else
+#define WAVE_SHARED(T, name_, n)              \
+  __shared__ T name_##_blk[CO_K3_WPB][n];     \
+  T(&name_)[n] = name_##_blk[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))]
+#endif
+// a wave barrier orders LDS traffic of the wave (its LDS slices are its own)
 #define WAVE_SYNC() __builtin_amdgcn_wave_barrier()
 #define UNI_I(x) __builtin_amdgcn_readfirstlane((int)(x))
 #define UNI_U(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
