@@ -666,14 +666,14 @@ __device__ __forceinline__ void rc3_epilogue(float (&out)[NP][2][16], const f32x
 
 #ifdef CO_PROF
 /* diagnostic builds: cycles of wave 0 of every workgroup by phase (tools/prof_nn.py) */
-__device__ unsigned long long rc3_prof[8];
+__device__ unsigned long long rc3_prof[9]; /* 0..5 phases, 6 whole pass, 7 passes, 8 whole pass in 100 MHz ticks */
 #define RC3_STAMP(slot)                                                              \
   {                                                                                  \
     unsigned long long now_ = __builtin_readcyclecounter();                          \
     if (tid == 0) atomicAdd(&rc3_prof[slot], now_ - stamp_);                         \
     stamp_ = now_;                                                                   \
   }
-extern "C" int ca_net_prof(unsigned long long out[8]) {
+extern "C" int ca_net_prof(unsigned long long out[9]) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(rc3_prof), sizeof(rc3_prof)) == hipSuccess ? 0 : 1;
 }
 #else
@@ -697,7 +697,7 @@ __device__ __forceinline__ void rcs_forward(const Rc3Params &Q) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, h = lane >> 5, p2 = (lane >> 4) & 1, c = lane & 15;
 #ifdef CO_PROF
   unsigned long long stamp_ = __builtin_readcyclecounter();
-  const unsigned long long start_ = stamp_;
+  const unsigned long long start_ = stamp_, real_ = __builtin_amdgcn_s_memrealtime();
 #endif
   const uint32_t lds_w_addr = co_lds_addr(lds_dyn);
   constexpr int epi_off = 2 * RCS_GROUP_WORDS(NT) + (NT == 2 ? RCS_FEAT_WORDS(NP) : 0);
@@ -817,6 +817,7 @@ __device__ __forceinline__ void rcs_forward(const Rc3Params &Q) {
   if (tid == 0) {
     atomicAdd(&rc3_prof[6], __builtin_readcyclecounter() - start_);
     atomicAdd(&rc3_prof[7], 1ull);
+    atomicAdd(&rc3_prof[8], __builtin_amdgcn_s_memrealtime() - real_);
   }
 #endif
 }
@@ -831,17 +832,7 @@ __global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_x3_small(Rc3Params
  * float32-class arithmetic at the MFMA cost of bf16x3.  fp16's exponent range is narrower (normal from 6.1e-5,
  * subnormal quantum 6e-8): remainders of small values lose relative, not absolute, accuracy -- measured against
  * float64 in tests/test_net_precision.py. */
-__global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_h3(Rc3Params Q) { rcs_forward<2, 2, 8, true>(Q); }
-/* (_small, batches up to RC3_SMALL_ROWS rows; up to RC6_THIN_ROWS of them on the four-wave path described at
- * co_k_rescnn_forward_x6 below: one wave per SIMD, 8 positions per workgroup, waves 4..7 leave at once) */
-__global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_h3_small(Rc3Params Q) {
-  if (*Q.base.d_rows <= RC6_THIN_ROWS) {
-    if (threadIdx.x >= 256) return;
-    rcs_forward<1, 2, 4, true>(Q);
-  } else {
-    rcs_forward<1, 2, 8, true>(Q);
-  }
-}
+/* (the kernels themselves: behind co_k_rescnn_forward_x6) */
 /* (Capping this kernel at 168 registers so that a wave of the search kernel fits beside two of its waves on a SIMD was
  * measured: the network kernel alone 5 % slower, the generation 4 % slower -- the kernel trace shows 81 % of the search
  * kernel's time overlapping the other pool's network launches already, tools/overlap.py.) */
@@ -859,6 +850,28 @@ __global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_x6(Rc3Params Q) {
     rcs_forward<1, 3, 8>(Q);
   }
 }
+
+/* The f16x3 kernels (see above rcs_forward): throughput kernel, 32 positions per workgroup; _small: batches up to
+ * RC3_SMALL_ROWS rows, 16 positions per workgroup, and up to RC6_THIN_ROWS rows on the four-wave thin path (one wave per
+ * SIMD, 8 positions per workgroup, waves 4..7 leave at once; see co_k_rescnn_forward_x6). */
+#ifdef CO_H3_SHAPE16
+/* experiment, not part of the product build: the same kernels on v_mfma_f32_16x16x32 (DESIGN.md "MFMA shape of K6h3") */
+#include "../../tools/exp/nn_rescnn_s16.inc"
+#else
+__global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_h3(Rc3Params Q) { rcs_forward<2, 2, 8, true>(Q); }
+__global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_h3_small(Rc3Params Q) {
+  if (*Q.base.d_rows <= RC6_THIN_ROWS) {
+    if (threadIdx.x >= 256) return;
+    rcs_forward<1, 2, 4, true>(Q);
+  } else {
+    rcs_forward<1, 2, 8, true>(Q);
+  }
+}
+#define RCH_LDS_WORDS(NP) RCS_LDS_WORDS(2, NP)
+#endif
+#ifndef RCH_THREADS
+#define RCH_THREADS 512
+#endif
 
 /* ------------------------------------------------------------------ host */
 struct ResCnnNet : CoNet {
@@ -1007,12 +1020,18 @@ static inline void rc_bf16_terms(float v, int nt, uint16_t *t, bool f16 = false)
 struct ResCnnSplitNet : ResCnnNet {
   int nt;
   bool f16;
+  bool shape16; /* fragments in the order of the 16x16x32 path (rq_forward) */
   uint32_t *d_trunk3 = nullptr;
   uint32_t *d_whead3 = nullptr;
   uint32_t *d_epi3 = nullptr;
   ResCnnSplitNet(const float *w, size_t max_rows, rt_stream_t s, int nterms, bool fp16 = false)
       : ResCnnNet(w, max_rows, s), nt(nterms), f16(fp16) {
-    const size_t stem_chunk = (size_t)512 * nt, conv_chunk = (size_t)2048 * nt;
+#ifdef CO_H3_SHAPE16
+    shape16 = f16; /* experiment build */
+#else
+    shape16 = false;
+#endif
+    const size_t stem_chunk = (size_t)(shape16 ? 1024 : 512) * nt, conv_chunk = (size_t)2048 * nt;
     std::vector<uint32_t> tr(9 * stem_chunk + 72 * conv_chunk, 0u);
     const float *p = w;
     size_t off = 0;
@@ -1022,6 +1041,14 @@ struct ResCnnSplitNet : ResCnnNet {
       const int cs = cv == 0 ? 1 : 4;
       const size_t chunk = cv == 0 ? stem_chunk : conv_chunk;
       const float *K = p;
+#ifdef CO_H3_SHAPE16
+      if (shape16) {
+        rq_host_pack_conv(tr, off, chunk, K, cin, cv == 0 ? 1 : 2, nt, f16);
+        off += 9 * chunk;
+        p += (size_t)9 * cin * 64 + 5 * 64;
+        continue;
+      }
+#endif
       for (int tap = 0; tap < 9; ++tap)
         for (int st = 0; st < cs; ++st)
           for (int to = 0; to < 2; ++to)
@@ -1046,9 +1073,12 @@ struct ResCnnSplitNet : ResCnnNet {
     /* 1x1 head convolutions as term fragments of one more K loop (same k-slot order as the
      * trunk): output row i = 0..3 policy planes, 4..5 value planes, the rest zero */
     const float *pk = p, *vk = pk + 64 * 4 + 4 * 5 + 64 * 96 + 96;
-    const size_t frag1 = (size_t)4 * nt * 256, head_words = frag1 + 6144 + 2048 + 1024;
+    const size_t frag1 = (size_t)(shape16 ? 2 : 4) * nt * 256, head_words = frag1 + 6144 + 2048 + 1024;
     std::vector<uint32_t> wh3(frag1, 0u);
-    for (int st = 0; st < 4; ++st)
+#ifdef CO_H3_SHAPE16
+    if (shape16) rq_host_pack_heads(wh3, pk, vk, nt, f16);
+#endif
+    for (int st = 0; st < (shape16 ? 0 : 4); ++st)
       for (int h = 0; h < 2; ++h)
         for (int i = 0; i < 32; ++i)
           for (int j = 0; j < 8; ++j) {
@@ -1075,9 +1105,9 @@ struct ResCnnSplitNet : ResCnnNet {
       RT_CHECK(hipFuncSetAttribute((const void *)co_k_rescnn_forward_x3_small, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    RCS_LDS_WORDS(2, 1) * 4));
       RT_CHECK(hipFuncSetAttribute((const void *)co_k_rescnn_forward_h3, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   RCS_LDS_WORDS(2, 2) * 4));
+                                   RCH_LDS_WORDS(2) * 4));
       RT_CHECK(hipFuncSetAttribute((const void *)co_k_rescnn_forward_h3_small, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   RCS_LDS_WORDS(2, 1) * 4));
+                                   RCH_LDS_WORDS(1) * 4));
     } else {
       RT_CHECK(hipFuncSetAttribute((const void *)co_k_rescnn_forward_x6, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    RCS_LDS_WORDS(3, 1) * 4));
@@ -1112,10 +1142,10 @@ struct ResCnnSplitNet : ResCnnNet {
       const int thin_rows = rows_cap < RC6_THIN_ROWS ? rows_cap : RC6_THIN_ROWS;
       const int small_grid = f16 && (thin_rows + 7) / 8 > (small_rows + 15) / 16 ? (thin_rows + 7) / 8 : (small_rows + 15) / 16;
       hipLaunchKernelGGL(f16 ? co_k_rescnn_forward_h3_small : co_k_rescnn_forward_x3_small, dim3(small_grid), dim3(512),
-                         RCS_LDS_WORDS(2, 1) * 4, s, q);
+                         (f16 ? RCH_LDS_WORDS(1) : RCS_LDS_WORDS(2, 1)) * 4, s, q);
       if (rows_cap > RC3_SMALL_ROWS)
-        hipLaunchKernelGGL(f16 ? co_k_rescnn_forward_h3 : co_k_rescnn_forward_x3, dim3((rows_cap + 31) / 32), dim3(512),
-                           RCS_LDS_WORDS(2, 2) * 4, s, q);
+        hipLaunchKernelGGL(f16 ? co_k_rescnn_forward_h3 : co_k_rescnn_forward_x3, dim3((rows_cap + 31) / 32), dim3(f16 ? RCH_THREADS : 512),
+                           (f16 ? RCH_LDS_WORDS(2) : RCS_LDS_WORDS(2, 2)) * 4, s, q);
     } else {
       /* enough workgroups for either path: 16 positions each in the throughput path, 8 in the thin one (<= 2048 rows) */
       const int thin_rows = rows_cap < RC6_THIN_ROWS ? rows_cap : RC6_THIN_ROWS;

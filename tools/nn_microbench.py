@@ -31,6 +31,6 @@ rng = np.random.default_rng(0)
 s = np.zeros((rows, 70), np.float32)
 s[:, :64] = rng.integers(0, 2, (rows, 64))
 s[:, 64:] = rng.integers(0, 5, (rows, 6)) * 0.25
-ms = t.net_bench(s, reps=20)
+ms = t.net_bench(s, reps=int(os.environ.get("NN_REPS", "20")))
 flop = (nets.rescnn4_flop_per_row() if kind not in (1, 4, 6) else 253400.0) * rows
 print("kind %d rows %d flags %s: %.3f ms per launch, %.1f TFLOP/s algorithmic" % (kind, rows, flags, ms, flop / ms / 1e9))
