@@ -70,7 +70,7 @@ EXPORTS = [
     "ca_last_error", "ca_device_check", "ca_trainer_create", "ca_trainer_destroy", "ca_trainer_num_requests",
     "ca_trainer_num_samples", "ca_trainer_score", "ca_trainer_avg_mate_length", "ca_trainer_write_requests",
     "ca_trainer_write_samples", "ca_trainer_write_scores", "ca_trainer_do_iteration", "ca_trainer_set_net",
-    "ca_trainer_run", "ca_trainer_net_forward", "ca_trainer_net_bench", "ca_trainer_export_samples", "ca_trainer_pack_samples_device", "ca_trainer_pin_host", "ca_trainer_unpin_host", "ca_trainer_set_positions", "ca_trainer_analysis", "ca_trainer_finish", "ca_trainer_reset", "ca_expand_samples", "ca_trainer_stats",
+    "ca_trainer_run", "ca_trainer_net_forward", "ca_trainer_net_bench", "ca_trainer_export_samples", "ca_trainer_pack_samples_device", "ca_trainer_pin_host", "ca_trainer_unpin_host", "ca_trainer_set_positions", "ca_trainer_analysis", "ca_trainer_finish", "ca_trainer_set_logging", "ca_trainer_reset", "ca_expand_samples", "ca_trainer_stats",
     "ca_trainer_game_info", "ca_trainer_trace", "ca_trainer_prof", "ca_rules_legal_moves", "ca_rules_do_move", "ca_rng_draw",
     "ca_fp_probe",
     "ca_tourney_create", "ca_tourney_destroy", "ca_tourney_add_player", "ca_tourney_add_match", "ca_tourney_all_done",
@@ -105,6 +105,7 @@ def declare(L):
     L.ca_trainer_set_positions.argtypes = [vp, i32p, i32p, i32p, i32p]
     L.ca_trainer_analysis.argtypes = [vp, i32p]
     L.ca_trainer_finish.argtypes = [vp]
+    L.ca_trainer_set_logging.argtypes = [vp, C.c_char_p, C.c_int32]
     L.ca_trainer_reset.argtypes = [vp, C.c_int32]
     L.ca_expand_samples.argtypes = [C.c_int, f32p, f32p, C.c_int32, f32p, f32p, f32p]
     L.ca_trainer_stats.argtypes = [vp, C.POINTER(CaStats)]

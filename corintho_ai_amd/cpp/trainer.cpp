@@ -16,7 +16,6 @@ void check(int rc) {
 Trainer::Trainer(int32_t num_games, const std::string &log_folder, int32_t seed, int32_t max_searches,
                  int32_t searches_per_eval, float c_puct, float epsilon, int32_t num_logged, int32_t num_threads,
                  bool testing) {
-  (void)log_folder;  // per-game text logs are host-side diagnostics of the reference; not produced on device
   ca_config cfg{};
   cfg.num_games = num_games;
   cfg.seed = seed;
@@ -24,14 +23,19 @@ Trainer::Trainer(int32_t num_games, const std::string &log_folder, int32_t seed,
   cfg.searches_per_eval = searches_per_eval;
   cfg.c_puct = c_puct;
   cfg.epsilon = epsilon;
-  cfg.num_logged = 0;  // the reference default (10) only selects which games are logged
-  static bool told = false;
-  if (num_logged > 0 && !told && (told = true))
-    std::fprintf(stderr, "corintho_hip Trainer: num_logged = %d ignored -- per-game text logs (trainer.cpp:243-250) are not "
-                         "produced on the device\n", (int)num_logged);
+  cfg.num_logged = 0;  // switched on below (ca_trainer_set_logging)
   cfg.num_threads = num_threads;
   cfg.testing = testing ? 1 : 0;
   check(ca_trainer_create(&cfg, &impl_));
+  // trainer.cpp:243-250: the first num_logged games write log_folder/game_<i>.txt
+  if (num_logged > 0) {
+    const int rc = ca_trainer_set_logging(impl_, log_folder.c_str(), num_logged);
+    if (rc != CA_OK) {
+      ca_trainer_destroy(impl_);
+      impl_ = nullptr;
+      check(rc);
+    }
+  }
 }
 
 Trainer::~Trainer() { ca_trainer_destroy(impl_); }

@@ -21,6 +21,7 @@
 #include "../../include/corintho_hip.h"
 #include "kernels.h"
 #include "nn.h"
+#include "logfmt.h"
 #include "rt.h"
 
 #ifdef CO_EMU
@@ -126,6 +127,10 @@ struct ca_trainer {
   DevBuf<int32_t> pend_src;
   DevBuf<uint32_t> pend_leaf, pend_path, pend_n, noise_raw, rng;
   DevBuf<int32_t> pend_depth, req_offset, trace, all_done;
+  DevBuf<int32_t> logbuf; /* per-game text logs: EngineParams::log */
+  std::string log_folder;
+  int num_logged = 0;
+  bool logs_written = false;
   DevBuf<float> req, nn_in, nn_in70, nn_eval, nn_probs, samples;
   DevBuf<unsigned long long> row_counter, pack_counter, prof, next_game;
   DevBuf<GameCtl> results;   /* [G] finished games by index (recycling pools) */
@@ -396,6 +401,56 @@ struct ca_trainer {
     timed_launches = nn_timed_rows = 0;
     nn_rows_evaluated = 0;
     cache_clean = false; /* run_pools empties the tables before the first iteration of the new generation */
+    if (logbuf.p) {
+      rt_memset(logbuf.p, 0, (size_t)num_logged * CO_LOG_CAP * 4, stream);
+      rt_sync(stream);
+    }
+    logs_written = false;
+  }
+
+  /* Trainer::initialize, trainer.cpp:243-250: the first num_logged games write `<log_folder>/game_<i>.txt` (i = the game's
+   * index in the generation).  Before the first iteration only. */
+  void set_logging(const char *folder, int n) {
+    if (tourney || cfg.analyse) throw EngineError(CA_ERR_STATE, "per-game logs belong to Trainer games (self-play or arena)");
+    if (iterations != 0 || trainer_iteration != 0) throw EngineError(CA_ERR_STATE, "ca_trainer_set_logging: the games have started");
+    if (n < 0) throw EngineError(CA_ERR_ARG, "ca_trainer_set_logging: num_logged < 0");
+    if (n > G) n = G;
+    if (n > R) n = R; /* logged games start in their own slots (mcts.h) */
+    num_logged = n;
+    log_folder = folder ? folder : "";
+    if (n > 0) {
+      logbuf.alloc((size_t)n * CO_LOG_CAP, stream);
+      rt_sync(stream);
+    } else {
+      logbuf.release();
+    }
+    P.log = logbuf.p;
+    P.num_logged = n;
+    logs_written = false;
+  }
+
+  /* the files, once every game is over (the reference writes them as the games go; a file that cannot be opened is
+   * skipped without a word there too: an ofstream in its fail state) */
+  void maybe_write_logs() {
+    if (!logbuf.p || !finished || logs_written) return;
+    logs_written = true;
+    fetch_games();
+    std::vector<int32_t> rec((size_t)num_logged * CO_LOG_CAP);
+    rt_d2h(rec.data(), logbuf.p, rec.size() * 4, stream);
+    rt_sync(stream);
+    for (int g = 0; g < num_logged; ++g) {
+      const int32_t *r = rec.data() + (size_t)g * CO_LOG_CAP;
+      if (r[0] < 0 || r[0] > CO_LOG_CAP - 1)
+        throw EngineError(CA_ERR_ENGINE, "text log of game " + std::to_string(cfg.game_base + g) + " does not fit its record (" +
+                                             std::to_string(r[0]) + " words)");
+      const std::string path = log_folder + "/game_" + std::to_string(cfg.game_base + g) + ".txt";
+      FILE *f = fopen(path.c_str(), "w");
+      if (!f) continue;
+      CoLogWriter wr(f);
+      const bool ok = wr.write_game(r + 1, r[0], host_games[g].result);
+      fclose(f);
+      if (!ok) throw EngineError(CA_ERR_ENGINE, "malformed text-log record of game " + std::to_string(cfg.game_base + g));
+    }
   }
 
   void fill_params(uint32_t cap, int total) {
@@ -443,6 +498,8 @@ struct ca_trainer {
     P.ctl = ctl.p;
     P.samples = samples.p;
     P.trace = trace.p;
+    P.log = logbuf.p;
+    P.num_logged = num_logged;
     P.all_done = all_done.p;
     P.row_counter = nullptr; /* counted in fused mode only */
     P.fused_pack = 0;
@@ -473,6 +530,7 @@ struct ca_trainer {
     any_error = h_ctl[2] != 0;
     scan_valid_for = to_play;
     scan_valid = true;
+    if (finished && !any_error) maybe_write_logs();
   }
 
   /* host_games[i] = control block of GAME i of this trainer: the slot itself without recycling; else the filed
@@ -1255,6 +1313,9 @@ extern "C" int ca_trainer_set_positions(ca_trainer *t, const int32_t *boards, co
 }
 extern "C" int ca_trainer_analysis(ca_trainer *t, int32_t *out) { CA_TGUARD(t->analysis(out)) }
 extern "C" int ca_trainer_finish(ca_trainer *t) { CA_TGUARD(t->finish_analysis()) }
+extern "C" int ca_trainer_set_logging(ca_trainer *t, const char *log_folder, int32_t num_logged) {
+  CA_TGUARD(t->set_logging(log_folder, num_logged))
+}
 extern "C" int ca_trainer_reset(ca_trainer *t, int32_t seed) { CA_TGUARD(t->reset_games(seed)) }
 /* ------------------------------------------------------------------ Tourney C ABI */
 struct ca_tourney {

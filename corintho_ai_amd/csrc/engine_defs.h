@@ -43,6 +43,7 @@
 #define CO_PATH_MAX 48
 #define CO_MT_N 624
 #define CO_TRACE_CAP 12288
+#define CO_LOG_CAP 49152 /* int32 per logged game: a ply records up to 5 + 1 + 5 x 96 + 6 x 64 + 5 words */
 #define CO_ARENA_PAD 160 /* units readable past the last block (whole-wave block loads) */
 
 /* ref: util.h:57-64 */
@@ -179,6 +180,11 @@ struct EngineParams {
   int32_t *ctl;           /* [4] written by co_k_scan: batch rows, all done, OR of the games' error bits, games not done */
   float *samples;       /* [G][CO_MAX_PLIES][166] */
   int32_t *trace;       /* [G][CO_TRACE_CAP] or null */
+  /* per-game text logs (Trainer's num_logged, trainer.cpp:243-250): the first num_logged games record what the
+   * reference's log prints at every move choice (mcts.h co_log_ply); word 0 of a game's record is its length.  The host
+   * writes the files when the games are over (engine.hip write_logs). */
+  int32_t *log;         /* [num_logged][CO_LOG_CAP] or null */
+  int32_t num_logged;
   int32_t *all_done;    /* [1] */
   unsigned long long *row_counter; /* [1] rows handed to the network so far */
   /* fused training mode: K3 packs its own requests.  pack_counter[iteration & 1] =

@@ -73,6 +73,7 @@ struct CoWave {
   float *req;
   float *samples;
   int32_t *trace;
+  int32_t *log; /* this game's text-log record (EngineParams::log), or null */
   unsigned long long *prof;
   /* config */
   int max_searches, spe, testing, trace_on, defer_handover, analyse, force_choose;
@@ -850,6 +851,103 @@ CO_DEV void co_reset_tree_to_child(CoWave &w, CoTree &t, int choice) {
   t.tc.searches_done = 0;
 }
 
+/* ---- per-game text logs (SelfPlayer::writePreMoveLogs / writeMoveChoice, selfplayer.cpp:185-204).  The device records the
+ * numbers, the host prints them (engine.hip write_logs).  One record per move choice:
+ *   1, to_play, depth, root visits, root result, root evaluation bits,
+ *   nc, nc x {move, visits, evaluation bits, result, probability bits}        the root's children (writeMoves :136-183)
+ *   m x {depth, move, visits, result, evaluation bits, probability bits}, -1   the main line (Node::writeMainLine,
+ *                                                                              node.cpp:197-240): most visits, then the
+ *                                                                              larger evaluation; a lost child at once
+ *   [after the choice, co_game_step] move, board low, board high, meta of the new position
+ * `ch` is the caller's scratch for one node's slots.  Logged games are few (Trainer's default is 10); their waves spend a
+ * few microseconds here once per ply. */
+CO_DEV void co_log_put(CoWave &w, int &at, int32_t v) {
+  if (at + 1 < CO_LOG_CAP) {
+    int32_t *dst = w.log + 1 + at;
+    FOR_LANES {
+      if (lane == 0) *dst = v;
+    }
+  }
+  ++at;
+}
+CO_DEV void co_log_commit(CoWave &w, int at) {
+  int32_t *dst = w.log;
+  FOR_LANES {
+    if (lane == 0) *dst = at;
+  }
+  WAVE_SYNC();
+}
+
+CO_DEV void co_log_ply(CoWave &w, CoTree &t, uint4 (&ch)[CO_NUM_MOVES]) {
+  uint4 *A = t.A;
+  uint32_t node = t.tc.root;
+  uint4 h0 = co_load_unit(A, node);
+  uint4 h1 = co_load_unit(A, node + 1);
+  uint4 rs = co_load_unit(A, h1.x);
+  int at = w.log[0];
+  co_log_put(w, at, 1);
+  co_log_put(w, at, w.gc.to_play);
+  co_log_put(w, at, (int)CO_META_DEPTH(h0.z));
+  co_log_put(w, at, co_slot_visits(rs));
+  co_log_put(w, at, co_slot_result(rs));
+  co_log_put(w, at, (int32_t)rs.y);
+  int depth = (int)CO_META_DEPTH(h0.z);
+  for (int level = 0;; ++level) {
+    int n = (int)CO_META_NEDGES(h0.z);
+    float denom = co_u2f(h1.y);
+    WAVE_SYNC();
+    for (int base = 0; base < n; base += CO_WAVE) {
+      FOR_LANES {
+        int e = base + lane;
+        if (e < n) ch[e] = A[node + 2 + e];
+      }
+    }
+    WAVE_SYNC();
+    if (level == 0) {
+      int nc = 0;
+      for (int e = 0; e < n; ++e) nc += ch[e].x != CO_NONE;
+      co_log_put(w, at, nc);
+      for (int e = 0; e < n; ++e) {
+        if (ch[e].x == CO_NONE) continue;
+        co_log_put(w, at, (int)(ch[e].z & 127u));
+        co_log_put(w, at, co_slot_visits(ch[e]));
+        co_log_put(w, at, (int32_t)ch[e].y);
+        co_log_put(w, at, co_slot_result(ch[e]));
+        co_log_put(w, at, (int32_t)co_f2u((float)((ch[e].z >> 7) & 511u) * denom));
+      }
+    }
+    int best = -1, max_visits = 0;
+    float max_eval = 0.0f;
+    for (int e = 0; e < n; ++e) {
+      if (ch[e].x == CO_NONE) continue;
+      int r = co_slot_result(ch[e]), v = co_slot_visits(ch[e]);
+      float ev = co_u2f(ch[e].y);
+      if (co_res_lost(r)) {
+        best = e;
+        break;
+      }
+      if (v > max_visits || (v == max_visits && ev > max_eval)) {
+        best = e;
+        max_visits = v;
+        max_eval = ev;
+      }
+    }
+    if (best < 0) break;
+    ++depth;
+    co_log_put(w, at, depth);
+    co_log_put(w, at, (int)(ch[best].z & 127u));
+    co_log_put(w, at, co_slot_visits(ch[best]));
+    co_log_put(w, at, co_slot_result(ch[best]));
+    co_log_put(w, at, (int32_t)ch[best].y);
+    co_log_put(w, at, (int32_t)co_f2u((float)((ch[best].z >> 7) & 511u) * denom));
+    node = ch[best].x;
+    h0 = co_load_unit(A, node);
+    h1 = co_load_unit(A, node + 1);
+  }
+  co_log_put(w, at, -1);
+  co_log_commit(w, at);
+}
+
 /* TrainMC::chooseMove and its four variants, trainmc.cpp:110-137, 298-473.
  * sample = this ply's (state[70], policy[96]) row, or null in testing mode. */
 CO_DEV int co_choose_move(CoWave &w, CoTree &t, float *sample) {
@@ -878,6 +976,7 @@ CO_DEV int co_choose_move(CoWave &w, CoTree &t, float *sample) {
   }
   /* children in edge order = the reference's sorted sibling list */
   WAVE_SHARED(uint4, ch, CO_NUM_MOVES);
+  if (w.log) co_log_ply(w, t, ch); /* (uses ch for the nodes of the main line) */
   for (int base = 0; base < n; base += CO_WAVE) {
     FOR_LANES {
       int e = base + lane;
@@ -1206,6 +1305,14 @@ CO_DEV int co_game_step(CoWave &w, const float *eval, const float *probs) {
       board = (uint64_t)h0.x | ((uint64_t)h0.y << 32);
       meta = h0.z;
       depth = (int)CO_META_DEPTH(h0.z);
+      if (w.log) { /* writeMoveChoice, selfplayer.cpp:199-204 */
+        int at = w.log[0];
+        co_log_put(w, at, choice);
+        co_log_put(w, at, (int32_t)h0.x);
+        co_log_put(w, at, (int32_t)h0.y);
+        co_log_put(w, at, (int32_t)meta);
+        co_log_commit(w, at);
+      }
     }
     if (w.pc) {
       w.gc.pos_lo = (uint32_t)board;
@@ -1410,6 +1517,7 @@ CO_DEV void co_mcts_step_wave(const EngineParams &P, int g) {
   /* samples and traces belong to the GAME, not to the slot */
   w.samples = P.samples ? P.samples + (size_t)gc.gid * CO_MAX_PLIES * CO_SAMPLE_FLOATS : (float *)0;
   w.trace = P.trace ? P.trace + (size_t)gc.gid * CO_TRACE_CAP : (int32_t *)0;
+  w.log = P.log && gc.gid < P.num_logged ? P.log + (size_t)gc.gid * CO_LOG_CAP : (int32_t *)0;
   w.prof = P.prof ? P.prof + (size_t)g * 16 : (unsigned long long *)0;
   w.max_searches = P.max_searches;
   w.spe = P.searches_per_eval;
@@ -1468,6 +1576,7 @@ CO_DEV void co_mcts_step_wave(const EngineParams &P, int g) {
     w.noise_words = 0;
     w.samples = P.samples ? P.samples + (size_t)gid * CO_MAX_PLIES * CO_SAMPLE_FLOATS : (float *)0;
     w.trace = P.trace ? P.trace + (size_t)gid * CO_TRACE_CAP : (int32_t *)0;
+    w.log = (int32_t *)0; /* logged games are the first ones: they start in their own slots */
     co_mt_seed(w.mt, P.seeds[gid]);
     step_eval = step_probs = (const float *)0; /* the first step of a game creates the root and asks for its evaluation */
   }

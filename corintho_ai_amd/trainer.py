@@ -45,8 +45,6 @@ class Trainer:
                  trace=False, game_base=0, total_games=0, pools=0, analyse=False, resident=0, eval_cache=True, _cdll=None):
         self._L = _cdll if _cdll is not None else _lib.load()
         self._t = C.c_void_p()
-        if num_logged:
-            raise ValueError("per-game text logs (num_logged > 0) are not produced by the device engine")
         cfg = _lib.CaConfig(num_games=num_games, seed=int(seed) & 0x7FFFFFFF if seed >= 0 else int(seed),
                             max_searches=max_searches, searches_per_eval=searches_per_eval, c_puct=c_puct,
                             epsilon=epsilon, num_logged=0, num_threads=num_threads, testing=int(bool(testing)),
@@ -57,6 +55,8 @@ class Trainer:
         self.searches_per_eval = searches_per_eval
         self.testing = bool(testing)
         _lib.check(self._L, self._L.ca_trainer_create(C.byref(cfg), C.byref(self._t)))
+        if num_logged:  # trainer.cpp:243-250: the first num_logged games write log_folder/game_<i>.txt
+            _lib.check(self._L, self._L.ca_trainer_set_logging(self._t, str(log_folder).encode(), int(num_logged)))
 
     def close(self):
         if getattr(self, "_t", None) and self._t.value:

@@ -48,7 +48,7 @@ typedef struct ca_config {
   int32_t searches_per_eval;  /* default 16 */
   float c_puct;               /* default 1.0 */
   float epsilon;              /* default 0.25 */
-  int32_t num_logged;         /* per-game text logs are not produced on device; must be 0 */
+  int32_t num_logged;         /* must be 0 here: the per-game text logs are switched on by ca_trainer_set_logging */
   int32_t num_threads;        /* accepted and ignored (OpenMP width of the reference) */
   int32_t testing;            /* arena mode: no samples, no opening temperature */
   /* device options */
@@ -90,6 +90,14 @@ int ca_device_check(int device);
 /* Trainer::Trainer (trainer.cpp:18-37) / ~Trainer */
 int ca_trainer_create(const ca_config *cfg, ca_trainer **out);
 void ca_trainer_destroy(ca_trainer *t);
+
+/* Trainer::initialize, trainer.cpp:243-250: the first num_logged games of the generation write
+ * `<log_folder>/game_<i>.txt` (i = game_base + index), the text SelfPlayer prints at every move choice
+ * (selfplayer.cpp:124-232; main line node.cpp:197-240).  Call before the first iteration.  The search kernel records
+ * the numbers; the files are written when the last game is over (the reference writes as it goes), byte for byte the
+ * reference's text.  A file that cannot be opened is skipped silently, as the reference's ofstream is.  Self-play and
+ * arena trainers only. */
+int ca_trainer_set_logging(ca_trainer *t, const char *log_folder, int32_t num_logged);
 
 /* int Trainer::num_requests(int to_play) -- trainer.cpp:39-49 */
 int ca_trainer_num_requests(ca_trainer *t, int to_play, int32_t *out);

@@ -58,7 +58,8 @@ int main(int argc, char **argv) {
   try {
     // main.pyx:299-310: Trainer(num_games, log_folder, seed, max_searches, searches_per_eval, c_puct,
     // epsilon, num_logged, num_threads, testing)
-    Trainer trainer(G, "logs", seed, S, spe, 1.0f, 0.25f, 0, 1, testing);
+    // two logged games (trainer.cpp:243-250): <prefix>.logs/game_0.txt, game_1.txt
+    Trainer trainer(G, prefix + ".logs", seed, S, spe, 1.0f, 0.25f, 2, 1, testing);
     const size_t cap = (size_t)G * spe;
     std::vector<float> evals(cap, 0.0f), probs(cap * NM, 0.0f), game_states(cap * GS, 0.0f);  // main.pyx:132-134
     int to_play = testing ? 0 : -1;

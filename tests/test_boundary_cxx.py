@@ -51,9 +51,11 @@ def test_cpp_trainer_plays_a_generation_equal_to_the_oracle(engine, testing, tmp
     G, seed, S_, spe = 16, 4711, 40, 8
     exe = _build_driver(tmp_path, engine)
     prefix = str(tmp_path / "run")
+    os.mkdir(prefix + ".logs")
+    os.mkdir(str(tmp_path / "oracle_logs"))
     subprocess.check_call([exe, prefix, str(G), str(seed), str(S_), str(spe), str(testing)])
     # the oracle through the same loop in Python, with the same stand-in network
-    o = O.Trainer(G, seed=seed, max_searches=S_, searches_per_eval=spe, testing=bool(testing))
+    o = O.Trainer(G, str(tmp_path / "oracle_logs"), seed, S_, spe, 1.0, 0.25, 2, 1, bool(testing))
     if testing:
         r = H.play_generation(o, G, spe, None, nets_by_player=(lambda s: H.hash_net(s, 1), lambda s: H.hash_net(s, 2)), record=True)
     else:
@@ -78,6 +80,10 @@ def test_cpp_trainer_plays_a_generation_equal_to_the_oracle(engine, testing, tmp
     fo = str(tmp_path / "oracle_scores.txt")
     o.writeScores(fo)
     assert open(prefix + ".scores.txt", "rb").read() == open(fo, "rb").read()
+    # the per-game text logs of the first two games
+    assert sorted(os.listdir(prefix + ".logs")) == ["game_0.txt", "game_1.txt"]
+    for name in ("game_0.txt", "game_1.txt"):
+        assert open(os.path.join(prefix + ".logs", name), "rb").read() == open(str(tmp_path / "oracle_logs" / name), "rb").read()
 
 
 @pytest.mark.parametrize("engine", ENGINES)

@@ -1,0 +1,80 @@
+"""Per-game text logs of the device engine (Trainer's num_logged, trainer.cpp:243-250) against the oracle's, byte for
+byte: the search kernel records the numbers of every move choice, engine.hip prints them (csrc/logfmt.h).  The oracle's
+own log is pinned in tests/test_oracle_reference_tests.py::test_per_game_text_logs."""
+import os
+
+import numpy as np
+import pytest
+
+from corintho_ai_amd import NET_MLP12X100, nets
+from oracle import oracle as O
+from tests import harness as H
+from tests.engines import ENGINES, make_trainer
+
+
+def _files(folder):
+    return {n: open(os.path.join(folder, n), "rb").read() for n in sorted(os.listdir(folder))}
+
+
+@pytest.mark.parametrize("engine", ENGINES)
+@pytest.mark.parametrize("G,S_,spe,eps,logged,testing", [(5, 60, 8, 0.25, 3, False), (4, 120, 16, 0.0, 4, False),
+                                                       (3, 40, 4, 0.25, 7, False), (4, 50, 8, 0.25, 2, True)])
+def test_logs_match_the_oracle(engine, tmp_path, G, S_, spe, eps, logged, testing):
+    """compat protocol, stand-in network on the host: the same evaluations reach both sides"""
+    a, b = tmp_path / "engine", tmp_path / "oracle"
+    a.mkdir()
+    b.mkdir()
+    t = make_trainer(engine, G, str(a), 77, S_, spe, 1.0, eps, logged, 1, testing, stagger=False)
+    o = O.Trainer(G, str(b), 77, S_, spe, 1.0, eps, logged, 1, testing)
+    o.set_stagger(False)
+    other = lambda s: H.hash_net(s * 0.5)  # a second stand-in model for the arena
+    by_player = (H.hash_net, other) if testing else None
+    H.play_generation(t, G, spe, H.hash_net, nets_by_player=by_player)
+    H.play_generation(o, G, spe, H.hash_net, nets_by_player=by_player)
+    fa, fb = _files(a), _files(b)
+    assert list(fa) == list(fb) == ["game_%d.txt" % i for i in range(min(logged, G))]
+    for name in fa:
+        assert fa[name] == fb[name], "%s differs from the oracle's log" % name
+        assert fa[name].count(b"TURN ") >= 2 and (b"WON!" in fa[name] or b"DRAWN." in fa[name])
+
+
+@pytest.mark.parametrize("engine", ENGINES)
+def test_logs_of_a_fused_generation(engine, tmp_path):
+    """fused mode (network and search on the device, two pools, recycled slots): the logged games are the first ones
+    of the generation whatever the slot pool; the oracle replays with the device network's outputs"""
+    G, S_, spe, logged = 12, 50, 8, 3
+    a, b = tmp_path / "engine", tmp_path / "oracle"
+    a.mkdir()
+    b.mkdir()
+    w = nets.init_mlp12x100(2)
+    t = make_trainer(engine, G, str(a), 5, S_, spe, 1.0, 0.25, logged, 1, False, stagger=False, resident=8, pools=2)
+    t.set_net(NET_MLP12X100, w)
+    assert t.run()
+    o = O.Trainer(G, str(b), 5, S_, spe, 1.0, 0.25, logged, 1, False)
+    o.set_stagger(False)
+    cap = t.stats()["resident_slots"] * spe  # rows one device evaluation takes
+
+    def fw(s):
+        parts = [t.net_forward(s[i:i + cap]) for i in range(0, s.shape[0], cap)]
+        return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
+
+    H.play_generation(o, G, spe, fw)
+    fa, fb = _files(a), _files(b)
+    assert list(fa) == list(fb) == ["game_%d.txt" % i for i in range(logged)]
+    for name in fa:
+        assert fa[name] == fb[name], "%s differs from the oracle's log" % name
+
+
+def test_logging_is_refused_once_the_games_run(tmp_path):
+    from tests.emu import emulib
+
+    L = emulib.load()
+    t = make_trainer("emu", 2, "", 1, 20, 4, 1.0, 0.25, 0, 1, False, stagger=False)
+    ev = np.zeros(2 * 4, np.float32)
+    pr = np.zeros((2 * 4, 96), np.float32)
+    t.doIteration(ev, pr)
+    assert L.ca_trainer_set_logging(t._t, str(tmp_path).encode(), 1) != 0
+    # an unwritable folder is skipped without an error, as the reference's ofstream is
+    t2 = make_trainer("emu", 2, str(tmp_path / "missing"), 1, 20, 4, 1.0, 0.25, 2, 1, False, stagger=False)
+    H.play_generation(t2, 2, 4, H.hash_net)
+    assert not (tmp_path / "missing").exists()
