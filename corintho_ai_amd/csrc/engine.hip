@@ -414,6 +414,8 @@ struct ca_trainer {
     if (tourney || cfg.analyse) throw EngineError(CA_ERR_STATE, "per-game logs belong to Trainer games (self-play or arena)");
     if (iterations != 0 || trainer_iteration != 0) throw EngineError(CA_ERR_STATE, "ca_trainer_set_logging: the games have started");
     if (n < 0) throw EngineError(CA_ERR_ARG, "ca_trainer_set_logging: num_logged < 0");
+    n -= cfg.game_base; /* a shard logs the games of the generation's first num_logged that it owns */
+    if (n < 0) n = 0;
     if (n > G) n = G;
     if (n > R) n = R; /* logged games start in their own slots (mcts.h) */
     num_logged = n;

@@ -43,7 +43,7 @@
 #define CO_PATH_MAX 48
 #define CO_MT_N 624
 #define CO_TRACE_CAP 12288
-#define CO_LOG_CAP 49152 /* int32 per logged game: a ply records up to 5 + 1 + 5 x 96 + 6 x 64 + 5 words */
+#define CO_LOG_CAP (64 * 880) /* int32 per logged game: a ply records up to 7 + 5 x 96 + 6 x 64 + 1 + 4 words, a game has fewer than 64 plies (6-bit depth) */
 #define CO_ARENA_PAD 160 /* units readable past the last block (whole-wave block loads) */
 
 /* ref: util.h:57-64 */

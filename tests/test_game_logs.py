@@ -78,3 +78,21 @@ def test_logging_is_refused_once_the_games_run(tmp_path):
     t2 = make_trainer("emu", 2, str(tmp_path / "missing"), 1, 20, 4, 1.0, 0.25, 2, 1, False, stagger=False)
     H.play_generation(t2, 2, 4, H.hash_net)
     assert not (tmp_path / "missing").exists()
+
+
+def test_a_shard_logs_the_games_it_owns(tmp_path):
+    """multi-GPU sharding (ca_config.game_base / total_games): the logged games are the first num_logged of the
+    GENERATION; each shard writes the ones it holds, under their generation-wide names"""
+    G, S_, spe, logged = 6, 40, 8, 4
+    a, b = tmp_path / "engine", tmp_path / "oracle"
+    a.mkdir()
+    b.mkdir()
+    o = O.Trainer(G, str(b), 9, S_, spe, 1.0, 0.25, logged, 1, False)
+    o.set_stagger(False)
+    H.play_generation(o, G, spe, H.hash_net)
+    for base in (0, 3):
+        t = make_trainer("emu", 3, str(a), 9, S_, spe, 1.0, 0.25, logged, 1, False, stagger=False, game_base=base, total_games=G)
+        H.play_generation(t, 3, spe, H.hash_net)
+    fa, fb = _files(a), _files(b)
+    assert list(fa) == list(fb) == ["game_%d.txt" % i for i in range(logged)]
+    assert fa == fb
