@@ -14,8 +14,14 @@ void tcheck(int rc) {
 
 Tourney::Tourney(int32_t num_threads, std::string log_folder) {
   (void)num_threads;  // host threads of the reference's OpenMP loop; matches run one wavefront each
-  (void)log_folder;   // match log files are host-side diagnostics of the reference; not produced on device
   tcheck(ca_tourney_create(0, 0, 0, &impl_));
+  // tourney.h:46: matches added with logging = true write <log_folder>/match_<p1>_<p2>_<index>.txt
+  const int rc = ca_tourney_set_log_folder(impl_, log_folder.c_str());
+  if (rc != CA_OK) {
+    ca_tourney_destroy(impl_);
+    impl_ = nullptr;
+    tcheck(rc);
+  }
 }
 
 Tourney::~Tourney() { ca_tourney_destroy(impl_); }

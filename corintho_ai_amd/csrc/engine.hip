@@ -128,7 +128,9 @@ struct ca_trainer {
   DevBuf<uint32_t> pend_leaf, pend_path, pend_n, noise_raw, rng;
   DevBuf<int32_t> pend_depth, req_offset, trace, all_done;
   DevBuf<int32_t> logbuf; /* per-game text logs: EngineParams::log */
-  std::string log_folder;
+  DevBuf<int32_t> log_index; /* tournament: EngineParams::log_index */
+  std::vector<int> log_game;          /* record k belongs to game log_game[k] ... */
+  std::vector<std::string> log_paths; /* ... and goes to this file */
   int num_logged = 0;
   bool logs_written = false;
   DevBuf<float> req, nn_in, nn_in70, nn_eval, nn_probs, samples;
@@ -418,40 +420,59 @@ struct ca_trainer {
     if (n < 0) n = 0;
     if (n > G) n = G;
     if (n > R) n = R; /* logged games start in their own slots (mcts.h) */
-    num_logged = n;
-    log_folder = folder ? folder : "";
-    if (n > 0) {
-      logbuf.alloc((size_t)n * CO_LOG_CAP, stream);
+    std::vector<int> games;
+    std::vector<std::string> paths;
+    for (int g = 0; g < n; ++g) {
+      games.push_back(g);
+      paths.push_back(std::string(folder ? folder : "") + "/game_" + std::to_string(cfg.game_base + g) + ".txt");
+    }
+    set_log_records(games, paths, false);
+  }
+
+  /* record k = game games[k], printed to paths[k]; with_index: the device finds a game's record through
+   * EngineParams::log_index (tournament matches added with logging = true) instead of "the first num_logged games" */
+  void set_log_records(const std::vector<int> &games, const std::vector<std::string> &paths, bool with_index) {
+    log_game = games;
+    log_paths = paths;
+    num_logged = (int)games.size();
+    if (num_logged > 0) {
+      logbuf.alloc((size_t)num_logged * CO_LOG_CAP, stream);
+      if (with_index) {
+        std::vector<int32_t> idx((size_t)G, -1);
+        for (int k = 0; k < num_logged; ++k) idx[(size_t)games[k]] = k;
+        log_index.alloc((size_t)G, stream);
+        rt_h2d(log_index.p, idx.data(), idx.size() * 4, stream);
+      }
       rt_sync(stream);
     } else {
       logbuf.release();
+      log_index.release();
     }
     P.log = logbuf.p;
-    P.num_logged = n;
+    P.num_logged = num_logged;
+    P.log_index = with_index ? log_index.p : nullptr;
     logs_written = false;
   }
 
   /* the files, once every game is over (the reference writes them as the games go; a file that cannot be opened is
    * skipped without a word there too: an ofstream in its fail state) */
   void maybe_write_logs() {
-    if (!logbuf.p || !finished || logs_written) return;
+    if (!logbuf.p || logs_written) return;
     logs_written = true;
     fetch_games();
     std::vector<int32_t> rec((size_t)num_logged * CO_LOG_CAP);
     rt_d2h(rec.data(), logbuf.p, rec.size() * 4, stream);
     rt_sync(stream);
-    for (int g = 0; g < num_logged; ++g) {
-      const int32_t *r = rec.data() + (size_t)g * CO_LOG_CAP;
+    for (int k = 0; k < num_logged; ++k) {
+      const int32_t *r = rec.data() + (size_t)k * CO_LOG_CAP;
       if (r[0] < 0 || r[0] > CO_LOG_CAP - 1)
-        throw EngineError(CA_ERR_ENGINE, "text log of game " + std::to_string(cfg.game_base + g) + " does not fit its record (" +
-                                             std::to_string(r[0]) + " words)");
-      const std::string path = log_folder + "/game_" + std::to_string(cfg.game_base + g) + ".txt";
-      FILE *f = fopen(path.c_str(), "w");
+        throw EngineError(CA_ERR_ENGINE, "text log " + log_paths[k] + " does not fit its record (" + std::to_string(r[0]) + " words)");
+      FILE *f = fopen(log_paths[k].c_str(), "w");
       if (!f) continue;
       CoLogWriter wr(f);
-      const bool ok = wr.write_game(r + 1, r[0], host_games[g].result);
+      const bool ok = wr.write_game(r + 1, r[0], host_games[log_game[k]].result);
       fclose(f);
-      if (!ok) throw EngineError(CA_ERR_ENGINE, "malformed text-log record of game " + std::to_string(cfg.game_base + g));
+      if (!ok) throw EngineError(CA_ERR_ENGINE, "malformed text-log record for " + log_paths[k]);
     }
   }
 
@@ -502,6 +523,7 @@ struct ca_trainer {
     P.trace = trace.p;
     P.log = logbuf.p;
     P.num_logged = num_logged;
+    P.log_index = log_index.p;
     P.all_done = all_done.p;
     P.row_counter = nullptr; /* counted in fused mode only */
     P.fused_pack = 0;
@@ -1326,6 +1348,9 @@ struct ca_tourney {
   int trace = 0;
   std::map<int, PlayerCfg> players;            /* Tourney::players_ (tourney.h:42) */
   std::vector<std::pair<int, int>> matches;    /* addMatch order */
+  std::vector<char> match_logging;             /* addMatch's `logging` */
+  std::string log_folder;                      /* Tourney::log_folder_ (tourney.h:46) */
+  bool seen_done = false;
   std::mt19937 generator;                      /* default constructed: seed 5489 (tourney.h:43) */
   std::vector<uint32_t> seeds;
   std::unique_ptr<ca_trainer> pool;            /* built at the first query after the last addMatch */
@@ -1394,6 +1419,18 @@ struct ca_tourney {
     p.scan_valid = false;
     p.host_games_valid = false;
     p.check_errors();
+    if (done) all_done(); /* (writes the match logs) */
+    return done;
+  }
+
+  /* Tourney::all_done (tourney.cpp:14-21); the log files of the matches are written the first time it is true */
+  bool all_done() {
+    ca_trainer &p = built();
+    const bool done = p.tourney_all_done();
+    if (done && !seen_done) {
+      seen_done = true;
+      p.maybe_write_logs();
+    }
     return done;
   }
 
@@ -1425,6 +1462,16 @@ struct ca_tourney {
     }
     t->match_seeds = seeds;
     t->init(c);
+    /* tourney.cpp:83-96: a match added with logging = true writes <log_folder>/match_<p1>_<p2>_<index>.txt */
+    std::vector<int> logged;
+    std::vector<std::string> paths;
+    for (size_t i = 0; i < matches.size(); ++i)
+      if (match_logging[i]) {
+        logged.push_back((int)i);
+        paths.push_back(log_folder + "/match_" + std::to_string(matches[i].first) + "_" + std::to_string(matches[i].second) + "_" +
+                        std::to_string(i) + ".txt");
+      }
+    if (!logged.empty()) t->set_log_records(logged, paths, true);
     if (exact_offsets) t->P.read_offset = nullptr; /* co_step_row falls back to the writeRequests rows */
     pool = std::move(t);
     return *pool;
@@ -1465,13 +1512,19 @@ extern "C" int ca_tourney_add_player(ca_tourney *t, int32_t player_id, int32_t m
 
 extern "C" int ca_tourney_add_match(ca_tourney *t, int32_t player1, int32_t player2, int32_t logging) {
   CA_GUARD({
-    (void)logging; /* match log files are not written */
     if (t->pool) throw EngineError(CA_ERR_STATE, "addMatch after the tournament has started");
     if (!t->players.count(player1) || !t->players.count(player2)) throw EngineError(CA_ERR_ARG, "addMatch: unknown player");
     if (t->players[player1].random && t->players[player2].random)
       throw EngineError(CA_ERR_ARG, "addMatch: at most one random player per match (match.cpp:72)");
     t->matches.emplace_back(player1, player2);
+    t->match_logging.push_back(logging ? 1 : 0);
     t->seeds.push_back((uint32_t)t->generator()); /* tourney.cpp:86 */
+  })
+}
+extern "C" int ca_tourney_set_log_folder(ca_tourney *t, const char *log_folder) {
+  CA_GUARD({
+    if (t->pool) throw EngineError(CA_ERR_STATE, "set_log_folder after the tournament has started");
+    t->log_folder = log_folder ? log_folder : "";
   })
 }
 
@@ -1495,7 +1548,7 @@ extern "C" int ca_tourney_set_exact_offsets(ca_tourney *t, int32_t on) {
 extern "C" int ca_tourney_run(ca_tourney *t, int64_t max_rounds, int32_t *all_done) {
   CA_GUARD(rt_set_device(t->device); *all_done = t->run(max_rounds) ? 1 : 0)
 }
-extern "C" int ca_tourney_all_done(ca_tourney *t, int32_t *out) { CA_GUARD(*out = t->built().tourney_all_done() ? 1 : 0) }
+extern "C" int ca_tourney_all_done(ca_tourney *t, int32_t *out) { CA_GUARD(*out = t->all_done() ? 1 : 0) }
 extern "C" int ca_tourney_num_requests(ca_tourney *t, int32_t id, int32_t *out) {
   CA_GUARD(rt_set_device(t->device); *out = t->built().tourney_num_requests(id))
 }

@@ -185,6 +185,7 @@ struct EngineParams {
    * writes the files when the games are over (engine.hip write_logs). */
   int32_t *log;         /* [num_logged][CO_LOG_CAP] or null */
   int32_t num_logged;
+  const int32_t *log_index; /* tournament: record of match i, or -1 (addMatch's `logging`); null = games 0 .. num_logged - 1 */
   int32_t *all_done;    /* [1] */
   unsigned long long *row_counter; /* [1] rows handed to the network so far */
   /* fused training mode: K3 packs its own requests.  pack_counter[iteration & 1] =

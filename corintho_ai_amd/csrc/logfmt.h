@@ -2,6 +2,7 @@
 // The search kernel records the numbers of every move choice (mcts.h co_log_ply, co_game_step); this file prints
 // them in the reference's layout:
 //   SelfPlayer::writePreMoveLogs / writeMoves / writeEval / writeMoveChoice   selfplayer.cpp:124-204
+//   (Match's copies of the four, match.cpp:78-159, and Match::endGame :163-190, print the same text)
 //   Node::writeMainLine                                                      node.cpp:197-240
 //   Game operator<<                                                          game.cpp:98-139
 //   Move operator<<                                                          move.cpp:56-78
@@ -85,6 +86,15 @@ struct CoLogWriter {
     fprintf(f, "Player %d to play", (int)CO_META_TO_PLAY(meta) + 1);
   }
 
+  /* writeMoveChoice: {move, board low, board high, meta of the new position} */
+  void put_choice(const int32_t *r) {
+    fputs("CHOSE MOVE ", f);
+    put_move(r[0]);
+    fputs("\nNEW POSITION:\n", f);
+    put_position((uint64_t)(uint32_t)r[1] | ((uint64_t)(uint32_t)r[2] << 32), (uint32_t)r[3]);
+    fputs("\n\n", f);
+  }
+
   struct Child {
     int move, visits, result;
     float evaluation, mean, probability;
@@ -95,6 +105,11 @@ struct CoLogWriter {
     int at = 0;
     auto need = [&](int n) { return at + n <= len; };
     while (at < len) {
+      if (need(5) && rec[at] == 2) { /* the move of a random player: no pre-move block (match.cpp:213-221) */
+        put_choice(rec + at + 1);
+        at += 5;
+        continue;
+      }
       if (!need(7) || rec[at] != 1) return false;
       const int to_play = rec[at + 1], depth = rec[at + 2], visits = rec[at + 3], result = rec[at + 4];
       const float evaluation = bits(rec[at + 5]);
@@ -150,11 +165,7 @@ struct CoLogWriter {
       }
       fputc('\n', f);
       if (!need(4)) return false;
-      fputs("CHOSE MOVE ", f);
-      put_move(rec[at]);
-      fputs("\nNEW POSITION:\n", f);
-      put_position((uint64_t)(uint32_t)rec[at + 1] | ((uint64_t)(uint32_t)rec[at + 2] << 32), (uint32_t)rec[at + 3]);
-      fputs("\n\n", f);
+      put_choice(rec + at);
       at += 4;
     }
     /* endGame, selfplayer.cpp:206-232 */

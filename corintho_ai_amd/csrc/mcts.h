@@ -859,6 +859,7 @@ CO_DEV void co_reset_tree_to_child(CoWave &w, CoTree &t, int choice) {
  *                                                                              node.cpp:197-240): most visits, then the
  *                                                                              larger evaluation; a lost child at once
  *   [after the choice, co_game_step] move, board low, board high, meta of the new position
+ * and for the move of a tournament's random player: 2, move, board low, board high, meta.
  * `ch` is the caller's scratch for one node's slots.  Logged games are few (Trainer's default is 10); their waves spend a
  * few microseconds here once per ply. */
 CO_DEV void co_log_put(CoWave &w, int &at, int32_t v) {
@@ -1273,6 +1274,15 @@ CO_DEV int co_game_step(CoWave &w, const float *eval, const float *probs) {
       terminal = (lm[0] | lm[1] | lm[2]) == 0u;
       tres = lines ? CO_RESULT_LOSS : CO_RESULT_DRAW;
       depth = w.gc.plies; /* root_->depth() */
+      if (w.log) { /* a random side has no pre-move block (match.cpp:213-221): record type 2 */
+        int at = w.log[0];
+        co_log_put(w, at, 2);
+        co_log_put(w, at, choice);
+        co_log_put(w, at, (int32_t)(uint32_t)board);
+        co_log_put(w, at, (int32_t)(uint32_t)(board >> 32));
+        co_log_put(w, at, (int32_t)meta);
+        co_log_commit(w, at);
+      }
     } else {
       CoTree &me = w.me;
       if (!w.pc) {
@@ -1517,7 +1527,11 @@ CO_DEV void co_mcts_step_wave(const EngineParams &P, int g) {
   /* samples and traces belong to the GAME, not to the slot */
   w.samples = P.samples ? P.samples + (size_t)gc.gid * CO_MAX_PLIES * CO_SAMPLE_FLOATS : (float *)0;
   w.trace = P.trace ? P.trace + (size_t)gc.gid * CO_TRACE_CAP : (int32_t *)0;
-  w.log = P.log && gc.gid < P.num_logged ? P.log + (size_t)gc.gid * CO_LOG_CAP : (int32_t *)0;
+  w.log = (int32_t *)0;
+  if (P.log) {
+    const int rec = P.log_index ? P.log_index[gc.gid] : gc.gid < P.num_logged ? gc.gid : -1;
+    if (rec >= 0) w.log = P.log + (size_t)rec * CO_LOG_CAP;
+  }
   w.prof = P.prof ? P.prof + (size_t)g * 16 : (unsigned long long *)0;
   w.max_searches = P.max_searches;
   w.spe = P.searches_per_eval;

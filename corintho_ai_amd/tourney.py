@@ -26,6 +26,8 @@ class Tourney:
         self._L = _cdll if _cdll is not None else _lib.load()
         self._t = C.c_void_p()
         _lib.check(self._L, self._L.ca_tourney_create(device, arena_units, int(bool(trace)), C.byref(self._t)))
+        if log_folder:  # tourney.h:46: matches added with logging=True write <log_folder>/match_<p1>_<p2>_<index>.txt
+            _lib.check(self._L, self._L.ca_tourney_set_log_folder(self._t, str(log_folder).encode()))
 
     def close(self):
         if getattr(self, "_t", None) and self._t.value:

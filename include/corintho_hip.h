@@ -235,14 +235,19 @@ int ca_trainer_prof(ca_trainer *t, unsigned long long out[36]);
  * ca_tourney_add_match.  Model ids are the caller's (negative = the dummy ids of random
  * players, tourney.pyx:131-134). ---- */
 typedef struct ca_tourney ca_tourney;
-/* Tourney(num_threads, log_folder), tourney.h:15 (threads and log folder have no device meaning) */
+/* Tourney(num_threads, log_folder), tourney.h:15 (threads have no device meaning; the folder: ca_tourney_set_log_folder) */
 int ca_tourney_create(int device, uint32_t arena_units, int trace, ca_tourney **out);
+/* Tourney::log_folder_ (tourney.h:46): where the matches added with logging = true write
+ * `match_<player1>_<player2>_<index>.txt` (tourney.cpp:90-95; the text of match.cpp:78-190).  Before the first query.
+ * The files are written when the last match is over (the reference writes them as the matches go); one that cannot
+ * be opened is skipped silently, as the reference's ofstream is. */
+int ca_tourney_set_log_folder(ca_tourney *t, const char *log_folder);
 void ca_tourney_destroy(ca_tourney *t);
 /* Tourney::addPlayer, tourney.cpp:72-78 */
 int ca_tourney_add_player(ca_tourney *t, int32_t player_id, int32_t model_id, int32_t max_searches,
                           int32_t searches_per_eval, float c_puct, float epsilon, int32_t random);
 /* Tourney::addMatch, tourney.cpp:80-96: the match's generator is seeded with the next output of
- * the tourney's default-constructed std::mt19937; `logging` is accepted and ignored */
+ * the tourney's default-constructed std::mt19937; `logging`: the match writes its text log (ca_tourney_set_log_folder) */
 int ca_tourney_add_match(ca_tourney *t, int32_t player1, int32_t player2, int32_t logging);
 /* Tourney::all_done, tourney.cpp:14-21 */
 int ca_tourney_all_done(ca_tourney *t, int32_t *out);

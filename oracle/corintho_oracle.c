@@ -1034,7 +1034,7 @@ static void trace_root(selfplayer_t *sp) {
 /* ---- per-game text logs: selfplayer.cpp:124-204, node.cpp:197-254, game.cpp:98-139, move.cpp:56-78, util.cpp:5-25.
  * A C++ ostream prints a float with operator<< as printf's %g would (precision 6) until a manipulator changes
  * the stream; writeEval's std::fixed << std::setprecision(6) does, for good. */
-static void log_float(selfplayer_t *sp, float v) { fprintf(sp->log, sp->log_fixed ? "%.6f" : "%g", (double)v); }
+static void lg_float(FILE *f, int *fixed, float v) { fprintf(f, *fixed ? "%.6f" : "%g", (double)v); }
 
 static const char *str_result(int r) { /* util.cpp:5-25 */
   switch (r) {
@@ -1076,18 +1076,18 @@ static void log_game(FILE *f, const game_t *g) { /* game.cpp:98-139 */
   fprintf(f, "Player %d to play", g->to_play + 1);
 }
 
-/* selfplayer.cpp:124-134 */
-static void log_eval(selfplayer_t *sp, const node_t *n) {
+/* selfplayer.cpp:124-134 = match.cpp:78-88 */
+static void log_eval(FILE *f, int *fixed, const node_t *n) {
   if (n->result != kResultNone) {
-    fputs(str_result(n->result), sp->log);
+    fputs(str_result(n->result), f);
     return;
   }
-  sp->log_fixed = 1;
-  log_float(sp, n->evaluation / (float)n->visits);
+  *fixed = 1;
+  lg_float(f, fixed, n->evaluation / (float)n->visits);
 }
 
 /* node.cpp:197-240: the line of most-visited children (a lost child ends the choice at once) */
-static void log_main_line(selfplayer_t *sp, const node_t *n) {
+static void log_main_line(FILE *f, int *fixed, const node_t *n) {
   const node_t *cur = n->first_child, *best = NULL;
   int max_visits = 0, edge_index = 0;
   float max_eval = 0.0f, prob = 0.0f;
@@ -1110,15 +1110,15 @@ static void log_main_line(selfplayer_t *sp, const node_t *n) {
     ++edge_index;
   }
   if (best != NULL) {
-    fprintf(sp->log, "%d. ", (int)best->depth);
-    log_move(sp->log, best->child_id);
-    fprintf(sp->log, " V: %d E: ", max_visits);
-    if (best->result != kResultNone) fputs(str_result(best->result), sp->log);
-    else log_float(sp, max_eval / (float)max_visits);
-    fputs(" p: ", sp->log);
-    log_float(sp, prob);
-    fputc('\t', sp->log);
-    log_main_line(sp, best);
+    fprintf(f, "%d. ", (int)best->depth);
+    log_move(f, best->child_id);
+    fprintf(f, " V: %d E: ", max_visits);
+    if (best->result != kResultNone) fputs(str_result(best->result), f);
+    else lg_float(f, fixed, max_eval / (float)max_visits);
+    fputs(" p: ", f);
+    lg_float(f, fixed, prob);
+    fputc('\t', f);
+    log_main_line(f, fixed, best);
   }
 }
 
@@ -1129,7 +1129,7 @@ typedef struct {
   const node_t *node;
 } log_move_data;
 
-static int log_move_cmp(const void *pa, const void *pb) { /* selfplayer.cpp:164-173 */
+static int log_move_cmp(const void *pa, const void *pb) { /* selfplayer.cpp:164-173 = match.cpp:121-131 */
   const log_move_data *a = (const log_move_data *)pa, *b = (const log_move_data *)pb;
   if (a->visits != b->visits) return a->visits > b->visits ? -1 : 1;
   if (a->evaluation != b->evaluation) return a->evaluation > b->evaluation ? -1 : 1;
@@ -1137,12 +1137,11 @@ static int log_move_cmp(const void *pa, const void *pb) { /* selfplayer.cpp:164-
   return a->move < b->move ? -1 : a->move > b->move ? 1 : 0;
 }
 
-/* selfplayer.cpp:136-183 */
-static void log_moves(selfplayer_t *sp) {
-  const node_t *root = sp->players[sp->to_play].root;
-  fputs("LEGAL MOVES:\n", sp->log);
-  log_main_line(sp, root);
-  fputc('\n', sp->log);
+/* selfplayer.cpp:136-183 = match.cpp:90-139 */
+static void log_moves(FILE *f, int *fixed, const node_t *root) {
+  fputs("LEGAL MOVES:\n", f);
+  log_main_line(f, fixed, root);
+  fputc('\n', f);
   log_move_data moves[CO_NUM_MOVES];
   int n = 0, edge_index = 0;
   for (const node_t *cur = root->first_child; cur != NULL;) {
@@ -1159,34 +1158,36 @@ static void log_moves(selfplayer_t *sp) {
   }
   qsort(moves, (size_t)n, sizeof moves[0], log_move_cmp); /* (a total order: std::sort gives the same sequence) */
   for (int i = 1; i < n; ++i) { /* the first one is in the main line already */
-    log_move(sp->log, moves[i].move);
-    fprintf(sp->log, " V: %d E: ", moves[i].visits);
-    log_eval(sp, moves[i].node);
-    fputs(" P: ", sp->log);
-    log_float(sp, moves[i].probability);
-    fputc('\t', sp->log);
+    log_move(f, moves[i].move);
+    fprintf(f, " V: %d E: ", moves[i].visits);
+    log_eval(f, fixed, moves[i].node);
+    fputs(" P: ", f);
+    lg_float(f, fixed, moves[i].probability);
+    fputc('\t', f);
   }
-  fputc('\n', sp->log);
+  fputc('\n', f);
 }
 
-/* selfplayer.cpp:185-197 */
-static void log_pre_move(selfplayer_t *sp) {
-  const node_t *root = sp->players[sp->to_play].root;
-  fprintf(sp->log, "TURN %d\nPLAYER %d TO PLAY\nVISITS: %d\n", (int)root->depth, sp->to_play + 1, (int)root->visits);
-  fputs("POSITION EVALUATION: ", sp->log);
-  log_eval(sp, root);
-  fputc('\n', sp->log);
-  log_moves(sp);
+/* selfplayer.cpp:185-197 = match.cpp:141-153 */
+static void log_pre_move_of(FILE *f, int *fixed, const node_t *root, int to_play) {
+  fprintf(f, "TURN %d\nPLAYER %d TO PLAY\nVISITS: %d\n", (int)root->depth, to_play + 1, (int)root->visits);
+  fputs("POSITION EVALUATION: ", f);
+  log_eval(f, fixed, root);
+  fputc('\n', f);
+  log_moves(f, fixed, root);
 }
 
-/* selfplayer.cpp:199-204 */
-static void log_move_choice(selfplayer_t *sp, int choice) {
-  fputs("CHOSE MOVE ", sp->log);
-  log_move(sp->log, choice);
-  fputs("\nNEW POSITION:\n", sp->log);
-  log_game(sp->log, &sp->players[sp->to_play].root->game);
-  fputs("\n\n", sp->log);
+/* selfplayer.cpp:199-204 = match.cpp:155-159 */
+static void log_move_choice_of(FILE *f, int choice, const game_t *after) {
+  fputs("CHOSE MOVE ", f);
+  log_move(f, choice);
+  fputs("\nNEW POSITION:\n", f);
+  log_game(f, after);
+  fputs("\n\n", f);
 }
+
+static void log_pre_move(selfplayer_t *sp) { log_pre_move_of(sp->log, &sp->log_fixed, sp->players[sp->to_play].root, sp->to_play); }
+static void log_move_choice(selfplayer_t *sp, int choice) { log_move_choice_of(sp->log, choice, &sp->players[sp->to_play].root->game); }
 
 /* ref: selfplayer.cpp:206-232 */
 static void sp_end_game(selfplayer_t *sp) {
@@ -1636,6 +1637,8 @@ typedef struct {
   int trace_on;
   int32_t *trace;
   int n_trace, cap_trace;
+  FILE *log; /* Match::log_file_ (match.h:98-101) */
+  int log_fixed;
 } match_t;
 
 static void match_trace_push(match_t *m, int32_t v) {
@@ -1673,6 +1676,7 @@ static void match_free(match_t *m) {
   if (m->root) node_delete(m->root);
   free(m->to_eval);
   free(m->trace);
+  if (m->log) fclose(m->log);
   free(m);
 }
 
@@ -1695,6 +1699,12 @@ static void match_end_game(match_t *m) {
   if (m->root->result == kResultDraw) m->result = kResultDraw;
   else if (m->to_play == 1) m->result = kResultLoss;
   else m->result = kResultWin;
+  if (m->log) { /* match.cpp:173-179, 190 */
+    if (m->result == kResultDraw) fputs("GAME IS DRAWN.\n", m->log);
+    else fprintf(m->log, "PLAYER %d WON!\n", m->to_play + 1);
+    fclose(m->log);
+    m->log = NULL;
+  }
   for (int i = 0; i < 2; ++i)
     if (!m->is_random[i]) mc_null_root(&m->players[i]);
   free(m->to_eval);
@@ -1738,10 +1748,12 @@ static int match_choose_move(match_t *m) {
 static int match_choose_move_and_continue(match_t *m) {
   int need_eval = 0;
   while (!need_eval) {
+    if (m->log && !m->is_random[m->to_play]) log_pre_move_of(m->log, &m->log_fixed, m->players[m->to_play].root, m->to_play);
     int choice = match_choose_move(m);
     node_t *next = node_new_child(&m->root->game, NULL, NULL, choice, m->root->depth + 1, &m->root_ctr);
     node_delete(m->root);
     m->root = next;
+    if (m->log) log_move_choice_of(m->log, choice, &m->root->game);
     if (n_terminal(m->root)) {
       match_end_game(m);
       return 1;
@@ -1806,8 +1818,12 @@ int co_tourney_add_player(co_tourney *t, int player_id, int model_id, int max_se
   return 0;
 }
 
-/* ref: tourney.cpp:80-96 (log files are not part of the restatement) */
-int co_tourney_add_match(co_tourney *t, int player1, int player2) {
+/* ref: tourney.cpp:80-96.  log_folder non-null = addMatch(..., logging = true) of a Tourney built with that folder: the
+ * match writes `<log_folder>/match_<player1>_<player2>_<index>.txt` (an unopenable file is skipped silently, like the
+ * reference's ofstream) */
+int co_tourney_add_match_logged(co_tourney *t, int player1, int player2, const char *log_folder);
+int co_tourney_add_match(co_tourney *t, int player1, int player2) { return co_tourney_add_match_logged(t, player1, player2, NULL); }
+int co_tourney_add_match_logged(co_tourney *t, int player1, int player2, const char *log_folder) {
   if (player1 < 0 || player1 >= CO_TOURNEY_MAX_PLAYERS || !t->has_player[player1]) return -1;
   if (player2 < 0 || player2 >= CO_TOURNEY_MAX_PLAYERS || !t->has_player[player2]) return -1;
   if (t->n_matches == t->cap_matches) {
@@ -1817,6 +1833,11 @@ int co_tourney_add_match(co_tourney *t, int player1, int player2) {
   }
   match_t *m = match_new(mt_next(&t->generator), &t->players[player1], &t->players[player2]);
   m->trace_on = t->trace_on;
+  if (log_folder) {
+    char path[4096];
+    snprintf(path, sizeof path, "%s/match_%d_%d_%d.txt", log_folder, player1, player2, t->n_matches);
+    m->log = fopen(path, "w");
+  }
   t->matches[t->n_matches] = m;
   t->is_done[t->n_matches] = 0;
   return t->n_matches++;

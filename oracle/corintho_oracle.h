@@ -126,6 +126,8 @@ void co_tourney_destroy(co_tourney *t);
 int co_tourney_add_player(co_tourney *t, int player_id, int model_id, int max_searches, int searches_per_eval,
                           float c_puct, float epsilon, int random);
 int co_tourney_add_match(co_tourney *t, int player1, int player2); /* returns the match index */
+/* addMatch(player1, player2, logging = true) of a Tourney(num_threads, log_folder): `<log_folder>/match_<p1>_<p2>_<index>.txt` */
+int co_tourney_add_match_logged(co_tourney *t, int player1, int player2, const char *log_folder);
 int co_tourney_all_done(const co_tourney *t);
 int co_tourney_num_requests(const co_tourney *t, int id);
 void co_tourney_write_requests(const co_tourney *t, float *game_states, int id);

@@ -109,6 +109,8 @@ def lib():
     L.co_tourney_add_player.restype = C.c_int
     L.co_tourney_add_match.argtypes = [vp, C.c_int, C.c_int]
     L.co_tourney_add_match.restype = C.c_int
+    L.co_tourney_add_match_logged.argtypes = [vp, C.c_int, C.c_int, C.c_char_p]
+    L.co_tourney_add_match_logged.restype = C.c_int
     L.co_tourney_all_done.argtypes = [vp]
     L.co_tourney_all_done.restype = C.c_int
     L.co_tourney_num_requests.argtypes = [vp, C.c_int]
@@ -387,6 +389,7 @@ class Tourney:
     """The reference's Tourney surface (tourney.h:13-46 / rating/tourney.pyx:15-31) on the oracle."""
 
     def __init__(self, num_threads=1, log_folder="", trace=False):
+        self._log_folder = str(log_folder)
         self._t = lib().co_tourney_create(num_threads)
         if trace:
             lib().co_tourney_enable_trace(self._t, 1)
@@ -403,7 +406,8 @@ class Tourney:
             raise ValueError("addPlayer")
 
     def addMatch(self, player1, player2, logging=False):
-        if lib().co_tourney_add_match(self._t, player1, player2) < 0:
+        # logging: the match writes <log_folder>/match_<player1>_<player2>_<index>.txt (tourney.cpp:83-96)
+        if lib().co_tourney_add_match_logged(self._t, player1, player2, self._log_folder.encode() if logging else None) < 0:
             raise ValueError("addMatch: unknown player")
 
     def all_done(self):

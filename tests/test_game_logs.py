@@ -96,3 +96,69 @@ def test_a_shard_logs_the_games_it_owns(tmp_path):
     fa, fb = _files(a), _files(b)
     assert list(fa) == list(fb) == ["game_%d.txt" % i for i in range(logged)]
     assert fa == fb
+
+
+# ---- Match logs of a tournament (Tourney::addMatch(..., logging = true), tourney.cpp:83-96; match.cpp:78-190)
+T_PLAYERS = [(0, 0, 40, 8, 1.0, 0.25, False), (1, 1, 24, 4, 1.5, 0.25, False), (2, 0, 16, 16, 1.0, 0.0, False),
+             (3, -1, 0, 0, 1.0, 0.25, True)]
+T_MATCHES = [(0, 1, True), (1, 0, False), (2, 1, True), (0, 3, True), (3, 1, True), (0, 2, False), (2, 3, True)]
+
+
+def _tourney(factory):
+    t = factory()
+    for p in T_PLAYERS:
+        t.addPlayer(*p)
+    for a, b, lg in T_MATCHES:
+        t.addMatch(a, b, lg)
+    return t
+
+
+@pytest.mark.parametrize("engine", ENGINES)
+def test_match_logs_match_the_oracle(engine, tmp_path):
+    from corintho_ai_amd.tourney import Tourney
+    from tests.engines import cdll
+
+    a, b = tmp_path / "engine", tmp_path / "oracle"
+    a.mkdir()
+    b.mkdir()
+    e = _tourney(lambda: Tourney(1, str(a), _cdll=cdll(engine)))
+    o = _tourney(lambda: O.Tourney(1, str(b)))
+    nets_by_model = {0: lambda s: H.hash_net(s, 11), 1: lambda s: H.hash_net(s, 22)}
+    rows = sum(T_PLAYERS[x][3] + T_PLAYERS[y][3] for x, y, _ in T_MATCHES)
+    H.play_tourney(e, [-1, 0, 1], nets_by_model, rows)
+    H.play_tourney(o, [-1, 0, 1], nets_by_model, rows)
+    fa, fb = _files(a), _files(b)
+    want = sorted("match_%d_%d_%d.txt" % (x, y, i) for i, (x, y, lg) in enumerate(T_MATCHES) if lg)
+    assert list(fa) == list(fb) == want
+    for name in fa:
+        assert fa[name] == fb[name], "%s differs from the oracle's log" % name
+    # a match against the random player logs the searcher's turns only, and every chosen move
+    txt = fa["match_0_3_3.txt"].decode()
+    assert txt.count("CHOSE MOVE") > txt.count("TURN ") > 0 and "PLAYER 2 TO PLAY" not in txt
+
+
+@pytest.mark.parametrize("engine", ENGINES)
+def test_match_logs_of_a_fused_tournament(engine, tmp_path):
+    """networks on the device (ca_tourney_run); the oracle replays with the same kernels' outputs"""
+    from corintho_ai_amd.tourney import Tourney
+    from tests.engines import cdll
+
+    a, b = tmp_path / "engine", tmp_path / "oracle"
+    a.mkdir()
+    b.mkdir()
+    weights = {0: nets.init_mlp12x100(seed=5, bn_noise=True), 1: nets.init_mlp12x100(seed=6, bn_noise=True)}
+    f = _tourney(lambda: Tourney(1, str(a), _cdll=cdll(engine)))
+    for mid, w in weights.items():
+        f.set_net(mid, 1, w)
+    assert f.run()
+    evaluators = {}
+    for mid, w in weights.items():
+        t = make_trainer(engine, 64, "", 1, 50, 16, 1.0, 0.25, 0, 1, False)
+        t.set_net(1, w)
+        evaluators[mid] = t
+    o = _tourney(lambda: O.Tourney(1, str(b)))
+    rows = sum(T_PLAYERS[x][3] + T_PLAYERS[y][3] for x, y, _ in T_MATCHES)
+    H.play_tourney(o, [-1, 0, 1], {mid: (lambda s, t=t: t.net_forward(s)) for mid, t in evaluators.items()}, rows)
+    fa, fb = _files(a), _files(b)
+    assert list(fa) == list(fb) and len(fa) == sum(lg for _, _, lg in T_MATCHES)
+    assert fa == fb
