@@ -419,7 +419,9 @@ struct ca_trainer {
     n -= cfg.game_base; /* a shard logs the games of the generation's first num_logged that it owns */
     if (n < 0) n = 0;
     if (n > G) n = G;
-    if (n > R) n = R; /* logged games start in their own slots (mcts.h) */
+    if (n > R) /* logged games start in their own slots (mcts.h): fewer slots than logged games would write fewer files than the reference */
+      throw EngineError(CA_ERR_ARG, "ca_trainer_set_logging: " + std::to_string(n) + " logged games on " + std::to_string(R) +
+                                        " resident slots -- a logged game must start in its own slot; raise ca_config.resident");
     std::vector<int> games;
     std::vector<std::string> paths;
     for (int g = 0; g < n; ++g) {
@@ -584,6 +586,7 @@ struct ca_trainer {
   }
 
   void check_errors() {
+    check_net_range();
     if (scan_valid && !any_error) return; /* the last scan saw no error bit in any game */
     fetch_games();
     for (int g = 0; g < G; ++g) {
@@ -902,9 +905,41 @@ struct ca_trainer {
   /* ------------------------------------------------------------ fused mode */
   void set_net(int slot, int kind, const float *weights, size_t n) {
     if (slot < 0 || slot > 1) throw EngineError(CA_ERR_ARG, "net slot must be 0 or 1");
-    nets[slot].reset(co_net_create(kind, weights, n, (size_t)R * spe, stream));
-    if (!nets[slot]) throw EngineError(CA_ERR_ARG, "unknown net kind or bad weight count");
-    if (slot == 0 && !pools.empty() && (pools[0].cache.hdr != nullptr) != use_cache()) free_pools(); /* rebuilt with / without tables */
+    std::unique_ptr<CoNet> fresh;
+    try {
+      fresh.reset(co_net_create(kind, weights, n, (size_t)R * spe, stream));
+    } catch (const std::invalid_argument &e) { /* weights outside the kind's operand range (nn.h range_exceeded) */
+      throw EngineError(CA_ERR_ARG, e.what());
+    }
+    if (!fresh) throw EngineError(CA_ERR_ARG, "unknown net kind or bad weight count");
+    if (slot == 0 && !pools.empty()) {
+      /* Does the new network change whether fused training keeps an evaluation cache?  The tables are part of the
+       * pools, and in the middle of a generation the pending leaves point into them (pend_src): refuse that. */
+      std::unique_ptr<CoNet> old = std::move(nets[0]);
+      nets[0] = std::move(fresh);
+      const bool toggles = (pools[0].cache.hdr != nullptr) != use_cache();
+      if (toggles && iterations > 0 && !finished) {
+        nets[0] = std::move(old);
+        throw EngineError(CA_ERR_STATE, "ca_trainer_set_net: this network turns the evaluation cache " +
+                                            std::string(pools[0].cache.hdr ? "off" : "on") +
+                                            " in the middle of a generation; finish or reset the generation first");
+      }
+      if (toggles) free_pools(); /* rebuilt with / without tables */
+    } else {
+      nets[slot] = std::move(fresh);
+    }
+    /* entries filled by the previous network must not serve the new one: the next run empties the tables (the value
+     * elements the pending leaves point to stay: those rows WERE evaluated by the network in place when they were queued) */
+    if (slot == 0) cache_clean = false;
+  }
+
+  /* nn.h range_exceeded: an f16x3 network met an operand beyond fp16's range -- its outputs since are NaN or wrong */
+  void check_net_range() {
+    for (int slot = 0; slot < 2; ++slot)
+      if (nets[slot] && nets[slot]->range_exceeded(stream))
+        throw EngineError(CA_ERR_ENGINE, std::string("network slot ") + std::to_string(slot) +
+                                             ": an activation left the fp16 range of the f16x3 kernels (|x| > 65504); the evaluations "
+                                             "are not valid -- use the float32-equivalent x6 kind of the same network");
   }
 
   /* host rows in, host results out (ca_trainer_net_forward): persistent device buffers; the rows travel as
@@ -927,6 +962,7 @@ struct ca_trainer {
     rt_d2h(evals, fw_ev.p, (size_t)n * 4, stream);
     rt_d2h(probs, fw_pr.p, (size_t)n * CO_NUM_MOVES * 4, stream);
     rt_sync(stream);
+    check_net_range();
   }
 
   void net_forward_rows(int slot, const float *d_in, int32_t rows_cap, const int32_t *d_rows, float *d_eval,

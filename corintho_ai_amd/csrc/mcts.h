@@ -492,18 +492,6 @@ CO_DEV void co_propagate_terminal(CoTree &t, const uint32_t *path_block, const u
       if (!all_known) return;
       uint4 s = co_load_unit(A, path_slot[d]);
       int has_draw = co_res_drawn(co_slot_result(s)); /* the PARENT's own result, as trainmc.cpp:518 */
-#ifdef CO_ABLATE_QUIRK1 /* experiment builds only (tools/exp/quirk_ablation.py): the evident intent -- a drawn CHILD */
-      has_draw = 0;
-      for (int base = 0; base < n; base += CO_WAVE) {
-        LV(int, dr);
-        FOR_LANES {
-          int e = base + lane;
-          L(dr) = 0;
-          if (e < n) L(dr) = co_res_drawn(co_slot_result(A[pb + 2 + e]));
-        }
-        if (WAVE_BALLOT(dr)) has_draw = 1;
-      }
-#endif
       co_store_unit(A, path_slot[d], co_slot_set_result(s, has_draw ? CO_DEDUCED_DRAW : CO_DEDUCED_LOSS));
     }
   }
@@ -633,9 +621,6 @@ CO_DEV void co_search(CoWave &w, CoTree &t, CoRoot &rc) {
           double b = co_div_small((double)pv, cv + 1.0f);
           float uv = (float)(a + b);
           float uc = drawn ? pv : uv;           /* visited child (trainmc.cpp:561-569; a drawn one without the /(n + 1): quirk 6) */
-#ifdef CO_ABLATE_QUIRK6 /* experiment builds only: the drawn child's term divided like the others */
-          uc = drawn ? (float)b : uv;
-#endif
           uc = searchable ? uc : CO_NEG_INF;
           uu = has_child ? uc : pv;             /* unvisited edge (:575-577) */
           uu = e < n ? uu : CO_NEG_INF;

@@ -26,8 +26,7 @@
 /* two fp16 terms per operand (22 significand bits), three MFMA products: float32-class arithmetic at the cost of bf16x3 */
 #define CO_NET_RESCNN4_H3 8
 #define CO_NET_MLP12X100_H3 9
-/* experiment (-DCO_WINOGRAD builds only): rescnn4 at the same split precision, 3x3 convolutions as Winograd F(2x2, 3x3) */
-#define CO_NET_RESCNN4_W6 7
+/* (7 was round 2's Winograd experiment, tools/exp/archive) */
 
 /* mlp12x100 flat weight layout (float32), matching Keras get_weights() order of
  * wrapper.py:256-271:
@@ -58,6 +57,14 @@ struct CoNet {
                        rt_stream_t s, const CoNetIO &io = CoNetIO()) = 0;
   /* algorithmic flop per row, for the roofline */
   virtual double flop_per_row() const = 0;
+  /* The f16x3 kinds hold every operand as two fp16 terms: a folded weight or an activation beyond fp16's largest
+   * finite value (CO_F16_MAX) would convert to infinity and the evaluation to NaN without a word.  Weights are checked
+   * when the net is created (std::invalid_argument); the kernels track the largest activation they split and raise a
+   * flag on the device, which this call reads (a 4-byte copy and a wait on `s`): true = some evaluation since the
+   * net was created left the range, its outputs are not to be trusted -- the engine turns that into an error and names
+   * the float32-equivalent x6 kind.  Kinds with float32's exponent range never report. */
+  virtual bool range_exceeded(rt_stream_t) { return false; }
 };
+#define CO_F16_MAX 65504.0f
 
 CoNet *co_net_create(int kind, const float *weights, size_t n_floats, size_t max_rows, rt_stream_t s);

@@ -252,18 +252,12 @@ struct MlpNet : CoNet {
 CoNet *co_rescnn_create(const float *weights, size_t n_floats, size_t max_rows, rt_stream_t s);
 CoNet *co_rescnn_split_create(const float *weights, size_t n_floats, size_t max_rows, rt_stream_t s, int nterms, bool f16 = false);
 CoNet *co_mlp_split_create(const float *weights, size_t n_floats, size_t max_rows, rt_stream_t s, int nterms, bool f16 = false);
-#ifdef CO_WINOGRAD
-CoNet *co_rescnn_wino_create(const float *weights, size_t n_floats, size_t max_rows, rt_stream_t s);
-#endif
 
 CoNet *co_net_create(int kind, const float *weights, size_t n_floats, size_t max_rows, rt_stream_t s) {
   if (kind == CO_NET_MLP12X100 && n_floats == (size_t)CO_MLP_NUM_WEIGHTS) return new MlpNet(weights, max_rows, s);
   if (kind == CO_NET_RESCNN4) return co_rescnn_create(weights, n_floats, max_rows, s);
   if (kind == CO_NET_RESCNN4_X3) return co_rescnn_split_create(weights, n_floats, max_rows, s, 2);
   if (kind == CO_NET_RESCNN4_X6) return co_rescnn_split_create(weights, n_floats, max_rows, s, 3);
-#ifdef CO_WINOGRAD
-  if (kind == CO_NET_RESCNN4_W6) return co_rescnn_wino_create(weights, n_floats, max_rows, s);
-#endif
   if (kind == CO_NET_MLP12X100_X3) return co_mlp_split_create(weights, n_floats, max_rows, s, 2);
   if (kind == CO_NET_MLP12X100_X6) return co_mlp_split_create(weights, n_floats, max_rows, s, 3);
   if (kind == CO_NET_RESCNN4_H3) return co_rescnn_split_create(weights, n_floats, max_rows, s, 2, true);

@@ -180,7 +180,7 @@ __device__ __forceinline__ void m3_init_bias(m3_f32x16 (&acc)[4], const float *b
 template <int NT, bool F16 = false>
 __global__ __launch_bounds__(256, 1) void co_k_mlp_forward_split_t(const float *__restrict__ in, const int32_t *__restrict__ d_rows,
                                                                    const uint32_t *__restrict__ wfrag, float *__restrict__ eval,
-                                                                   float *__restrict__ probs, CoNetIO io) {
+                                                                   float *__restrict__ probs, CoNetIO io, uint32_t *range_flag) {
   static_assert(M3_CHUNK_PIECES_PER_WAVE(2) == 9 && M3_CHUNK_PIECES_PER_WAVE(3) == 13, "vmcnt immediates of M3_CHUNK_HEAD");
   extern __shared__ __attribute__((aligned(16))) uint32_t m3_lds[]; /* ring of three chunk slots */
   const int rows = *d_rows;
@@ -221,6 +221,7 @@ __global__ __launch_bounds__(256, 1) void co_k_mlp_forward_split_t(const float *
   m3_stage<NT>(wfrag, lds_base, 0, wave, lane);
   m3_stage<NT>(wfrag, lds_base + M3_CHUNK_WORDS(NT) * 4u, 1, wave, lane);
   m3_f32x16 acc[4];
+  float amax = 0.0f; /* F16: the largest activation split into fp16 terms (nn.h range_exceeded) */
   for (int l = 0; l < M3_NLAYERS; ++l) {
     const int c0 = 2 * l;
     {
@@ -248,12 +249,16 @@ __global__ __launch_bounds__(256, 1) void co_k_mlp_forward_split_t(const float *
             float v0 = acc[T][8 * a + 2 * m], v1 = acc[T][8 * a + 2 * m + 1];
             v0 = v0 > 0.0f ? v0 : 0.0f;
             v1 = v1 > 0.0f ? v1 : 0.0f;
+            if constexpr (F16) amax = __builtin_fmaxf(amax, __builtin_fmaxf(v0, v1));
             uint32_t t[NT];
             m3_split<NT, F16>(v0, v1, t);
 #pragma unroll
             for (int i = 0; i < NT; ++i) b[i][2 * T + a][m] = t[i];
           }
     }
+  }
+  if constexpr (F16) {
+    if (!(amax <= CO_F16_MAX)) atomicOr(range_flag, 1u); /* (never in range: no lane enters) */
   }
   /* heads: features 0..95 = policy logits (tiles 0..2), feature 96 = value (tile 3, g 0, h 0, i 0) */
   float mx = -INFINITY;
@@ -318,6 +323,7 @@ static inline float m3_f16_to_f(uint16_t u) {
 
 struct MlpSplitNet : CoNet {
   uint32_t *d_w = nullptr;
+  uint32_t *d_range = nullptr; /* f16: the kernels' out-of-range flag */
   size_t cap;
   int nt;
   bool f16;
@@ -382,6 +388,9 @@ struct MlpSplitNet : CoNet {
                 int k = 32 * T + 8 * (2 * a + (j >> 2)) + 4 * h + (j & 3);
                 int o = 32 * to + i;
                 float v = k < kin[l] ? (float)K[l][(size_t)k * 128 + o] : 0.0f;
+                if (f16 && !(fabsf(v) <= CO_F16_MAX))
+                  throw std::invalid_argument("mlp12x100h3: a weight of layer " + std::to_string(l) + " is " + std::to_string(v) +
+                                              " after the BatchNorm fold, beyond the fp16 range of the f16x3 kernels: use mlp12x100x6");
                 size_t lane = 32 * h + i;
                 for (int t = 0; t < nt; ++t) {
                   uint16_t term = f16 ? m3_f16_rne(v) : m3_bf16_rne(v);
@@ -397,6 +406,7 @@ struct MlpSplitNet : CoNet {
     }
     rt_malloc((void **)&d_w, buf.size() * 4, s);
     rt_h2d(d_w, buf.data(), buf.size() * 4, s);
+    if (f16) rt_malloc((void **)&d_range, 4, s);
     rt_sync(s);
     if (f16)
       RT_CHECK(hipFuncSetAttribute((const void *)co_k_mlp_forward_h3, hipFuncAttributeMaxDynamicSharedMemorySize, M3_LDS_BYTES(2)));
@@ -405,7 +415,17 @@ struct MlpSplitNet : CoNet {
     else
       RT_CHECK(hipFuncSetAttribute((const void *)co_k_mlp_forward_x6, hipFuncAttributeMaxDynamicSharedMemorySize, M3_LDS_BYTES(3)));
   }
-  ~MlpSplitNet() override { rt_free(d_w); }
+  ~MlpSplitNet() override {
+    rt_free(d_w);
+    rt_free(d_range);
+  }
+  bool range_exceeded(rt_stream_t s) override {
+    if (!d_range) return false;
+    uint32_t flag = 0;
+    rt_d2h(&flag, d_range, 4, s);
+    rt_sync(s);
+    return flag != 0;
+  }
   size_t max_rows() const override { return cap; }
   int kind() const override { return f16 ? CO_NET_MLP12X100_H3 : nt == 2 ? CO_NET_MLP12X100_X3 : CO_NET_MLP12X100_X6; }
   double flop_per_row() const override { return 2.0 * (70 * 100 + 11 * 100 * 100 + 100 + 100 * 96); }
@@ -415,13 +435,13 @@ struct MlpSplitNet : CoNet {
     if (grid < 1) return;
     if (f16)
       hipLaunchKernelGGL(co_k_mlp_forward_h3, dim3(grid), dim3(256), M3_LDS_BYTES(2), s, d_in, d_rows, (const uint32_t *)d_w, d_eval,
-                         d_probs, io);
+                         d_probs, io, d_range);
     else if (nt == 2)
       hipLaunchKernelGGL(co_k_mlp_forward_x3, dim3(grid), dim3(256), M3_LDS_BYTES(2), s, d_in, d_rows, (const uint32_t *)d_w, d_eval,
-                         d_probs, io);
+                         d_probs, io, d_range);
     else
       hipLaunchKernelGGL(co_k_mlp_forward_x6, dim3(grid), dim3(256), M3_LDS_BYTES(3), s, d_in, d_rows, (const uint32_t *)d_w, d_eval,
-                         d_probs, io);
+                         d_probs, io, d_range);
     RT_CHECK(hipGetLastError());
   }
 };

@@ -421,6 +421,7 @@ struct Rc3Params {
   const uint32_t *whead3; /* RCS_HEAD_WORDS: [4 steps][NT terms][64 lanes][4 words] 1x1 head convs in fragment order,
                            * then the fp32 dense weights wpol, wv1, wv2 as in RcParams */
   const uint32_t *epi3;   /* RC3_EPI_WORDS: RcParams::epi, padded */
+  uint32_t *range_flag;   /* f16x3: raised when an activation beyond fp16's range was split (nn.h range_exceeded) */
 };
 
 template <int NT>
@@ -616,7 +617,7 @@ __device__ __forceinline__ void rcs_conv3x3(f32x16 (&acc)[NP][2], const uint32_t
 
 /* fp32 tile values -> the packed operands of the next convolution */
 template <int NP, int NT, bool F16 = false>
-__device__ __forceinline__ void rcs_pack(uint32_t (&p)[NT][NP][4][4], const float (&v)[NP][2][16]) {
+__device__ __forceinline__ void rcs_pack(uint32_t (&p)[NT][NP][4][4], const float (&v)[NP][2][16], float &amax) {
 #pragma unroll
   for (int np = 0; np < NP; ++np)
 #pragma unroll
@@ -626,6 +627,8 @@ __device__ __forceinline__ void rcs_pack(uint32_t (&p)[NT][NP][4][4], const floa
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
           uint32_t t[NT];
+          /* (what is packed is an input plane or the output of a ReLU: never negative) */
+          if constexpr (F16) amax = __builtin_fmaxf(amax, __builtin_fmaxf(v[np][T][8 * a + 2 * m], v[np][T][8 * a + 2 * m + 1]));
           rcs_split<NT, F16>(v[np][T][8 * a + 2 * m], v[np][T][8 * a + 2 * m + 1], t);
 #pragma unroll
           for (int i = 0; i < NT; ++i) p[i][np][2 * T + a][m] = t[i];
@@ -724,7 +727,8 @@ __device__ __forceinline__ void rcs_forward(const Rc3Params &Q) {
     }
   }
   uint32_t pk[NT][NP][4][4];
-  rcs_pack<NP, NT, F16>(pk, x);
+  float amax = 0.0f;
+  rcs_pack<NP, NT, F16>(pk, x, amax);
   /* weight stream, requested behind the input loads (vmcnt retires in issue order): group 0, the
    * epilogue constants and, with two terms, the head weights (the wait before the first MFMA
    * covers them) */
@@ -739,19 +743,22 @@ __device__ __forceinline__ void rcs_forward(const Rc3Params &Q) {
   RC3_STAMP(1)
   const float *lds_epi = reinterpret_cast<const float *>(lds_epi_w);
   rc3_epilogue<false, NP>(x, acc, x, lds_epi, h);
-  rcs_pack<NP, NT, F16>(pk, x);
+  rcs_pack<NP, NT, F16>(pk, x, amax);
   RC3_STAMP(2)
   for (int b = 0; b < 4; ++b) {
     rcs_conv3x3<4, NP, NT, NW, F16>(acc, pk, ch, Q, lds_w, lds_w_addr, wave, lane);
     RC3_STAMP(3)
     rc3_epilogue<false, NP>(y, acc, x, lds_epi + (1 + 2 * b) * 192, h);
-    rcs_pack<NP, NT, F16>(pk, y);
+    rcs_pack<NP, NT, F16>(pk, y, amax);
     RC3_STAMP(2)
     rcs_conv3x3<4, NP, NT, NW, F16>(acc, pk, ch, Q, lds_w, lds_w_addr, wave, lane);
     RC3_STAMP(3)
     rc3_epilogue<true, NP>(x, acc, x, lds_epi + (2 + 2 * b) * 192, h);
-    rcs_pack<NP, NT, F16>(pk, x);
+    rcs_pack<NP, NT, F16>(pk, x, amax);
     RC3_STAMP(2)
+  }
+  if constexpr (F16) {
+    if (!(amax <= CO_F16_MAX)) atomicOr(Q.range_flag, 1u); /* (never in range: no lane enters) */
   }
   if (NT != 2) {
     /* the head weights were requested behind the last group */
@@ -854,10 +861,6 @@ __global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_x6(Rc3Params Q) {
 /* The f16x3 kernels (see above rcs_forward): throughput kernel, 32 positions per workgroup; _small: batches up to
  * RC3_SMALL_ROWS rows, 16 positions per workgroup, and up to RC6_THIN_ROWS rows on the four-wave thin path (one wave per
  * SIMD, 8 positions per workgroup, waves 4..7 leave at once; see co_k_rescnn_forward_x6). */
-#ifdef CO_H3_SHAPE16
-/* experiment, not part of the product build: the same kernels on v_mfma_f32_16x16x32 (DESIGN.md "MFMA shape of K6h3") */
-#include "../../tools/exp/nn_rescnn_s16.inc"
-#else
 __global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_h3(Rc3Params Q) { rcs_forward<2, 2, 8, true>(Q); }
 __global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_h3_small(Rc3Params Q) {
   if (*Q.base.d_rows <= RC6_THIN_ROWS) {
@@ -868,10 +871,7 @@ __global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_h3_small(Rc3Params
   }
 }
 #define RCH_LDS_WORDS(NP) RCS_LDS_WORDS(2, NP)
-#endif
-#ifndef RCH_THREADS
 #define RCH_THREADS 512
-#endif
 
 /* ------------------------------------------------------------------ host */
 struct ResCnnNet : CoNet {
@@ -1010,6 +1010,9 @@ static inline float rc_f16_to_f(uint16_t u) {
 }
 /* v -> nt 16-bit terms: bf16(v) (f16: fp16(v)), the same of the remainder, ... (the device's rcs_split) */
 static inline void rc_bf16_terms(float v, int nt, uint16_t *t, bool f16 = false) {
+  if (f16 && !(fabsf(v) <= CO_F16_MAX))
+    throw std::invalid_argument("rescnn4h3: a convolution weight is " + std::to_string(v) +
+                                ", beyond the fp16 range of the f16x3 kernels: use rescnn4x6");
   for (int i = 0; i < nt; ++i) {
     t[i] = f16 ? rc_f16_rne(v) : rc_bf16_rne(v);
     v = v - (f16 ? rc_f16_to_f(t[i]) : rc_bf16_to_f(t[i]));
@@ -1020,18 +1023,13 @@ static inline void rc_bf16_terms(float v, int nt, uint16_t *t, bool f16 = false)
 struct ResCnnSplitNet : ResCnnNet {
   int nt;
   bool f16;
-  bool shape16; /* fragments in the order of the 16x16x32 path (rq_forward) */
   uint32_t *d_trunk3 = nullptr;
   uint32_t *d_whead3 = nullptr;
   uint32_t *d_epi3 = nullptr;
+  uint32_t *d_range = nullptr; /* f16: the kernels' out-of-range flag */
   ResCnnSplitNet(const float *w, size_t max_rows, rt_stream_t s, int nterms, bool fp16 = false)
       : ResCnnNet(w, max_rows, s), nt(nterms), f16(fp16) {
-#ifdef CO_H3_SHAPE16
-    shape16 = f16; /* experiment build */
-#else
-    shape16 = false;
-#endif
-    const size_t stem_chunk = (size_t)(shape16 ? 1024 : 512) * nt, conv_chunk = (size_t)2048 * nt;
+    const size_t stem_chunk = (size_t)512 * nt, conv_chunk = (size_t)2048 * nt;
     std::vector<uint32_t> tr(9 * stem_chunk + 72 * conv_chunk, 0u);
     const float *p = w;
     size_t off = 0;
@@ -1041,14 +1039,6 @@ struct ResCnnSplitNet : ResCnnNet {
       const int cs = cv == 0 ? 1 : 4;
       const size_t chunk = cv == 0 ? stem_chunk : conv_chunk;
       const float *K = p;
-#ifdef CO_H3_SHAPE16
-      if (shape16) {
-        rq_host_pack_conv(tr, off, chunk, K, cin, cv == 0 ? 1 : 2, nt, f16);
-        off += 9 * chunk;
-        p += (size_t)9 * cin * 64 + 5 * 64;
-        continue;
-      }
-#endif
       for (int tap = 0; tap < 9; ++tap)
         for (int st = 0; st < cs; ++st)
           for (int to = 0; to < 2; ++to)
@@ -1073,12 +1063,9 @@ struct ResCnnSplitNet : ResCnnNet {
     /* 1x1 head convolutions as term fragments of one more K loop (same k-slot order as the
      * trunk): output row i = 0..3 policy planes, 4..5 value planes, the rest zero */
     const float *pk = p, *vk = pk + 64 * 4 + 4 * 5 + 64 * 96 + 96;
-    const size_t frag1 = (size_t)(shape16 ? 2 : 4) * nt * 256, head_words = frag1 + 6144 + 2048 + 1024;
+    const size_t frag1 = (size_t)4 * nt * 256, head_words = frag1 + 6144 + 2048 + 1024;
     std::vector<uint32_t> wh3(frag1, 0u);
-#ifdef CO_H3_SHAPE16
-    if (shape16) rq_host_pack_heads(wh3, pk, vk, nt, f16);
-#endif
-    for (int st = 0; st < (shape16 ? 0 : 4); ++st)
+    for (int st = 0; st < 4; ++st)
       for (int h = 0; h < 2; ++h)
         for (int i = 0; i < 32; ++i)
           for (int j = 0; j < 8; ++j) {
@@ -1097,6 +1084,7 @@ struct ResCnnSplitNet : ResCnnNet {
     rt_d2d(d_whead3 + frag1, P.wpol, 6144 * 4, s); /* the dense weights in the base class's MFMA order */
     rt_d2d(d_whead3 + frag1 + 6144, P.wv1, 2048 * 4, s);
     rt_d2d(d_whead3 + frag1 + 6144 + 2048, P.wv2, 1024 * 4, s);
+    if (f16) rt_malloc((void **)&d_range, 4, s);
     rt_malloc((void **)&d_epi3, (size_t)RC3_EPI_WORDS * 4, s); /* zero-filled: the padding is staged too */
     rt_d2d(d_epi3, P.epi, (size_t)RC_NUM_CONVS * 192 * 4, s);
     if (nt == 2) {
@@ -1119,6 +1107,14 @@ struct ResCnnSplitNet : ResCnnNet {
     rt_free(d_trunk3);
     rt_free(d_whead3);
     rt_free(d_epi3);
+    rt_free(d_range);
+  }
+  bool range_exceeded(rt_stream_t s) override {
+    if (!d_range) return false;
+    uint32_t flag = 0;
+    rt_d2h(&flag, d_range, 4, s);
+    rt_sync(s);
+    return flag != 0;
   }
   int kind() const override { return f16 ? CO_NET_RESCNN4_H3 : nt == 2 ? CO_NET_RESCNN4_X3 : CO_NET_RESCNN4_X6; }
   void forward(const float *d_in, int32_t rows_cap, const int32_t *d_rows, float *d_eval, float *d_probs,
@@ -1134,6 +1130,7 @@ struct ResCnnSplitNet : ResCnnNet {
     q.wtrunk = d_trunk3;
     q.whead3 = d_whead3;
     q.epi3 = d_epi3;
+    q.range_flag = d_range;
     if (nt == 2) {
       /* both kernels are queued; the row count on the device decides which one works (the other's
        * workgroups return at once).  Batches that can exceed RC3_SMALL_ROWS need the throughput kernel. */
@@ -1165,9 +1162,3 @@ CoNet *co_rescnn_split_create(const float *weights, size_t n_floats, size_t max_
   if (n_floats != (size_t)RC_NUM_WEIGHTS || (nterms != 2 && nterms != 3) || (f16 && nterms != 2)) return nullptr;
   return new ResCnnSplitNet(weights, max_rows, s, nterms, f16);
 }
-
-#ifdef CO_WINOGRAD
-/* experiment, not part of the product build: the F(2x2, 3x3) formulation of the convolutions (kind 7).  Measured slower
- * than co_k_rescnn_forward_x6 on gfx950 -- DESIGN.md "Measured and rejected" has the numbers and the reasons. */
-#include "../../tools/exp/nn_rescnn_wino.inc"
-#endif

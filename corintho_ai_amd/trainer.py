@@ -39,6 +39,19 @@ def _f32(a, what):
     return a.ctypes.data_as(_lib.f32p)
 
 
+def _eval_cache_cfg(eval_cache):
+    """ca_config.eval_cache from the Python argument: True -> 0 (on where it pays, table sized automatically),
+    False / None -> -1 (off), an int n in 6..30 -> a table of 2**n entries per pool.  Anything else is refused
+    (0 and 1 as plain ints would silently mean something else on each side of the C ABI)."""
+    if eval_cache is True:
+        return 0
+    if eval_cache is False or eval_cache is None:
+        return -1
+    if isinstance(eval_cache, (int, np.integer)) and 6 <= int(eval_cache) <= 30:
+        return int(eval_cache)
+    raise ValueError("eval_cache must be True, False or a table size log2 in 6..30, not %r" % (eval_cache,))
+
+
 class Trainer:
     def __init__(self, num_games, log_folder="", seed=0, max_searches=1600, searches_per_eval=16, c_puct=1.0,
                  epsilon=0.25, num_logged=0, num_threads=1, testing=False, *, device=0, stagger=True, arena_units=0,
@@ -50,7 +63,7 @@ class Trainer:
                             epsilon=epsilon, num_logged=0, num_threads=num_threads, testing=int(bool(testing)),
                             device=device, no_stagger=int(not stagger), arena_units=arena_units, trace=int(bool(trace)),
                             game_base=game_base, total_games=total_games, pools=pools, analyse=int(bool(analyse)),
-                            resident=int(resident), eval_cache=(0 if eval_cache is True else int(eval_cache) if eval_cache else -1))
+                            resident=int(resident), eval_cache=_eval_cache_cfg(eval_cache))
         self.num_games = num_games
         self.searches_per_eval = searches_per_eval
         self.testing = bool(testing)

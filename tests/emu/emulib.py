@@ -13,6 +13,11 @@ _cache = {}
 
 def load():
     name = "libcorintho_emu.so"
+    alt = os.environ.get("CO_EMU_LIB")  # another build of the same source (tests/emu/sanitize.mk, CPU only)
+    if alt:
+        if alt not in _cache:
+            _cache[alt] = _lib.declare(C.CDLL(alt))
+        return _cache[alt]
     if name not in _cache:
         subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
         _cache[name] = _lib.declare(C.CDLL(os.path.join(_HERE, name)))

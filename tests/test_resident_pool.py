@@ -203,3 +203,37 @@ def test_evaluation_cache_with_a_tiny_table_and_an_iteration_cap(engine, monkeyp
     for g in range(G):
         assert np.array_equal(t.trace(g), o.trace(g)), g
     assert all(x.tobytes() == y.tobytes() for x, y in zip(H.get_samples(t), H.get_samples(o)))
+
+
+@pytest.mark.parametrize("engine", ENGINES)
+def test_a_new_network_in_mid_generation_is_not_served_by_the_old_ones_entries(engine):
+    """set_net between two capped runs: the rows queued from then on are evaluated by the NEW network -- the table's
+    entries were filled by the old one and must not serve it.  The uncached engine is the yardstick; an engine whose
+    table survived the change returns the old network's outputs for every position met before."""
+    G, S_, spe, seed = 12, 40, 8, 77
+    w0, w1 = nets.init_mlp12x100(seed=3, bn_noise=True), nets.init_mlp12x100(seed=4, bn_noise=True)
+    out = {}
+    for cache in (False, 14):
+        t = make_trainer(engine, G, "", seed, S_, spe, 1.0, 0.25, 0, 1, False, stagger=False, trace=True, eval_cache=cache)
+        t.set_net(1, w0)
+        assert not t.run(max_iterations=25)
+        t.set_net(1, w1)
+        assert t.run()
+        out[cache] = (_digest(t, G), [t.trace(g).tobytes() for g in range(G)], t.stats())
+    assert out[14][0] == out[False][0] and out[14][1] == out[False][1]
+    assert out[14][2]["nn_rows_evaluated"] < out[14][2]["nn_rows"]  # (the cache did serve rows)
+    # and the change did matter: the same generation under the first network alone differs
+    t = make_trainer(engine, G, "", seed, S_, spe, 1.0, 0.25, 0, 1, False, stagger=False, trace=True, eval_cache=False)
+    t.set_net(1, w0)
+    assert t.run()
+    assert _digest(t, G) != out[False][0]
+
+
+def test_eval_cache_argument_is_explicit():
+    from corintho_ai_amd.trainer import _eval_cache_cfg
+
+    assert _eval_cache_cfg(True) == 0 and _eval_cache_cfg(False) == -1 and _eval_cache_cfg(None) == -1
+    assert _eval_cache_cfg(12) == 12
+    for bad in (0, 1, 5, 31, "on", 2.5):
+        with pytest.raises(ValueError):
+            _eval_cache_cfg(bad)
