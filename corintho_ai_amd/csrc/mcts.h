@@ -1220,12 +1220,17 @@ CO_DEV void co_analyse_finish(CoWave &w, CoTree &t, int choice) {
  * (250 KB of instructions in front of a 64 KB instruction cache).  Returns "game over". */
 CO_DEV int co_game_step(CoWave &w, const float *eval, const float *probs) {
   const float *ev = eval, *pr = probs;
-  if (w.gc.resume) {
+  if (w.gc.resume == 1) {
     /* continuation of a deferred hand-over: selfplayer.cpp:287-288 */
     w.gc.resume = 0;
     ev = pr = (const float *)0;
   }
   int skip_iteration = (w.pc && w.pc[w.gc.to_play].random) /* match.cpp:68-70 */ || w.force_choose;
+  if (w.gc.resume == 2) { /* the turn ended in co_k_search (fused training in two kernels): enter at the move choice */
+    w.gc.resume = 0;
+    skip_iteration = 1;
+    ev = pr = (const float *)0;
+  }
   int fresh_root = 0;
   for (;;) {
     if (!skip_iteration) {
@@ -1462,13 +1467,20 @@ CO_DEV void co_cache_resolve(const EngineParams &P, CoWave &w, int g, int n, int
   }
 }
 
-/* Trainer::doIteration for game g (trainer.cpp:164-236): the body of the
- * `omp parallel for`, one wavefront per game. */
-CO_DEV void co_mcts_step_wave(const EngineParams &P, int g) {
+/* ---- the step of one game's wavefront, in pieces shared by the three search kernels (kernels.h):
+ *   co_k_mcts_step  the whole step in one kernel (compat protocol, arena, tournaments, analysis, and fused training
+ *                   once a pool has thinned out);
+ *   co_k_search     fused training: the receive + simulate half of the step -- the hot loop and nothing else;
+ *   co_k_turn       fused training: the rest (move choice, logs, re-root, hand-over, end of game, slot recycling) for
+ *                   the games whose turn ended in this iteration's co_k_search. */
+
+/* first wave of a pool's launch: clear the counters of the NEXT iteration (nobody reads them before the next launch) */
+CO_DEV void co_pool_housekeeping(const EngineParams &P, int g) {
   if (P.fused_pack && g == P.pool_lo) {
     FOR_LANES {
       if (lane == 0) {
         P.pack_counter[(P.iteration + 1) & 1] = 0ull;
+        if (P.turn_count) P.turn_count[(P.iteration + 1) & 1] = 0u;
         if (P.cache.hdr) {
           /* the other parity's counter of rows to evaluate was the previous iteration's (its network launch is
            * over): book it, clear it for the next iteration */
@@ -1479,15 +1491,10 @@ CO_DEV void co_mcts_step_wave(const EngineParams &P, int g) {
       }
     }
   }
-  GameCtl gc = P.games[g];
-  /* both trees' control words, fetched with the game's (not behind it) */
-  const TreeCtl tc0 = P.trees[2 * g], tc1 = P.trees[2 * g + 1];
-  const int gate = co_step_gate(P, g, gc);
-  if (gate != 1) {
-    if (gate == 2 && P.fused_pack) co_atomic_add_u64(P.pack_counter + (P.iteration & 1), 1ull << 32); /* still running */
-    return;
-  }
-  CoWave w;
+}
+
+/* the wavefront's view of game slot g.  (Fields a kernel never touches cost nothing: they are never loaded.) */
+CO_DEV void co_wave_init(const EngineParams &P, int g, const GameCtl &gc, const TreeCtl &tc0, const TreeCtl &tc1, CoWave &w) {
   w.g = g;
   w.gc = gc;
   {
@@ -1529,58 +1536,54 @@ CO_DEV void co_mcts_step_wave(const EngineParams &P, int g) {
   w.epsilon = P.epsilon;
   w.pc = P.pcfg ? P.pcfg + 2 * g : (const PlayerCfg *)0;
   co_use_player(w, gc.to_play);
-  CO_PROF_ADD(w, 4, 1ull);
-  unsigned long long t_wave0 = CO_CLK();
-#if defined(CO_PROF) && !defined(CO_EMU)
-  unsigned long long t_real0 = __builtin_amdgcn_s_memrealtime();
-#endif
-  int off = co_step_row(P, g, gc);
-  const float *step_eval = P.nn_eval + off, *step_probs = P.nn_probs + (size_t)off * CO_NUM_MOVES;
   w.cval = P.cache.hdr ? P.cache.val : (const float *)0;
   w.csrc = P.cache.hdr ? P.pend_src + (size_t)g * P.searches_per_eval : (const int32_t *)0;
-  int done;
-  for (;;) { /* one pass, unless the slot's game ends and the pool hands it the next one */
-    done = co_game_step(w, step_eval, step_probs);
-    if (!done) break;
-    w.gc.done = 1;
-    if (!P.results) break;
-    /* resident-slot pool: file the finished game under its index, take the next unstarted one */
-    {
-      GameCtl *dst = P.results + w.gc.gid;
-      FOR_LANES {
-        if (lane == 0) *dst = w.gc;
-      }
-      WAVE_SYNC();
+}
+
+/* The slot's game is over: file it, and in a resident-slot pool hand the slot the next unstarted game.  Returns 1 when
+ * a fresh game sits in the slot (its first step -- root + request for its evaluation -- is the caller's next pass). */
+CO_DEV int co_slot_next_game(const EngineParams &P, CoWave &w) {
+  w.gc.done = 1;
+  if (!P.results) return 0;
+  {
+    GameCtl *dst = P.results + w.gc.gid;
+    FOR_LANES {
+      if (lane == 0) *dst = w.gc;
     }
-    const unsigned long long next = co_atomic_add_u64(P.next_game, 1ull);
-    if (next >= (unsigned long long)P.total_local) break; /* none left: the slot is done */
-    /* Trainer::initialize for game `next` (trainer.cpp:243-255) in this slot: a fresh SelfPlayer -- own
-     * generator seeded from the Trainer stream by game index, two empty trees (the arena of the finished game
-     * is given back whole: the bump pointers return to zero), colour parity by global index */
-    const int gid = (int)next;
-    if (w.gc.to_play != 0) { /* w.me is the tree of the player to move: player 0 starts */
-      CoTree tmp = w.me;
-      w.me = w.opp;
-      w.opp = tmp;
-    }
-    GameCtl fresh;
-    fresh.to_play = 0; fresh.done = 0; fresh.result = 0; fresh.mate_turn = 0; fresh.n_samples = 0;
-    fresh.parity = (P.game_base + gid) % 2; fresh.error = 0; fresh.n_pending = 0; fresh.rng_idx = CO_MT_N;
-    fresh.plies = 0; fresh.searches = 0u; fresh.evals = 0u; fresh.nodes = 0u; fresh.trace_len = 0;
-    fresh.row_off = 0; fresh.resume = 0; fresh.pos_lo = 0u; fresh.pos_hi = 0u; fresh.pos_meta = CO_META_START;
-    fresh.gid = gid;
-    w.gc = fresh;
-    w.me.tc.root = CO_NONE; w.me.tc.searches_done = 0; w.me.tc.units_used = 0u;   /* peak_units: high-water of the slot */
-    w.opp.tc.root = CO_NONE; w.opp.tc.searches_done = 0; w.opp.tc.units_used = 0u;
-    w.noise_words = 0;
-    w.samples = P.samples ? P.samples + (size_t)gid * CO_MAX_PLIES * CO_SAMPLE_FLOATS : (float *)0;
-    w.trace = P.trace ? P.trace + (size_t)gid * CO_TRACE_CAP : (int32_t *)0;
-    w.log = (int32_t *)0; /* logged games are the first ones: they start in their own slots */
-    co_mt_seed(w.mt, P.seeds[gid]);
-    step_eval = step_probs = (const float *)0; /* the first step of a game creates the root and asks for its evaluation */
+    WAVE_SYNC();
   }
-  /* Trainer::writeRequests fused into the step: reserve rows of the compact batch (any order: a row's
-   * evaluation does not depend on its position).  The atomic's round trip runs under the noise capture. */
+  const unsigned long long next = co_atomic_add_u64(P.next_game, 1ull);
+  if (next >= (unsigned long long)P.total_local) return 0; /* none left: the slot is done */
+  /* Trainer::initialize for game `next` (trainer.cpp:243-255) in this slot: a fresh SelfPlayer -- own
+   * generator seeded from the Trainer stream by game index, two empty trees (the arena of the finished game
+   * is given back whole: the bump pointers return to zero), colour parity by global index */
+  const int gid = (int)next;
+  if (w.gc.to_play != 0) { /* w.me is the tree of the player to move: player 0 starts */
+    CoTree tmp = w.me;
+    w.me = w.opp;
+    w.opp = tmp;
+  }
+  GameCtl fresh;
+  fresh.to_play = 0; fresh.done = 0; fresh.result = 0; fresh.mate_turn = 0; fresh.n_samples = 0;
+  fresh.parity = (P.game_base + gid) % 2; fresh.error = 0; fresh.n_pending = 0; fresh.rng_idx = CO_MT_N;
+  fresh.plies = 0; fresh.searches = 0u; fresh.evals = 0u; fresh.nodes = 0u; fresh.trace_len = 0;
+  fresh.row_off = 0; fresh.resume = 0; fresh.pos_lo = 0u; fresh.pos_hi = 0u; fresh.pos_meta = CO_META_START;
+  fresh.gid = gid;
+  w.gc = fresh;
+  w.me.tc.root = CO_NONE; w.me.tc.searches_done = 0; w.me.tc.units_used = 0u;   /* peak_units: high-water of the slot */
+  w.opp.tc.root = CO_NONE; w.opp.tc.searches_done = 0; w.opp.tc.units_used = 0u;
+  w.noise_words = 0;
+  w.samples = P.samples ? P.samples + (size_t)gid * CO_MAX_PLIES * CO_SAMPLE_FLOATS : (float *)0;
+  w.trace = P.trace ? P.trace + (size_t)gid * CO_TRACE_CAP : (int32_t *)0;
+  w.log = (int32_t *)0; /* logged games are the first ones: they start in their own slots */
+  co_mt_seed(w.mt, P.seeds[gid]);
+  return 1;
+}
+
+/* End of a game's step.  Trainer::writeRequests fused into the step: reserve rows of the compact batch (any order: a
+ * row's evaluation does not depend on its position; the atomic's round trip runs under the noise capture), reserve the
+ * generator outputs owed to the queued leaves, resolve the rows against the evaluation cache, copy them to the batch. */
+CO_DEV void co_step_tail(const EngineParams &P, CoWave &w, int g, int done) {
   const int packs = P.fused_pack && !w.gc.done && !w.gc.error;
   unsigned long long old = 0ull;
   if (packs) old = co_atomic_add_u64(P.pack_counter + (P.iteration & 1), (1ull << 32) | (unsigned long long)w.gc.n_pending);
@@ -1613,6 +1616,47 @@ CO_DEV void co_mcts_step_wave(const EngineParams &P, int g) {
       }
     }
   }
+}
+
+CO_DEV void co_wave_store(const EngineParams &P, const CoWave &w, int g) {
+  FOR_LANES {
+    if (lane == 0) {
+      P.games[g] = w.gc;
+      P.trees[2 * g + w.gc.to_play] = w.me.tc;
+      P.trees[2 * g + 1 - w.gc.to_play] = w.opp.tc;
+    }
+  }
+}
+
+/* Trainer::doIteration for game g (trainer.cpp:164-236): the body of the
+ * `omp parallel for`, one wavefront per game -- the whole step (co_k_mcts_step). */
+CO_DEV void co_mcts_step_wave(const EngineParams &P, int g) {
+  co_pool_housekeeping(P, g);
+  GameCtl gc = P.games[g];
+  /* both trees' control words, fetched with the game's (not behind it) */
+  const TreeCtl tc0 = P.trees[2 * g], tc1 = P.trees[2 * g + 1];
+  const int gate = co_step_gate(P, g, gc);
+  if (gate != 1) {
+    if (gate == 2 && P.fused_pack) co_atomic_add_u64(P.pack_counter + (P.iteration & 1), 1ull << 32); /* still running */
+    return;
+  }
+  CoWave w;
+  co_wave_init(P, g, gc, tc0, tc1, w);
+  CO_PROF_ADD(w, 4, 1ull);
+  unsigned long long t_wave0 = CO_CLK();
+#if defined(CO_PROF) && !defined(CO_EMU)
+  unsigned long long t_real0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  int off = co_step_row(P, g, gc);
+  const float *step_eval = P.nn_eval + off, *step_probs = P.nn_probs + (size_t)off * CO_NUM_MOVES;
+  int done;
+  for (;;) { /* one pass, unless the slot's game ends and the pool hands it the next one */
+    done = co_game_step(w, step_eval, step_probs);
+    if (!done) break;
+    if (!co_slot_next_game(P, w)) break;
+    step_eval = step_probs = (const float *)0; /* the first step of a game creates the root and asks for its evaluation */
+  }
+  co_step_tail(P, w, g, done);
   CO_PROF_ADD(w, 7, CO_CLK() - t_wave0);
 #if defined(CO_PROF) && !defined(CO_EMU)
   if (w.prof && g == 1 && (threadIdx.x & 63) == 0) {
@@ -1628,11 +1672,81 @@ CO_DEV void co_mcts_step_wave(const EngineParams &P, int g) {
     atomicAdd(P.prof + (size_t)P.num_games * 16 + 4 + bucket, 1ull);
   }
 #endif
+  co_wave_store(P, w, g);
+}
+
+/* ---- fused training, the step in two kernels.  The receive + simulate half (co_k_search): TrainMC::doIteration of the
+ * player to move and nothing else.  A turn that ends here (`done`) is handed to co_k_turn through the pool's turn list;
+ * its move is chosen there, in the same iteration.  The game's own sequence of operations -- tree updates, generator
+ * draws -- is the single kernel's: per-game results do not depend on which kernels played it. */
+CO_DEV void co_search_step_wave(const EngineParams &P, int g) {
+  co_pool_housekeeping(P, g);
+  GameCtl gc = P.games[g];
+  const TreeCtl tc0 = P.trees[2 * g], tc1 = P.trees[2 * g + 1];
+  const int gate = co_step_gate(P, g, gc);
+  if (gate != 1) {
+    if (gate == 2) co_atomic_add_u64(P.pack_counter + (P.iteration & 1), 1ull << 32); /* still running */
+    return;
+  }
+  CoWave w;
+  co_wave_init(P, g, gc, tc0, tc1, w);
+  CO_PROF_ADD(w, 4, 1ull);
+  unsigned long long t_wave0 = CO_CLK();
+  const int off = co_step_row(P, g, gc);
+  const float *ev = P.nn_eval + off, *pr = P.nn_probs + (size_t)off * CO_NUM_MOVES;
+  if (w.gc.resume) { /* continuation of a deferred hand-over (co_game_step): nothing to receive */
+    w.gc.resume = 0;
+    ev = pr = (const float *)0;
+  }
+  const int turn_over = co_mc_do_iteration(w, w.me, ev, pr);
+  if (turn_over && !w.gc.error) {
+    /* the move choice is co_k_turn's: queue the game (nothing is pending: a turn ends with every leaf received) */
+    w.gc.resume = 2;
+    const uint32_t at = co_atomic_add_u32(P.turn_count + (P.iteration & 1), 1u);
+    uint32_t *lst = P.turn_list;
+    FOR_LANES {
+      if (lane == 0) lst[at] = (uint32_t)g;
+    }
+  } else {
+    co_step_tail(P, w, g, 0);
+  }
+  CO_PROF_ADD(w, 7, CO_CLK() - t_wave0);
+  /* what this kernel may have changed (the rest of the control block is co_k_turn's) */
+  GameCtl *dst = P.games + g;
+  TreeCtl *tdst = P.trees + 2 * g + w.gc.to_play;
   FOR_LANES {
     if (lane == 0) {
-      P.games[g] = w.gc;
-      P.trees[2 * g + w.gc.to_play] = w.me.tc;
-      P.trees[2 * g + 1 - w.gc.to_play] = w.opp.tc;
+      dst->error = w.gc.error;
+      dst->n_pending = w.gc.n_pending;
+      dst->rng_idx = w.gc.rng_idx;
+      dst->searches = w.gc.searches;
+      dst->evals = w.gc.evals;
+      dst->nodes = w.gc.nodes;
+      dst->row_off = w.gc.row_off;
+      dst->resume = w.gc.resume;
+      *tdst = w.me.tc;
     }
   }
+}
+
+/* The other half (co_k_turn), for a game whose turn ended in this iteration's co_k_search: co_game_step entered at the
+ * move choice (resume == 2), always ending its step at the hand-over (the new mover's searches are the next
+ * iteration's co_k_search: lock-step scheduling, see co_game_step). */
+CO_DEV void co_turn_step_wave(const EngineParams &P, int g) {
+  GameCtl gc = P.games[g];
+  const TreeCtl tc0 = P.trees[2 * g], tc1 = P.trees[2 * g + 1];
+  CoWave w;
+  co_wave_init(P, g, gc, tc0, tc1, w);
+  w.defer_handover = 1;
+  int done;
+  for (;;) { /* one pass, unless the slot's game ends and the pool hands it the next one */
+    /* (no evaluation is pending on any path through here -- a turn ends with every leaf received, a fresh game has
+     * none -- so the pointers are never read; real ones rather than null constants, on which this compiler's
+     * simplifycfg crashes after inlining) */
+    done = co_game_step(w, P.nn_eval, P.nn_probs);
+    if (!done) break;
+    if (!co_slot_next_game(P, w)) break;
+  }
+  co_step_tail(P, w, g, done);
+  co_wave_store(P, w, g);
 }

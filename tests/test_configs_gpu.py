@@ -1,7 +1,12 @@
-"""BASELINE.json configs 3, 4 and 5 at FULL size on one MI355X (configs[1] is
-tests/test_engine_parity.py::test_full_size_generation_properties).  Too big for the oracle as a
-whole, so each is checked through size-independent properties plus an oracle replay of its first
-32 games, fed by the same device network, bit for bit.
+"""BASELINE.json configs 2, 3, 4 and 5 at FULL size on one MI355X.
+
+configs[1] -- the configuration `bench.py` times by default: 4096 games, 400 sims/move, the residual CNN at f16x3
+(NET_RESCNN4_H3), evaluation cache on, two pools -- is replayed WHOLE on the CPU oracle (all 4096 games, fed by the same
+device network: samples, score, mate length bit for bit; the reference's counterpart is tests/cpp/trainer_test.cpp:21-136,
+which runs the one code path there is), and so is the bench's `recycled` variant (16 384 games on the 4 096 slots).
+tests/test_engine_parity.py::test_full_size_generation_properties adds the size-independent properties, determinism and
+sharding for the same configuration.  Configs 3-5 are checked through size-independent properties plus an oracle replay
+of a slice (cfg3: 32 games of the shard; cfg4: a 512-game generation whole; cfg5: all 1024 games), bit for bit.
 
   cfg3  32 768 games sharded over 8 GPUs: ONE shard of it on this GPU -- rank 7 of 8, games
         [28 672, 32 768), seeds / parity / colours on the global index (trainer.cpp:243-255)
@@ -12,7 +17,7 @@ whole, so each is checked through size-independent properties plus an oracle rep
 import numpy as np
 import pytest
 
-from corintho_ai_amd import NET_RESCNN4_X6, nets
+from corintho_ai_amd import NET_RESCNN4_H3, NET_RESCNN4_X6, nets
 from oracle import oracle as O
 from tests import harness as H
 from tests.engines import make_trainer
@@ -30,6 +35,55 @@ def _replay_first_games(t, G_total, base, sims, spe, seed, n=NREPLAY, eps=0.25):
     o.set_stagger(False)
     H.play_generation(o, n, spe, lambda st: t.net_forward(st))
     return o
+
+
+def _replay_whole_generation(t, G, sims, spe, seed, c_puct=1.0, eps=0.25):
+    """EVERY game of trainer t's generation on the CPU oracle, evaluated by t's device network (in pieces of the rows one
+    device evaluation takes): sample tensors, score and mate length must be the same bytes (tools/big_parity.py as a test)"""
+    o = O.Trainer(G, seed=seed, max_searches=sims, searches_per_eval=spe, c_puct=c_puct, epsilon=eps, num_threads=16)
+    o.set_stagger(False)
+    cap = t.stats()["resident_slots"] * spe
+
+    def fw(states):
+        parts = [t.net_forward(states[i:i + cap]) for i in range(0, states.shape[0], cap)]
+        return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
+
+    H.play_generation(o, G, spe, fw)
+    sp, oc = t.export_samples()
+    ogs, oev, opr = H.get_samples(o)
+    n = t.num_samples()
+    assert ogs.shape[0] == n * 8 == sp.shape[0] * 8
+    assert ogs[0::8].tobytes() == sp[:, :70].tobytes(), "states differ from the oracle"
+    assert opr[0::8].tobytes() == sp[:, 70:].tobytes(), "policies differ from the oracle"
+    assert oev[0::8].tobytes() == oc.tobytes(), "outcomes differ from the oracle"
+    assert o.score() == t.score() and o.avg_mate_length() == t.avg_mate_length()
+    return o
+
+
+@pytest.mark.parametrize("games,slots", [(4096, -1), (16384, 4096)], ids=["default", "recycled"])
+def test_cfg2_the_bench_default_whole_on_the_oracle(games, slots):
+    """what `python bench.py` times (and its `recycled` variant): NET_RESCNN4_H3, evaluation cache on, two pools,
+    400 sims/move, seed 12345 -- every game replayed on the oracle"""
+    S_, spe, seed = 400, 16, 12345
+    t = make_trainer("hip", games, "", seed, S_, spe, 1.0, 0.25, 0, 1, False, stagger=False, resident=slots, pools=2)
+    t.set_net(NET_RESCNN4_H3, nets.init_rescnn4(0))
+    assert t.run()
+    st = t.stats()
+    assert st["resident_slots"] == 4096 and st["pools"] == 2
+    assert st["nn_rows"] == st["evals"] > 0
+    assert 0 < st["nn_rows_evaluated"] < 0.9 * st["nn_rows"]  # the evaluation cache is on and serves rows
+    _replay_whole_generation(t, games, S_, spe, seed)
+    print("cfg2 (%d games on %d slots): %d plies, %d simulations, %d of %d request rows evaluated, score %.6f"
+          % (games, st["resident_slots"], st["plies"], st["searches"], st["nn_rows_evaluated"], st["nn_rows"], t.score()))
+
+
+def test_cfg4_a_512_game_generation_whole_on_the_oracle():
+    """cfg4's setting (1600 sims/move, Dirichlet noise) at the bench's arithmetic, 512 games, every game on the oracle"""
+    G, S_, spe, seed = 512, 1600, 16, 4321
+    t = make_trainer("hip", G, "", seed, S_, spe, 1.0, 0.25, 0, 1, False, stagger=False)
+    t.set_net(NET_RESCNN4_H3, nets.init_rescnn4(0))
+    assert t.run()
+    _replay_whole_generation(t, G, S_, spe, seed)
 
 
 def _check_training_generation(t, G):

@@ -552,14 +552,15 @@ def test_fused_arena_matches_oracle(engine):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind_name", ["NET_RESCNN4_X6", "NET_RESCNN4_X3"])  # X6 = the bench default (float32-equivalent)
+@pytest.mark.parametrize("kind_name", ["NET_RESCNN4_H3", "NET_RESCNN4_X6"])  # H3 = the bench default (f16x3); X6 = float32-equivalent
 def test_full_size_generation_properties(kind_name):
     """BASELINE configs[1] at full size (4096 games, 400 sims/move, residual CNN, fused): too big
     for the oracle, so checked through size-independent properties -- every game finished, the
     reference's sample invariants (ranges, probability sums, the 7 symmetry copies being
     permutations, selfplayer_test.cpp:63-142), alternating outcome labels, determinism of a
     re-run, a 256-game shard reproducing its slice, and the first 64 games of the same generation
-    replayed on the oracle (fed by the same device network) bit for bit."""
+    replayed on the oracle (fed by the same device network) bit for bit.  (The whole generation on the oracle:
+    tests/test_configs_gpu.py::test_cfg2_the_bench_default_whole_on_the_oracle.)"""
     import corintho_ai_amd as CA
 
     NET_RESCNN4_X3 = getattr(CA, kind_name)  # (the kind under test)

@@ -125,3 +125,51 @@ def test_fused_bf16x6_generation_replays_on_the_oracle(kind, make):
     for x, y in zip(H.get_samples(f), H.get_samples(o)):
         assert x.tobytes() == y.tobytes()
     assert f.score() == o.score()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Range guard of the f16x3 kinds (nn.h CoNet::range_exceeded): an operand beyond fp16's largest finite value would
+# turn into infinity, the evaluation into NaN and the tree would run on NaN priors without a word.  Weights are
+# refused when the network is set; activations raise a device flag that ends the run with an error naming the x6 kind.
+def _scaled(kind, what):
+    """adversarial weight sets: `weight` = one weight beyond fp16's range; `activation` = every weight in range, the
+    first layer scaled so that its outputs are not"""
+    if kind in (NET_RESCNN4_H3, NET_RESCNN4_X6):
+        w = nets.init_rescnn4(0, bn_noise=True)
+        n_stem = 3 * 3 * nets.RES_CIN * nets.RES_C
+        if what == "weight":
+            w[n_stem + 6 * nets.RES_C + 5] = 1.0e5  # a kernel weight of the first block's first convolution
+        else:
+            w[:n_stem] *= 5.0e5  # weights up to 4.7e4, stem outputs ~ 1e5 and beyond
+    else:
+        w = nets.init_mlp12x100(2, bn_noise=True)
+        if what == "weight":
+            w[70 * 100 + 500 + 17] = -7.0e5  # a kernel weight of the second layer (times the BatchNorm scale 0.35 .. 2.1 folded into it)
+        else:
+            w[:70 * 100] *= 2.0e5  # weights up to 3.8e4, first-layer outputs ~ 1e5 and beyond
+    return w
+
+
+@pytest.mark.parametrize("h3,x6", [(NET_RESCNN4_H3, NET_RESCNN4_X6), (NET_MLP12X100_H3, NET_MLP12X100_X6)], ids=["rescnn4", "mlp12x100"])
+def test_f16x3_refuses_what_does_not_fit_fp16(h3, x6):
+    t = make_trainer("hip", 64, "", 1, 30, 8, 1.0, 0.25, 0, 1, False, stagger=False)
+    states = _states(256, 5)
+    # (1) a weight beyond the range: refused at set_net, the message names the way out; the x6 kind takes it
+    with pytest.raises(RuntimeError, match="x6"):
+        t.set_net(h3, _scaled(h3, "weight"))
+    t.set_net(x6, _scaled(h3, "weight"))
+    ev, pr = t.net_forward(states)
+    assert np.all(np.isfinite(ev)) and np.all(np.isfinite(pr))
+    # (2) activations beyond the range: the evaluation ends in an error, never in silent NaN; x6 evaluates the same weights
+    t.set_net(h3, _scaled(h3, "activation"))
+    with pytest.raises(RuntimeError, match="fp16 range"):
+        t.net_forward(states)
+    with pytest.raises(RuntimeError, match="fp16 range"):
+        t.run()
+    t.set_net(x6, _scaled(h3, "activation"))
+    ev, pr = t.net_forward(states)
+    assert np.all(np.isfinite(ev)) and np.all(np.isfinite(pr))
+    # (3) in range: nothing is reported, a generation runs
+    t2 = make_trainer("hip", 64, "", 1, 30, 8, 1.0, 0.25, 0, 1, False, stagger=False)
+    t2.set_net(h3, nets.init_rescnn4(0, bn_noise=True) if h3 == NET_RESCNN4_H3 else nets.init_mlp12x100(2, bn_noise=True))
+    assert t2.run()
