@@ -254,7 +254,9 @@ CO_KERNEL co_k_rules_batch(const uint64_t *boards, const uint32_t *metas, int n,
   int i = CO_BLOCK_IDX;
   if (i >= n) return;
   uint32_t lm[3];
-  int l = co_legal_moves(boards[i], metas[i], lm);
+  CoLanes K;
+  co_lanes_init(K);
+  int l = co_legal_moves(boards[i], metas[i], lm, K);
   FOR_LANES {
     if (lane < 3) masks[i * 3 + lane] = lm[lane];
     if (lane == 0) lines[i] = l;

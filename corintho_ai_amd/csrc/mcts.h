@@ -56,6 +56,7 @@ struct CoTree {
 struct CoWave {
   int g;
   GameCtl gc;
+  CoLanes K; /* per-lane constants of the rule layer (rules.h) */
   /* the tree of the player to move and the opponent's; swapped on hand-over so that
    * no register-resident state is indexed dynamically (that would spill to scratch) */
   CoTree me, opp;
@@ -131,13 +132,14 @@ CO_DEV void co_trace_push(CoWave &w, int32_t v) {
 CO_DEV uint32_t co_create_node(CoWave &w, CoTree &t, uint64_t board, uint32_t meta_game, int depth, uint32_t parent,
                                uint32_t self_slot, int *res_out, int *n_out = (int *)0, uint32_t *lm_out = (uint32_t *)0) {
   uint32_t lm[3];
-  int is_lines = co_legal_moves(board, meta_game, lm);
+  int is_lines = co_legal_moves(board, meta_game, lm, w.K);
   if (lm_out) {
     lm_out[0] = lm[0];
     lm_out[1] = lm[1];
     lm_out[2] = lm[2];
   }
-  int n = co_popc32(lm[0]) + co_popc32(lm[1]) + co_popc32(lm[2]);
+  const int n01 = co_popc32(lm[0]) + co_popc32(lm[1]);
+  int n = n01 + co_popc32(lm[2]);
   int res = CO_RESULT_NONE;
   if (n == 0) res = is_lines ? CO_RESULT_LOSS : CO_RESULT_DRAW;
   *res_out = res;
@@ -160,17 +162,9 @@ CO_DEV uint32_t co_create_node(CoWave &w, CoTree &t, uint64_t board, uint32_t me
     if (lane == 2 && self_slot == CO_NONE)
       A[own] = make_uint4(CO_NONE, 0u, 1u << 16, (uint32_t)res | 0x100u); /* visits 1, all_visited (node.h:164,186) */
     /* edges in ascending move id: rank = number of legal moves below this id */
-    int id0 = lane;
-    uint32_t wlo = id0 < 32 ? lm[0] : lm[1];
-    if ((wlo >> (id0 & 31)) & 1u) {
-      int rank = id0 < 32 ? co_popc32(lm[0] & ((1u << id0) - 1u))
-                          : co_popc32(lm[0]) + co_popc32(lm[1] & ((1u << (id0 - 32)) - 1u));
-      A[b + 2 + rank] = make_uint4(CO_NONE, 0u, (uint32_t)id0, 0u);
-    }
-    if (lane < 32 && ((lm[2] >> lane) & 1u)) {
-      int rank = co_popc32(lm[0]) + co_popc32(lm[1]) + co_popc32(lm[2] & ((1u << lane) - 1u));
-      A[b + 2 + rank] = make_uint4(CO_NONE, 0u, (uint32_t)(64 + lane), 0u);
-    }
+    const uint64_t lm01 = (uint64_t)lm[0] | ((uint64_t)lm[1] << 32);
+    if ((lm01 >> lane) & 1ull) A[b + 2 + LANE_RANK64(lm01)] = make_uint4(CO_NONE, 0u, (uint32_t)lane, 0u);
+    if (((uint64_t)lm[2] >> lane) & 1ull) A[b + 2 + n01 + LANE_RANK64((uint64_t)lm[2])] = make_uint4(CO_NONE, 0u, (uint32_t)(64 + lane), 0u);
   }
   WAVE_SYNC();
   return b;
@@ -764,7 +758,7 @@ CO_DEV void co_request_root(CoWave &w, CoTree &t) {
   WAVE_SYNC();
   uint64_t board = (uint64_t)h0.x | ((uint64_t)h0.y << 32);
   uint32_t lm[3];
-  co_legal_moves(board, h0.z, lm); /* (a root asks once per tree; its edges hold the same moves) */
+  co_legal_moves(board, h0.z, lm, w.K); /* (a root asks once per tree; its edges hold the same moves) */
   co_request(w, board, h0.z, root, (int)CO_META_NEDGES(h0.z), lm, 0, one_path);
 }
 
@@ -1191,7 +1185,7 @@ CO_DEV void co_analyse_finish(CoWave &w, CoTree &t, int choice) {
   uint4 h1 = co_load_unit(t.A, t.tc.root + 1);
   uint4 rs = co_load_unit(t.A, h1.x);
   uint32_t lm[3];
-  co_legal_moves((uint64_t)h0.x | ((uint64_t)h0.y << 32), h0.z, lm);
+  co_legal_moves((uint64_t)h0.x | ((uint64_t)h0.y << 32), h0.z, lm, w.K);
   uint32_t *out = (uint32_t *)w.req;
   FOR_LANES {
     if (lane == 0) {
@@ -1253,14 +1247,14 @@ CO_DEV int co_game_step(CoWave &w, const float *eval, const float *probs) {
       board = (uint64_t)w.gc.pos_lo | ((uint64_t)w.gc.pos_hi << 32);
       meta = w.gc.pos_meta;
       uint32_t lm[3];
-      co_legal_moves(board, meta, lm);
+      co_legal_moves(board, meta, lm, w.K);
       int n = co_popc32(lm[0]) + co_popc32(lm[1]) + co_popc32(lm[2]);
       choice = co_nth_move(lm, (int)co_uniform_below(w, (uint32_t)n));
       co_trace_push(w, -2);
       co_trace_push(w, choice);
       w.gc.plies++;
       co_do_move(&board, &meta, choice);
-      int lines = co_legal_moves(board, meta, lm);
+      int lines = co_legal_moves(board, meta, lm, w.K);
       terminal = (lm[0] | lm[1] | lm[2]) == 0u;
       tres = lines ? CO_RESULT_LOSS : CO_RESULT_DRAW;
       depth = w.gc.plies; /* root_->depth() */
@@ -1497,6 +1491,7 @@ CO_DEV void co_pool_housekeeping(const EngineParams &P, int g) {
 CO_DEV void co_wave_init(const EngineParams &P, int g, const GameCtl &gc, const TreeCtl &tc0, const TreeCtl &tc1, CoWave &w) {
   w.g = g;
   w.gc = gc;
+  co_lanes_init(w.K);
   {
     const size_t stride = (size_t)P.cap_units + CO_ARENA_PAD;
     const int tm = 2 * g + gc.to_play, to = 2 * g + 1 - gc.to_play;

@@ -54,35 +54,31 @@ CO_DEV void co_decode_move(int id, int *is_place, int *piece, int *from, int *to
   }
 }
 
-/* every 4th bit of x (bits 4c + k, k given by the caller's shift) gathered into bits 0..15 */
-CO_DEV uint32_t co_plane(uint64_t x) {
-  x &= 0x1111111111111111ull;
-  x = (x | (x >> 3)) & 0x0303030303030303ull;
-  x = (x | (x >> 6)) & 0x000F000F000F000Full;
-  x = (x | (x >> 12)) & 0x000000FF000000FFull;
-  x = (x | (x >> 24)) & 0xFFFFull;
-  return (uint32_t)x;
-}
+/* Per-lane constants of the rule layer: functions of the lane index alone, computed once per wavefront
+ * (co_lanes_init) and kept in registers across the simulations of a step.
+ *   candidate line j = lane < 34, in the reference's scan order: lanes 0-11 rows (i = j / 3; long, left triple, right
+ *   triple), 12-23 columns, 24-29 long diagonals (main: long, upper, lower; anti: ...), 30-33 short diagonals.  Every
+ *   candidate is an arithmetic progression of cells: line_mask = its cells, line_base = its first line_breakers index
+ *   (+ the top piece);
+ *   move id = lane < 48: the nibble shifts (4 x cell) of its source and destination cells (move.cpp:11-42);
+ *   placements: id 48 + cell on lanes 48-63 and ids 64 + lane on lanes 0-31 all look at cell lane & 15. */
+struct CoLanes {
+  LV(uint32_t, plane_hi);  /* the board bit this lane contributes to the plane ballot (piece lane >> 4 of cell lane & 15): */
+  LV(uint32_t, plane_sh);  /* ... in the high word?  and its position there */
+  LV(uint32_t, line_mask);
+  LV(int, line_base);
+  LV(uint32_t, from_hi);   /* move id = lane < 48: is the source cell's nibble in the high word of the board, */
+  LV(uint32_t, from_sh);   /* ... and its shift there */
+  LV(uint32_t, to_hi);
+  LV(uint32_t, to_sh);
+};
 
-/* game.cpp:28-43.  out[3] = 96-bit legal mask; returns is_lines.  Uniform.
- * The board is split into four 16-cell bit planes (base, column, capital, frozen); basic
- * legality of all 96 moves (game.cpp:193-242) is then ~80 wave-uniform bit operations on
- * those planes -- scalar work, no per-lane code -- and only the 34 candidate lines are
- * tested one per lane. */
-CO_DEV int co_legal_moves(uint64_t board, uint32_t meta, uint32_t out[3]) {
-  const uint32_t B = co_plane(board), C = co_plane(board >> 1), A = co_plane(board >> 2), F = co_plane(board >> 3);
-  const uint32_t N = B | C | A;             /* non-empty */
-  const uint32_t E = ~N & 0xFFFFu;          /* empty */
-  const uint32_t T2 = A, T1 = C & ~A, T0 = B & ~C & ~A; /* top piece (game.cpp:158-168) */
-  /* ---- the 34 candidate lines, in the reference's scan order: lanes 0-11 rows (i = j/3;
-   * long, left triple, right triple), 12-23 columns, 24-29 long diagonals (main: long, upper,
-   * lower; anti: ...), 30-33 short diagonals.  Every candidate is an arithmetic progression
-   * of cells; it is a line iff all its cells lie in one top-piece plane. */
-  LV(int, match);
-  LV(int, ctop);
-  LV(int, cbase);
+CO_DEV void co_lanes_init(CoLanes &K) {
   FOR_LANES {
-    int j = lane;
+    const int pbit = (lane & 15) * 4 + (lane >> 4);
+    L(K.plane_hi) = (uint32_t)(pbit >> 5);
+    L(K.plane_sh) = (uint32_t)(pbit & 31);
+    const int j = lane;
     int c0 = 0, step = 1, count = 0, base = 0;
     if (j < 12) {
       int i = j / 3, k = j % 3;
@@ -102,76 +98,111 @@ CO_DEV int co_legal_moves(uint64_t board, uint32_t meta, uint32_t out[3]) {
       c0 = s == 0 ? 2 : s == 1 ? 1 : s == 2 ? 7 : 4; step = (s & 1) ? 5 : 3; count = 3;
       base = 90 + 3 * s;
     }
-    uint32_t M = (1u << c0) | (1u << (c0 + step)) | (1u << (c0 + 2 * step));
-    if (count == 4) M |= 1u << (c0 + 3 * step);
-    int t = (T0 & M) == M ? 0 : (T1 & M) == M ? 1 : (T2 & M) == M ? 2 : -1;
-    L(match) = count != 0 && t >= 0;
-    L(ctop) = t;
-    L(cbase) = base;
+    uint32_t M = 0u;
+    if (count) {
+      M = (1u << c0) | (1u << (c0 + step)) | (1u << (c0 + 2 * step));
+      if (count == 4) M |= 1u << (c0 + 3 * step);
+    }
+    L(K.line_mask) = M;
+    L(K.line_base) = base;
+    int is_place, piece, from, to;
+    co_decode_move(lane < 48 ? lane : 0, &is_place, &piece, &from, &to);
+    L(K.from_hi) = (uint32_t)(from >> 3);
+    L(K.from_sh) = (uint32_t)(4 * (from & 7));
+    L(K.to_hi) = (uint32_t)(to >> 3);
+    L(K.to_sh) = (uint32_t)(4 * (to & 7));
   }
-  uint64_t cand = WAVE_BALLOT(match);
+}
+
+/* game.cpp:28-43.  out[3] = 96-bit legal mask; returns is_lines.  Uniform in, uniform out; inside:
+ *   the four 16-cell bit planes (base, column, capital, frozen) are ONE ballot -- lane l tests piece l >> 4 of cell
+ *   l & 15;
+ *   the 34 candidate lines are tested one per lane against the top-piece planes (game.cpp:249-405);
+ *   placements (canPlace, game.cpp:193-220) are a dozen bit operations on the planes;
+ *   stack moves (canMove, game.cpp:222-232): lane id < 48 looks at the nibbles of ITS move's two cells -- two compares
+ *   per lane, whose masks are the legality bits.
+ * (Round 3 computed planes and legality as ~450 scalar instructions per position -- the largest single cost of a
+ * simulation.) */
+CO_DEV int co_legal_moves(uint64_t board, uint32_t meta, uint32_t out[3], const CoLanes &K) {
+  const uint32_t blo = (uint32_t)board, bhi = (uint32_t)(board >> 32);
+  LV(int, pbit);
+  LV(int, mv1);
+  LV(int, mv2);
+  FOR_LANES {
+    L(pbit) = (int)(((L(K.plane_hi) ? bhi : blo) >> L(K.plane_sh)) & 1u);
+    /* a nibble = {base, column, capital, frozen} of a cell.  a -> b is legal iff both are non-empty, neither is frozen and
+     * bottom(a) - top(b) == 1: a column-bottomed stack (nibble 2 or 6) on a bare base (1), or a bare capital (4) on a
+     * column-topped stack (2 or 3) -- as one byte i = a | b << 4: i in {0x12, 0x16} or i in {0x24, 0x34} */
+    const uint32_t na = ((L(K.from_hi) ? bhi : blo) >> L(K.from_sh)) & 15u, nb = ((L(K.to_hi) ? bhi : blo) >> L(K.to_sh)) & 15u;
+    const uint32_t i = na | (nb << 4);
+    L(mv1) = lane < 48 && (i & 0xFBu) == 0x12u;
+    L(mv2) = lane < 48 && (i & 0xEFu) == 0x24u;
+  }
+  const uint64_t planes = WAVE_BALLOT(pbit);
+  const uint64_t moves = WAVE_BALLOT(mv1) | WAVE_BALLOT(mv2);
+  const uint32_t B = (uint32_t)planes & 0xFFFFu, C = (uint32_t)(planes >> 16) & 0xFFFFu, A = (uint32_t)(planes >> 32) & 0xFFFFu;
+  const uint32_t F = (uint32_t)(planes >> 48);
+  const uint32_t T2 = A, T1 = C & ~A, T0 = B & ~C & ~A; /* top piece (game.cpp:158-168) */
+  /* ---- lines: a candidate is a line iff all its cells lie in one top-piece plane */
+  LV(int, match);
+  LV(int, ctop);
+  FOR_LANES {
+    const uint32_t M = L(K.line_mask);
+    const int t = (T0 & M) == M ? 0 : (T1 & M) == M ? 1 : (T2 & M) == M ? 2 : -1;
+    L(match) = M != 0u && t >= 0;
+    L(ctop) = t;
+  }
+  const uint64_t cand = WAVE_BALLOT(match);
   uint32_t m0 = 0xFFFFFFFFu, m1 = 0xFFFFFFFFu, m2 = 0xFFFFFFFFu;
   int is_lines = 0;
-  /* one line per category, first match in scan order (game.cpp:265,310,330-356,368-388) */
-#pragma unroll
-  for (int cat = 0; cat < 4; ++cat) {
-    const uint64_t cmask = cat == 0 ? 0xFFFull : cat == 1 ? (0xFFFull << 12) : cat == 2 ? (0x3Full << 24) : (0xFull << 30);
-    uint64_t c = cand & cmask;
-    if (!c) continue;
+  if (cand) {
     is_lines = 1;
-    int j = co_ffs64(c) - 1;
-    int t = WAVE_BCAST(ctop, j);
-    int line = WAVE_BCAST(cbase, j) + t;
-    m0 &= CO_LINE_BREAKERS[line][0];
-    m1 &= CO_LINE_BREAKERS[line][1];
-    m2 &= CO_LINE_BREAKERS[line][2];
-    if (cat < 2 && t == 2) {
-      int k = (cat == 0 ? j : j - 12) % 3;
-      if (k != 0) {
-        /* capital triple in a row/column: game.cpp:280-309.  ec = extension
-         * coordinate; the cells Space{kk, ec, isCol}, kk = 0..3, are visited. */
-        int is_col = cat == 1;
-        int ec = k == 1 ? 3 : 0;
-        for (int kk = 0; kk < 4; ++kk) {
-          int cell = is_col ? (ec * 4 + kk) : (kk * 4 + ec);
-          if ((A >> cell) & 1u) continue;
-          /* moves kk -> kk-1 and kk -> kk+1 along that line of cells */
-          if (kk > 0) {
-            int id = is_col ? (24 + ec * 3 + (kk - 1)) : (36 + (kk - 1) * 4 + ec);
-            if (id < 32) m0 &= ~(1u << id); else m1 &= ~(1u << (id - 32));
-          }
-          if (kk < 3) {
-            int id = is_col ? (ec * 3 + kk) : (12 + kk * 4 + ec);
-            if (id < 32) m0 &= ~(1u << id); else m1 &= ~(1u << (id - 32));
+    /* one line per category, first match in scan order (game.cpp:265,310,330-356,368-388) */
+#pragma unroll
+    for (int cat = 0; cat < 4; ++cat) {
+      const uint64_t cmask = cat == 0 ? 0xFFFull : cat == 1 ? (0xFFFull << 12) : cat == 2 ? (0x3Full << 24) : (0xFull << 30);
+      uint64_t c = cand & cmask;
+      if (!c) continue;
+      int j = co_ffs64(c) - 1;
+      int t = WAVE_BCAST(ctop, j);
+      int line = WAVE_BCAST(K.line_base, j) + t;
+      m0 &= CO_LINE_BREAKERS[line][0];
+      m1 &= CO_LINE_BREAKERS[line][1];
+      m2 &= CO_LINE_BREAKERS[line][2];
+      if (cat < 2 && t == 2) {
+        int k = (cat == 0 ? j : j - 12) % 3;
+        if (k != 0) {
+          /* capital triple in a row/column: game.cpp:280-309.  ec = extension
+           * coordinate; the cells Space{kk, ec, isCol}, kk = 0..3, are visited. */
+          int is_col = cat == 1;
+          int ec = k == 1 ? 3 : 0;
+          for (int kk = 0; kk < 4; ++kk) {
+            int cell = is_col ? (ec * 4 + kk) : (kk * 4 + ec);
+            if ((A >> cell) & 1u) continue;
+            /* moves kk -> kk-1 and kk -> kk+1 along that line of cells */
+            if (kk > 0) {
+              int id = is_col ? (24 + ec * 3 + (kk - 1)) : (36 + (kk - 1) * 4 + ec);
+              if (id < 32) m0 &= ~(1u << id); else m1 &= ~(1u << (id - 32));
+            }
+            if (kk < 3) {
+              int id = is_col ? (ec * 3 + kk) : (12 + kk * 4 + ec);
+              if (id < 32) m0 &= ~(1u << id); else m1 &= ~(1u << (id - 32));
+            }
           }
         }
       }
     }
   }
-  /* ---- basic legality of all 96 moves on the planes.
-   * place (canPlace, game.cpp:193-220): an empty cell takes anything; a frozen one nothing;
-   * a column goes on a bare base; a capital on anything without a capital except a bare base */
-  const uint32_t NF = N & ~F;
-  const uint32_t tp3 = CO_META_TO_PLAY(meta) * 3;
-  uint32_t pb = CO_META_PIECE(meta, tp3 + 0) ? E : 0u;
-  uint32_t pc = CO_META_PIECE(meta, tp3 + 1) ? (E | (NF & B & ~C & ~A)) : 0u;
-  uint32_t pa = CO_META_PIECE(meta, tp3 + 2) ? (E | (NF & ~A & ~(B & ~C))) : 0u;
-  /* move a -> b (canMove, game.cpp:222-232): both non-empty, neither frozen,
-   * bottom(a) - top(b) == 1, i.e. (bottom 1 on top 0) or (bottom 2 on top 1) */
-  const uint32_t Bo1 = ~B & C, Bo2 = ~B & ~C & A;
-  const uint32_t R = NF & (NF >> 1) & ((Bo1 & (T0 >> 1)) | (Bo2 & (T1 >> 1))) & 0x7777u; /* from col < 3 */
-  const uint32_t D = NF & (NF >> 4) & ((Bo1 & (T0 >> 4)) | (Bo2 & (T1 >> 4))) & 0x0FFFu; /* from row < 3 */
-  const uint32_t Lf = NF & (NF << 1) & ((Bo1 & (T0 << 1)) | (Bo2 & (T1 << 1))) & 0xEEEEu; /* from col > 0 */
-  const uint32_t U = NF & (NF << 4) & ((Bo1 & (T0 << 4)) | (Bo2 & (T1 << 4))) & 0xFFF0u;  /* from row > 0 */
-  /* move ids (move.cpp:11-42): right r*3+c, down 12+cell, left 24+r*3+(c-1), up 36+cell-4 */
-  const uint32_t rid = (R & 7u) | (((R >> 4) & 7u) << 3) | (((R >> 8) & 7u) << 6) | (((R >> 12) & 7u) << 9);
-  const uint32_t lid = ((Lf >> 1) & 7u) | (((Lf >> 5) & 7u) << 3) | (((Lf >> 9) & 7u) << 6) | (((Lf >> 13) & 7u) << 9);
-  const uint32_t b0 = rid | (D << 12) | (lid << 24);
-  const uint32_t b1 = (lid >> 8) | ((U >> 4) << 4) | (pb << 16);
-  const uint32_t b2 = pc | (pa << 16);
-  out[0] = m0 & b0;
-  out[1] = m1 & b1;
-  out[2] = m2 & b2;
+  /* ---- placements on the planes (canPlace, game.cpp:193-220): an empty cell takes anything (frozen or not: the test for
+   * empty comes first); a frozen one nothing else; a column goes on a bare base, a capital on a column-topped stack */
+  const uint32_t E = ~(B | C | A) & 0xFFFFu;
+  const uint32_t mine = CO_META_TO_PLAY(meta) ? meta >> 9 : meta; /* the mover's three counters in the low nine bits */
+  const uint32_t pb = (mine & 7u) ? E : 0u;
+  const uint32_t pc = (mine & 0x38u) ? (E | (T0 & ~F)) : 0u;
+  const uint32_t pa = (mine & 0x1C0u) ? (E | (T1 & ~F)) : 0u;
+  out[0] = m0 & (uint32_t)moves;
+  out[1] = m1 & ((uint32_t)(moves >> 32) | (pb << 16));
+  out[2] = m2 & (pc | (pa << 16));
   return is_lines;
 }
 
@@ -195,18 +226,14 @@ CO_DEV void co_do_move(uint64_t *board, uint32_t *meta, int id) {
   *meta = m ^ (1u << 18);
 }
 
-/* game.cpp:45-58: lanes 0..63 write the board bits, lanes 0..5 the reserves.
+/* game.cpp:45-58: lanes 0..63 write the board bits, lanes 0..5 the reserves (the mover's first).
  * `row` has room for CO_STATE_STRIDE floats; the padding is zeroed. */
 CO_DEV void co_write_state(uint64_t board, uint32_t meta, float *row) {
+  /* the six counters in the mover's order: the second player's view swaps the two groups of nine bits */
+  const uint32_t pc = meta & 0x3FFFFu;
+  const uint32_t rot = CO_META_TO_PLAY(meta) ? ((pc >> 9) | (pc << 9)) & 0x3FFFFu : pc;
   FOR_LANES {
-    row[lane] = ((board >> lane) & 1ull) ? 1.0f : 0.0f;
-    if (lane < CO_STATE_STRIDE - 64) {
-      float v = 0.0f;
-      if (lane < 6) {
-        uint32_t tp = CO_META_TO_PLAY(meta);
-        v = (float)CO_META_PIECE(meta, (tp * 3 + lane) % 6) * 0.25f;
-      }
-      row[64 + lane] = v;
-    }
+    row[lane] = (float)(uint32_t)((board >> lane) & 1ull);
+    if (lane < CO_STATE_STRIDE - 64) row[64 + lane] = lane < 6 ? (float)((rot >> (3 * lane)) & 7u) * 0.25f : 0.0f;
   }
 }

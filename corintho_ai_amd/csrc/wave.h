@@ -71,6 +71,8 @@ static inline int emu_sum_i32(const int *p) {
 #define WAVE_MAX_F32(x) emu_max_f32(x)
 #define WAVE_SUM_I32(x) emu_sum_i32(x)
 #define WAVE_BCAST(x, i) (x[(i)])
+/* inside FOR_LANES: the number of set bits of a wave-uniform 64-bit mask below this lane's bit */
+#define LANE_RANK64(m) __builtin_popcountll((unsigned long long)(m) & ((1ull << lane) - 1ull))
 static inline int co_popc64(uint64_t v) { return __builtin_popcountll(v); }
 static inline int co_popc32(uint32_t v) { return __builtin_popcount(v); }
 static inline int co_ffs64(uint64_t v) { return __builtin_ffsll((long long)v); } /* 1-based, 0 if none */
@@ -193,6 +195,8 @@ __device__ __forceinline__ uint4 co_bcast<uint4>(uint4 v, int i) {
 #define WAVE_MAX_F32(x) co_wave_max_f32(x)
 #define WAVE_SUM_I32(x) co_wave_sum_i32(x)
 #define WAVE_BCAST(x, i) co_bcast(x, (i))
+/* inside FOR_LANES: the number of set bits of a wave-uniform 64-bit mask below this lane's bit (v_mbcnt_lo / _hi) */
+#define LANE_RANK64(m) ((int)__builtin_amdgcn_mbcnt_hi((uint32_t)((uint64_t)(m) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)(m), 0u)))
 __device__ __forceinline__ int co_popc64(uint64_t v) { return __popcll(v); }
 __device__ __forceinline__ int co_popc32(uint32_t v) { return __popc(v); }
 __device__ __forceinline__ int co_ffs64(uint64_t v) { return __ffsll((unsigned long long)v); }

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic A/B: time whole generations with two prebuilt engine libraries in the same process
 on the same GPU, alternating, so that box-to-box variance cancels.
-usage: ab.py libA.so libB.so [net] [games] [reps] [pools]"""
+usage: ab.py libA.so libB.so [libC.so ...] [net] [games] [reps] [pools]"""
 import ctypes as C
 import os
 import sys
@@ -11,11 +11,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from corintho_ai_amd import NET_MLP12X100, NET_RESCNN4, NET_RESCNN4_X3, Trainer, _lib, nets  # noqa: E402
 
-libs = sys.argv[1:3]
-net = sys.argv[3] if len(sys.argv) > 3 else "rescnn4x3"
-G = int(sys.argv[4]) if len(sys.argv) > 4 else 4096
-reps = int(sys.argv[5]) if len(sys.argv) > 5 else 3
-pools = int(sys.argv[6]) if len(sys.argv) > 6 else 1
+libs = [a for a in sys.argv[1:] if a.endswith(".so")]
+rest = [a for a in sys.argv[1:] if not a.endswith(".so")]
+net = rest[0] if len(rest) > 0 else "rescnn4x3"
+G = int(rest[1]) if len(rest) > 1 else 4096
+reps = int(rest[2]) if len(rest) > 2 else 3
+pools = int(rest[3]) if len(rest) > 3 else 1
 kind = {"mlp12x100": NET_MLP12X100, "mlp12x100x3": 4, "rescnn4": NET_RESCNN4, "rescnn4x3": NET_RESCNN4_X3, "rescnn4h3": 8, "mlp12x100h3": 9,
         "rescnn4x6": 5, "mlp12x100x6": 6}[net]
 w = nets.init_mlp12x100(0) if net.startswith("mlp12x100") else nets.init_rescnn4(0)

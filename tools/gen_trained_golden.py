@@ -68,6 +68,55 @@ def extra_models(ids=(92, 4)):
     print("ref_models.npz:", sorted(out))
 
 
+# The population of round 4 (tests/test_reference_results.py, tools/ref_population.py): players of
+# rating/tourney/players.txt chosen before any of their rows was replayed -- the next-strongest two (2, 3: does the
+# oddity of player 1's first-mover rows repeat for them?) and 18 drawn with a fixed seed from the searching players
+# 4 .. 93 that were not committed yet.  Player p <= 93 plays checkpoint model_(93 - p).
+POPULATION_SEED = 20261004
+
+
+def population_players():
+    rng = np.random.default_rng(POPULATION_SEED)
+    cand = [p for p in range(4, 94) if p not in (46, 89, 90)]
+    return [2, 3] + sorted(int(x) for x in rng.choice(cand, 18, replace=False))
+
+
+def population_models():
+    """tests/golden/ref_models_pop.npz: weights (the engine's flat layout) of the population's checkpoints"""
+    out = {}
+    states = np.load(os.path.join(OUT, "net_vectors.npz"))["states"][:64]
+    for p in population_players():
+        i = 93 - p
+        path = os.path.join(REF, "model_%d.tflite" % i)
+        w = TI.mlp12x100_from_tflite(path)
+        m = TI.read_tflite(path)
+        roles = TI.output_roles(m)
+        g = TI.tflite_forward_np(m, states, dtype=np.float64)
+        v2, p2 = nets.mlp12x100_forward_f64(w, states)
+        assert np.max(np.abs(v2 - g[roles["value"]][:, 0])) < 2e-6 and np.max(np.abs(p2 - g[roles["policy"]])) < 2e-6
+        out["model_%d" % i] = w
+    np.savez_compressed(os.path.join(OUT, "ref_models_pop.npz"), **out)
+    print("ref_models_pop.npz: players", population_players(), "models", sorted(int(k.split("_")[1]) for k in out))
+    # the reference's rows between the 25 committed players (data of rating/results.txt: first player, second player,
+    # the first player's wins, draws, losses), all 600 ordered pairs
+    import json
+
+    players = sorted([0, 1, 46, 89, 90] + population_players())
+    rows = []
+    for line in open("/root/reference/corintho_ai/rating/results.txt"):
+        f = line.split()
+        if len(f) == 5 and int(f[0]) in players and int(f[1]) in players:
+            rows.append([int(x) for x in f])
+    assert len(rows) == len(players) * (len(players) - 1)
+    json.dump({"source": "corintho_ai/rating/results.txt (rows between the listed players of rating/tourney/players.txt; "
+                         "player p <= 93 plays model_(93 - p) with `1600 16 3.0 0.25 0`)",
+               "players": players, "rows": rows}, open(os.path.join(OUT, "ref_results_pop.json"), "w"))
+    print("ref_results_pop.json: %d rows, %d games" % (len(rows), sum(sum(r[2:]) for r in rows)))
+
+
 if __name__ == "__main__":
-    main()
-    extra_models()
+    if "--population" in sys.argv:
+        population_models()
+    else:
+        main()
+        extra_models()
