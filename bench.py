@@ -101,8 +101,9 @@ def parse():
     ap.add_argument("--arena-units", type=int, default=0)
     ap.add_argument("--no-unshared", action="store_true", help="skip the extra single-pool generation behind roofline.unshared (profiling runs)")
     ap.add_argument("--pools", type=int, default=0, help="independent game pools on separate streams per GPU (0 = engine default)")
-    ap.add_argument("--cpu-games", type=int, default=1024, help="games of the bounded CPU-baseline sample (0 = skip)")
-    ap.add_argument("--cpu-seconds", type=float, default=6.0, help="CPU time budget of each CPU-baseline leg")
+    ap.add_argument("--cpu-games", type=int, default=64,
+                    help="games of the CPU-baseline generation that carries cpu_baseline.value, played to the end (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=60.0, help="safety cap of each CPU-baseline leg (a leg that hits it is reported as extrapolated)")
     ap.add_argument("--recycle-games", type=int, default=16384,
                     help="games of the `recycled` variant: one generation of this many games on --games resident slots "
                          "(a slot whose game ends takes the next game); 0 = skip")
@@ -118,28 +119,66 @@ def parse():
 def launch_ranks(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, the
     environment torch.distributed.run would give them), relay rank 0's JSON line, fail if any rank fails.
-    Runs before anything touches the GPU in this process."""
+    Runs before anything touches the GPU in this process.  All children are watched: the first one to fail ends
+    the others (a rank that died during set-up would otherwise leave the rest waiting in a collective), and the
+    whole job has a time limit.  Children are always fresh processes, never a re-exec of this one."""
     import socket
     import subprocess
+    import tempfile
 
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    env = dict(os.environ, WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-               LOCAL_WORLD_SIZE=str(args.gpus), CORINTHO_BENCH_SELF_LAUNCHED="1")
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    limit_s = float(os.environ.get("CORINTHO_BENCH_TIMEOUT", "3000"))
     cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
-    procs = []
-    for r in range(args.gpus):
-        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
-    sys.stdout.flush()
-    if any(rcs):
-        raise SystemExit("bench.py --gpus %d: rank exit codes %s" % (args.gpus, rcs))
+    for attempt in range(3):  # the rendezvous port is free when we look, not necessarily when rank 0 binds it: retry
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        env = dict(os.environ, WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   LOCAL_WORLD_SIZE=str(args.gpus), CORINTHO_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        outs = [tempfile.TemporaryFile() for _ in range(args.gpus)]
+        errs = [tempfile.TemporaryFile() for _ in range(args.gpus)]
+        procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=outs[r], stderr=errs[r])
+                 for r in range(args.gpus)]
+        t0 = time.time()
+        failed = None
+        while True:
+            rcs = [p.poll() for p in procs]
+            bad = [r for r, rc in enumerate(rcs) if rc not in (None, 0)]
+            if bad:
+                failed = bad[0]
+                break
+            if all(rc == 0 for rc in rcs):
+                break
+            if time.time() - t0 > limit_s:
+                failed = -1
+                break
+            time.sleep(0.2)
+        if failed is not None:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+        texts = []
+        for f in errs:
+            f.seek(0)
+            texts.append(f.read().decode(errors="replace"))
+        if failed is not None and failed >= 0 and "EADDRINUSE" in texts[failed].upper().replace(" ", "") and attempt < 2:
+            continue  # someone took the port between our look and the rank's bind
+        for r, t in enumerate(texts):  # what the ranks wrote to stderr is relayed, rank by rank
+            if t.strip():
+                sys.stderr.write("".join("[rank %d] %s\n" % (r, line) for line in t.rstrip().split("\n")))
+        if failed is not None:
+            raise SystemExit("bench.py --gpus %d: %s" % (args.gpus, "time limit of %.0f s reached" % limit_s if failed < 0 else
+                                                        "rank %d exited with code %s; the other ranks were stopped" % (failed, procs[failed].returncode)))
+        outs[0].seek(0)
+        sys.stdout.write(outs[0].read().decode())
+        sys.stdout.flush()
+        return
 
 
 def measured_traffic(kernel, args, net, npools):
@@ -191,13 +230,13 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_leg(args, G, threads, net_name, weights, budget_s, evals_per_game):
+def cpu_leg(args, G, threads, net_name, weights, cap_s, evals_per_game):
     """One leg of the CPU baseline: the oracle (CPU restatement of the reference's OpenMP path,
-    trainer.cpp:175-196) on `threads` host threads, `G` games of the bench workload, the network
-    evaluated on the CPU between iterations as the reference's Keras loop does (main.pyx:70-83), for
-    `budget_s` seconds of wall time (whole iterations).  The sample covers the first iterations of
-    the generation -- all games running, batches of G x spe rows -- and is scaled to games/s by the
-    leaf evaluations a game needs (measured on the GPU run of the same workload)."""
+    trainer.cpp:175-196) on `threads` host threads plays ONE WHOLE generation of `G` games of the bench
+    workload, the network evaluated on the CPU between iterations as the reference's Keras loop does
+    (main.pyx:70-83).  games/s = G / wall time of the finished generation.  `cap_s` is a safety net only: a
+    leg still running then stops and reports its rate scaled by the evaluations a game needs
+    (finished = false)."""
     from corintho_ai_amd import nets
     from oracle import oracle as O
     from tests import harness as H
@@ -242,36 +281,41 @@ def cpu_leg(args, G, threads, net_name, weights, budget_s, evals_per_game):
         probs[:n] = p
         rows += n
         iters += 1
-        if time.perf_counter() - t0 >= budget_s and iters >= 2:
+        if time.perf_counter() - t0 >= cap_s:
             break
     dt = time.perf_counter() - t0
-    return {"games_per_s": rows / dt / evals_per_game, "leaf_evals_per_s": rows / dt, "threads": threads, "net": net_name,
-            "seconds": dt, "network_seconds": nn_s, "iterations": iters, "rows": rows, "finished": bool(done)}
+    return {"games_per_s": G / dt if done else rows / dt / evals_per_game, "leaf_evals_per_s": rows / dt, "threads": threads,
+            "net": net_name, "games": G, "seconds": dt, "network_seconds": nn_s, "iterations": iters, "rows": rows,
+            "finished": bool(done)}
 
 
 def cpu_baseline(args, arch, weights_by_arch, evals_per_game):
+    """Whole (small) generations of the bench workload on the host cores, one per leg, sized so that each takes
+    seconds: `--cpu-games` games for the leg that carries `value` (all cores, the bench's architecture), fewer for
+    one thread, more for the cheap network and for the search alone."""
     cores = host_cores()
     G = args.cpu_games
     legs = {}
     other = "mlp12x100" if arch == "rescnn4" else "rescnn4"
+    size = {"rescnn4": (G, max(G // 4, 8)), "mlp12x100": (4 * G, 2 * G), "none": (16 * G, 4 * G)}
     for name, threads, net in (("all_cores", cores, arch), ("one_thread", 1, arch),
                                ("all_cores_" + other, cores, other), ("one_thread_" + other, 1, other),
                                ("all_cores_search_only", cores, "none"), ("one_thread_search_only", 1, "none")):
-        legs[name] = cpu_leg(args, G, threads, net, weights_by_arch.get(net), args.cpu_seconds, evals_per_game)
+        legs[name] = cpu_leg(args, size[net][0 if threads > 1 else 1], threads, net, weights_by_arch.get(net), args.cpu_seconds, evals_per_game)
     main = legs["all_cores"]
     return {
         "value": main["games_per_s"],
         "unit": "games/s",
         "cores": cores,
         "kind": "port",
-        "extrapolated": not main["finished"],  # the first iterations of the generation, scaled by evaluations per game
+        "extrapolated": not main["finished"],
         "cpu_model": cpu_model(),
         "sample": "oracle/ (C restatement of trainer.cpp/selfplayer.cpp/trainmc.cpp, OpenMP over games) + float32 %s on the host "
-                  "(%s), %d threads: the first %d iterations of a %d-game generation of the bench workload (%d sims/move, spe %d; "
-                  "batches of %d rows), %.1f s, %.1f s of it network; leaf evaluations/s scaled to games/s by the %.0f "
-                  "evaluations a game takes in the GPU run"
-                  % (arch, "torch CPU" if arch == "rescnn4" else "numpy", cores, main["iterations"], G, args.sims, args.spe,
-                     main["rows"] // max(main["iterations"], 1), main["seconds"], main["network_seconds"], evals_per_game),
+                  "(%s), %d threads: one whole generation of %d games of the bench workload (%d sims/move, spe %d), played to the "
+                  "end%s: %d iterations, %d request rows, %.1f s, %.1f s of it network"
+                  % (arch, "torch CPU" if arch == "rescnn4" else "numpy", cores, main["games"], args.sims, args.spe,
+                     "" if main["finished"] else " -- NOT reached within the cap, rate scaled by evaluations per game", main["iterations"],
+                     main["rows"], main["seconds"], main["network_seconds"]),
         "one_thread": legs["one_thread"]["games_per_s"],
         "legs": legs,
     }
@@ -288,6 +332,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     emu = args.engine == "emu"
+    if os.environ.get("CORINTHO_BENCH_TEST_FAIL_RANK") == str(rank):  # tests/test_distributed_cpu.py: a rank that dies during set-up
+        raise SystemExit(3)
     dist = None
     torch = None
     use_dist = world > 1 or os.environ.get("CORINTHO_FORCE_DIST") == "1"  # the latter: 1-rank rehearsal of the RCCL path
@@ -410,37 +456,51 @@ def main():
         barrier()
         return time.perf_counter() - t0, totals
 
-    def roofline_of(net, totals, npools):
-        """roofline object of the dominant kernel family of a measured run (HIP-event durations of the
-        timed launches on the pools' streams: one iteration per pool and window of eight carries events)"""
+    def rooflines_of(net, totals, npools, wall_s=None, generations=1):
+        """roofline objects of both kernel families of a measured run: (dominant, {"network": .., "search": ..}).
+        Per-launch rates from the HIP-event durations of the timed launches on the pools' streams (one iteration per
+        pool and window of eight carries events); `wall` = the same algorithmic work over the run's wall time."""
         _, arch, dtype, peak, issued, kname = NETS[net]
         flop_per_row = flop_by_arch[arch]
         nn_s, mcts_s = totals["nn_ms"] * 1e-3, totals["mcts_ms"] * 1e-3
         tl = totals["timed_launches"]
-        if nn_s >= mcts_s:
-            if tl > 0:
-                achieved = totals["nn_timed_rows"] * flop_per_row / max(totals["nn_timed_ms"] * 1e-3, 1e-12) / 1e12
-            else:
-                achieved = totals["nn_rows_evaluated"] * flop_per_row / max(nn_s, 1e-12) / 1e12
-            useful = nets.rescnn4_useful_flop_per_row() / flop_per_row if arch == "rescnn4" else 1.0
-            r = {"kernel": kname, "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                 "frac": achieved / peak, "traffic": measured_traffic(kname, args, net, npools),
-                 "issued_frac": issued * achieved / peak,
-                 # products of a 3x3 tap with the zero padding of the 4x4 board (44 of 144) not counted as work
-                 "algorithmic_useful": {"achieved": achieved * useful, "frac": achieved * useful / peak},
-                 "algorithmic": "%.1f KFLOP/row x %d rows in %d timed launches of %d (x%d MFMA products issued per algorithmic one)"
-                                % (flop_per_row / 1e3, totals["nn_timed_rows"] if tl else totals["nn_rows_evaluated"],
-                                   tl if tl else totals["nn_launches"], totals["nn_launches"], int(issued)),
-                 "avg_launch_ms": (totals["nn_timed_ms"] / tl) if tl else totals["nn_ms"] / max(totals["nn_launches"], 1)}
+        if tl > 0:
+            achieved = totals["nn_timed_rows"] * flop_per_row / max(totals["nn_timed_ms"] * 1e-3, 1e-12) / 1e12
         else:
-            achieved = totals["searches"] * BYTES_PER_SIM / max(mcts_s, 1e-12) / 1e9
-            r = {"kernel": "co_k_mcts_step", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                 "traffic": measured_traffic("co_k_mcts_step", args, net, npools),
-                 "algorithmic": "%.0f B/simulation x %d simulations" % (BYTES_PER_SIM, totals["searches"]),
-                 "avg_launch_ms": (totals["mcts_timed_ms"] / tl) if tl else totals["mcts_ms"] / max(totals["mcts_launches"], 1)}
-        r["streams"] = npools
-        return r
+            achieved = totals["nn_rows_evaluated"] * flop_per_row / max(nn_s, 1e-12) / 1e12
+        useful = nets.rescnn4_useful_flop_per_row() / flop_per_row if arch == "rescnn4" else 1.0
+        rn = {"kernel": kname, "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+              "frac": achieved / peak, "traffic": measured_traffic(kname, args, net, npools),
+              "issued_frac": issued * achieved / peak,
+              # products of a 3x3 tap with the zero padding of the 4x4 board (44 of 144) not counted as work
+              "algorithmic_useful": {"achieved": achieved * useful, "frac": achieved * useful / peak},
+              "algorithmic": "%.1f KFLOP/row x %d rows in %d timed launches of %d (x%d MFMA products issued per algorithmic one)"
+                             % (flop_per_row / 1e3, totals["nn_timed_rows"] if tl else totals["nn_rows_evaluated"],
+                                tl if tl else totals["nn_launches"], totals["nn_launches"], int(issued)),
+              "avg_launch_ms": (totals["nn_timed_ms"] / tl) if tl else totals["nn_ms"] / max(totals["nn_launches"], 1)}
+        sims_per_launch = totals["searches"] / max(totals["mcts_launches"], 1)
+        s_launch_ms = (totals["mcts_timed_ms"] / tl) if tl else totals["mcts_ms"] / max(totals["mcts_launches"], 1)
+        achieved_s = sims_per_launch * BYTES_PER_SIM / max(s_launch_ms * 1e-3, 1e-12) / 1e9
+        rs = {"kernel": "co_k_mcts_step (+ co_k_priors)", "bound": "hbm", "achieved": achieved_s, "peak": HBM_PEAK_GBS,
+              "unit": "GB/s", "frac": achieved_s / HBM_PEAK_GBS,
+              "traffic": measured_traffic("co_k_mcts_step", args, net, npools),
+              "algorithmic": "%.0f B/simulation x %.0f simulations per launch (%d simulations in %d launches)"
+                             % (BYTES_PER_SIM, sims_per_launch, totals["searches"], totals["mcts_launches"]),
+              "avg_launch_ms": s_launch_ms,
+              "note": "graph work classified under the HBM roofline (bytes per simulation, SURVEY 8d); what bounds it is one "
+                      "wavefront's dependent instruction chain per game, not bandwidth (DESIGN section 6)"}
+        if wall_s:
+            # the same algorithmic work over the wall time of the timed region: <= 1 by construction (the per-launch rates
+            # of two pools' streams overlap in time and may add up to more than the wall-level one)
+            rn["wall"] = {"achieved": totals["nn_rows_evaluated"] * flop_per_row / wall_s / 1e12,
+                          "frac": totals["nn_rows_evaluated"] * flop_per_row / wall_s / 1e12 / peak}
+            rs["wall"] = {"achieved": totals["searches"] * BYTES_PER_SIM / wall_s / 1e9,
+                          "frac": totals["searches"] * BYTES_PER_SIM / wall_s / 1e9 / HBM_PEAK_GBS}
+        rn["streams"] = rs["streams"] = npools
+        return (rn if nn_s >= mcts_s else rs), {"network": rn, "search": rs}
+
+    def roofline_of(net, totals, npools, wall_s=None):
+        return rooflines_of(net, totals, npools, wall_s)[0]
 
     # ------------------------------------------------------------------ the timed region
     dt, totals = run_generations(tr, args.net, args.steps, args.warmup, 0, use_dist)
@@ -469,7 +529,7 @@ def main():
         nn_s = totals["nn_ms"] * 1e-3
         mcts_s = totals["mcts_ms"] * 1e-3
         npools = int(totals.get("pools", 1))
-        roofline = roofline_of(args.net, totals, npools)
+        roofline, both = rooflines_of(args.net, totals, npools, wall_s=dt)
         if npools > 1 and not args.no_unshared and world == 1:
             # The timed region runs the games as `npools` pools on separate streams, so the durations
             # above are those of kernels SHARING the GPU with the other pool's kernels (their sum
@@ -504,6 +564,9 @@ def main():
                 "c_puct": args.c_puct, "epsilon": args.epsilon, "parallelism": "games sharded x%d" % world,
             },
             "roofline": roofline,
+            # the other kernel family of the same run (BASELINE.md section 3 asks for the search kernel AND the inference kernel)
+            "roofline_search": both["search"],
+            "roofline_network": both["network"],
             "detail": {
                 "sims_per_s": job_searches / dt,
                 "leaf_evals_per_s": job_evals / dt,
@@ -545,7 +608,7 @@ def main():
                 d1, t1 = run_generations(tr, name, vsteps, 1, 7000, False)
                 vflop = flop_by_arch[NETS[name][1]]
                 variants[name] = {"games_per_s": G * vsteps / d1, "ms_per_step": d1 * 1e3 / vsteps, "steps": vsteps, "warmup": 1,
-                                  "dtype": NETS[name][2], "roofline": roofline_of(name, t1, int(t1.get("pools", 1))),
+                                  "dtype": NETS[name][2], "roofline": roofline_of(name, t1, int(t1.get("pools", 1)), wall_s=d1),
                                   "network_TFLOPs_algorithmic": t1["nn_rows_evaluated"] * vflop / max(t1["nn_ms"] * 1e-3, 1e-12) / 1e12,
                                   "nn_rows_evaluated_over_requested": t1["nn_rows_evaluated"] / max(t1["nn_rows"], 1),
                                   "mcts_GBps_algorithmic": t1["searches"] * BYTES_PER_SIM / max(t1["mcts_ms"] * 1e-3, 1e-12) / 1e9,
@@ -557,7 +620,7 @@ def main():
                 d3, t3 = run_generations(tr3, args.net, min(5, args.steps), 1, 11000, False)
                 n3 = min(5, args.steps)
                 out["detail"]["no_eval_cache"] = {"games_per_s": G * n3 / d3, "ms_per_step": d3 * 1e3 / n3, "steps": n3, "warmup": 1,
-                                                  "roofline": roofline_of(args.net, t3, int(t3.get("pools", 1))),
+                                                  "roofline": roofline_of(args.net, t3, int(t3.get("pools", 1)), wall_s=d3),
                                                   "nn_rows_evaluated_over_requested": t3["nn_rows_evaluated"] / max(t3["nn_rows"], 1)}
                 del tr3
         if world == 1 and args.recycle_games > G:
@@ -570,10 +633,20 @@ def main():
             out["detail"]["recycled"] = {
                 "games_per_s": args.recycle_games * rsteps / d2, "games": args.recycle_games, "resident_slots": G,
                 "steps": rsteps, "warmup": 1, "ms_per_step": d2 * 1e3 / rsteps,
-                "network_batch": batch_fill(t2, G), "roofline": roofline_of(args.net, t2, int(t2.get("pools", 1))),
+                "network_batch": batch_fill(t2, G), "roofline": roofline_of(args.net, t2, int(t2.get("pools", 1)), wall_s=d2),
                 "iterations_per_step": t2["iterations"] / rsteps,
                 "note": "same workload per game; %d games per generation on %d slots" % (args.recycle_games, G)}
             del tr2
+        # the numbers a reader compares `value` with, in one place (each is measured above, same workload)
+        d = out["detail"]
+        out["detail"]["summary"] = {
+            "games_per_s": value,
+            "no_eval_cache_games_per_s": d.get("no_eval_cache", {}).get("games_per_s"),
+            "float32_equivalent_bf16x6_games_per_s": d.get("variants", {}).get("rescnn4x6", {}).get("games_per_s"),
+            "fp32_mfma_games_per_s": d.get("variants", {}).get("rescnn4", {}).get("games_per_s"),
+            "reference_network_mlp12x100h3_games_per_s": d.get("variants", {}).get("mlp12x100h3", {}).get("games_per_s"),
+            "recycled_games_per_s": d.get("recycled", {}).get("games_per_s"),
+        }
         if world == 1 and args.cpu_games > 0:
             out["cpu_baseline"] = cpu_baseline(args, arch, weights_by_arch, out["detail"]["evals_per_game"])
         print(json.dumps(out))

@@ -101,6 +101,18 @@ def test_bench_gpus_2_launches_two_ranks_itself():
     assert o1["n_gpus"] == 1 and o1["detail"]["ranks_seen"] == 1 and "collectives_per_step" not in o1["detail"]
 
 
+def test_bench_ends_every_rank_when_one_dies_during_set_up():
+    """a rank other than 0 that dies before the communicator is up: the launcher stops the survivors (rank 0 would
+    otherwise wait in the rendezvous until its time-out) and reports the rank and its exit code"""
+    import time
+
+    t0 = time.time()
+    r = _bench(["--gpus", "2"] + TINY, env_extra={"CORINTHO_BENCH_TEST_FAIL_RANK": "1"}, timeout=120)
+    assert r.returncode != 0 and time.time() - t0 < 90
+    assert "rank 1 exited with code 3" in r.stderr, r.stderr[-2000:]
+    assert not r.stdout.strip()
+
+
 def test_bench_refuses_a_world_size_that_is_not_gpus():
     r = _bench(["--gpus", "4"] + TINY, {"WORLD_SIZE": "2", "RANK": "0"})
     assert r.returncode != 0 and "does not match WORLD_SIZE" in r.stderr
