@@ -541,7 +541,7 @@ struct ca_trainer {
     P.turn_list = nullptr;
     P.turn_count = nullptr;
 #ifdef CO_PROF
-    prof.alloc((size_t)R * 16 + 24, stream);
+    prof.alloc((size_t)R * CO_NPROF + 24, stream);
     P.prof = prof.p;
 #else
     P.prof = nullptr;
@@ -1681,19 +1681,19 @@ extern "C" int ca_tourney_stats(ca_tourney *t, ca_stats *out) {
 }
 
 /* diagnostic builds (-DCO_PROF): summed in-kernel cycle stamps, see mcts.h; not in the public header */
-extern "C" int ca_trainer_prof(ca_trainer *t, unsigned long long out[36]) {
+extern "C" int ca_trainer_prof(ca_trainer *t, unsigned long long out[CO_NPROF + 20]) {
   CA_TGUARD({
-    for (int i = 0; i < 36; ++i) out[i] = 0;
+    for (int i = 0; i < CO_NPROF + 20; ++i) out[i] = 0;
     if (!t->prof.p) throw EngineError(CA_ERR_STATE, "not a -DCO_PROF build");
-    std::vector<unsigned long long> h((size_t)t->R * 16);
+    std::vector<unsigned long long> h((size_t)t->R * CO_NPROF);
     rt_d2h(h.data(), t->prof.p, h.size() * 8, t->stream);
     rt_sync(t->stream);
     for (int g = 0; g < t->R; ++g)
-      for (int i = 0; i < 16; ++i) out[i] += h[(size_t)g * 16 + i];
+      for (int i = 0; i < CO_NPROF; ++i) out[i] += h[(size_t)g * CO_NPROF + i];
     unsigned long long clk[20];
-    rt_d2h(clk, t->prof.p + (size_t)t->R * 16, sizeof clk, t->stream);
+    rt_d2h(clk, t->prof.p + (size_t)t->R * CO_NPROF, sizeof clk, t->stream);
     rt_sync(t->stream);
-    for (int i = 0; i < 20; ++i) out[16 + i] = clk[i];
+    for (int i = 0; i < 20; ++i) out[CO_NPROF + i] = clk[i];
   })
 }
 

@@ -21,30 +21,37 @@ CO_CONST uint32_t CO_GAMMA_BITS[CO_NUM_GAMMA] = CO_GAMMA_BITS_INIT;
 
 #define CO_NEG_INF (-__builtin_huge_valf())
 
-/* in-kernel phase stamps (diagnostic build only: hipcc -DCO_PROF); slots:
- * 0 receive, 1 search, 2 choose/hand-over, 3 expand (inside 1), 4 steps, 5 searches, 6 receives */
+/* In-kernel phase stamps (diagnostic build only: hipcc -DCO_PROF, tools/prof_phases.py).  A wavefront keeps ONE running
+ * clock (w.tph): CO_PH(slot) charges the cycles since the previous stamp to `slot`, so the slots add up to the wave's
+ * whole step; the sums live in registers and are written once, at the end of the step (a stamp is an s_memtime and a
+ * wait for it, ~50 cycles).  CO_PH_MEM(slot) first waits for the wave's outstanding memory operations, so that a phase
+ * that ends with loads in flight is charged their latency (it also removes the overlap the product build has).
+ * Slots: 0 backup: indices, 1 backup: slots fetched, 2 move choice / hand-over, 3 backup: sums and stores,
+ *   4 steps (count), 5 simulations (count), 6 evaluations received (count), 7 whole step (cycles, measured apart),
+ *   8 PUCT scan, 9 virtual-loss store + path, 10 expansion: slot + path update, 11 descent: block fetch waited for,
+ *   12 terminal leaf, 13 (unused), 14 expansion: legal moves, 15 expansion: node stores, 16 expansion: doMove,
+ *   17 request: state row, 18 request: pending-leaf records, 19 simulation start (root copy), 20 loop control + root
+ *   load, 21 step tail (noise, batch rows, cache), 22 wave set-up, 23 levels scanned (count), 24 expansions (count) */
+#define CO_NPROF 32
 #if defined(CO_PROF) && !defined(CO_EMU)
 #define CO_CLK() __builtin_amdgcn_s_memtime()
-#define CO_PROF_ADD(w, slot, v)                                   \
-  do {                                                            \
-    if ((w).prof && (threadIdx.x & 63) == 0) (w).prof[slot] += (v); \
-  } while (0)
-/* phases of one simulation (slots 8..13): scan, slot stores, expansion, block fetch of the descent (waited for),
- * terminal handling, request */
+#define CO_PROF_ADD(w, slot, v) ((w).pacc[slot] += (v))
 #define CO_PH(slot)                               \
   do {                                            \
     unsigned long long now_ = CO_CLK();           \
-    CO_PROF_ADD(w, slot, now_ - tph_);            \
-    tph_ = now_;                                  \
+    w.pacc[slot] += now_ - w.tph;                 \
+    w.tph = now_;                                 \
   } while (0)
-#define CO_PH_START() unsigned long long tph_ = CO_CLK()
-#define CO_PH_DRAIN() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#define CO_PH_MEM(slot)                                               \
+  do {                                                                \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       \
+    CO_PH(slot);                                                      \
+  } while (0)
 #else
 #define CO_CLK() 0ull
 #define CO_PROF_ADD(w, slot, v) ((void)0)
 #define CO_PH(slot) ((void)0)
-#define CO_PH_START() ((void)0)
-#define CO_PH_DRAIN() ((void)0)
+#define CO_PH_MEM(slot) ((void)0)
 #endif
 
 struct CoTree {
@@ -56,6 +63,9 @@ struct CoTree {
 struct CoWave {
   int g;
   GameCtl gc;
+#if defined(CO_PROF) && !defined(CO_EMU)
+  unsigned long long pacc[CO_NPROF], tph;
+#endif
   CoLanes K; /* per-lane constants of the rule layer (rules.h) */
   /* the tree of the player to move and the opponent's; swapped on hand-over so that
    * no register-resident state is indexed dynamically (that would spill to scratch) */
@@ -133,6 +143,7 @@ CO_DEV uint32_t co_create_node(CoWave &w, CoTree &t, uint64_t board, uint32_t me
                                uint32_t self_slot, int *res_out, int *n_out = (int *)0, uint32_t *lm_out = (uint32_t *)0) {
   uint32_t lm[3];
   int is_lines = co_legal_moves(board, meta_game, lm, w.K);
+  CO_PH(14);
   if (lm_out) {
     lm_out[0] = lm[0];
     lm_out[1] = lm[1];
@@ -167,6 +178,7 @@ CO_DEV uint32_t co_create_node(CoWave &w, CoTree &t, uint64_t board, uint32_t me
     if (((uint64_t)lm[2] >> lane) & 1ull) A[b + 2 + n01 + LANE_RANK64((uint64_t)lm[2])] = make_uint4(CO_NONE, 0u, (uint32_t)(64 + lane), 0u);
   }
   WAVE_SYNC();
+  CO_PH(15);
   return b;
 }
 
@@ -176,6 +188,7 @@ CO_DEV void co_request(CoWave &w, uint64_t board, uint32_t meta, uint32_t leaf, 
                        const uint32_t *path_slot) {
   int k = w.gc.n_pending;
   co_write_state(board, meta, w.req + (size_t)k * CO_STATE_STRIDE);
+  CO_PH(17);
   uint32_t *pp = w.pend_path + (size_t)k * CO_PATH_MAX;
   const uint32_t pn = ((uint32_t)w.noise_words << 8) | (uint32_t)n_edges;
   w.noise_words += n_edges; /* one generator output per legal move (trainmc.cpp:236-246) */
@@ -196,6 +209,7 @@ CO_DEV void co_request(CoWave &w, uint64_t board, uint32_t meta, uint32_t leaf, 
   }
   WAVE_SYNC();
   w.gc.n_pending = k + 1;
+  CO_PH(18);
 }
 
 /* ---- receiveEval (trainmc.cpp:269-296), split in two.
@@ -400,6 +414,7 @@ CO_DEV void co_backup_batch(CoWave &w, CoTree &t, int k0, int nb, const float *e
       L(at[k]) = pp[L(on[k]) ? lane : 0];
     }
   }
+  CO_PH_MEM(0);
 #pragma unroll
   for (int k = 0; k < CO_RB; ++k) {
     FOR_LANES {
@@ -409,6 +424,7 @@ CO_DEV void co_backup_batch(CoWave &w, CoTree &t, int k0, int nb, const float *e
       L(nw[k]) = sl.w & ~0x100u; /* all_visited := false */
     }
   }
+  CO_PH_MEM(1);
 #pragma unroll
   for (int k = 0; k < CO_RB; ++k) {
     int D = WAVE_BCAST(dv, k);
@@ -437,6 +453,7 @@ CO_DEV void co_backup_batch(CoWave &w, CoTree &t, int k0, int nb, const float *e
     }
   }
   WAVE_SYNC();
+  CO_PH(3);
   w.gc.evals += (uint32_t)nb;
 }
 
@@ -444,12 +461,10 @@ CO_DEV void co_backup_batch(CoWave &w, CoTree &t, int k0, int nb, const float *e
  * (co_k_priors ran on this launch's rows) */
 CO_DEV void co_receive_eval(CoWave &w, CoTree &t, const float *eval) {
   int n = w.gc.n_pending;
-  unsigned long long t0 = CO_CLK();
   for (int k0 = 0; k0 < n; k0 += CO_RB) {
     int nb = n - k0 < CO_RB ? n - k0 : CO_RB;
     co_backup_batch(w, t, k0, nb, eval);
   }
-  CO_PROF_ADD(w, 0, CO_CLK() - t0);
   CO_PROF_ADD(w, 6, (unsigned long long)n);
   w.gc.n_pending = 0;
   w.noise_words = 0;
@@ -583,7 +598,7 @@ CO_DEV void co_search(CoWave &w, CoTree &t, CoRoot &rc) {
     }
   }
   WAVE_SYNC();
-  CO_PH_START();
+  CO_PH_MEM(19);
   while (!co_res_terminal(co_slot_result(cs))) {
     int n = (int)CO_META_NEDGES(h0.z);
     float denom = co_u2f(h1.y);
@@ -632,6 +647,7 @@ CO_DEV void co_search(CoWave &w, CoTree &t, CoRoot &rc) {
       }
     }
     CO_PH(8);
+    CO_PROF_ADD(w, 23, 1ull);
     /* ---- visit the current node (virtual loss on every node of the path) */
     cs = co_slot_set_visits(cs, visits + 1);
     cs.y = co_f2u(co_u2f(cs.y) + 1.0f);
@@ -669,10 +685,9 @@ CO_DEV void co_search(CoWave &w, CoTree &t, CoRoot &rc) {
       co_do_move(&board, &meta, move);
       int res;
       int depth = (int)CO_META_DEPTH(h0.z) + 1;
-      unsigned long long te = CO_CLK();
+      CO_PH(16);
+      CO_PROF_ADD(w, 24, 1ull);
       uint32_t nb = co_create_node(w, t, board, meta, depth, cur, child_slot, &res, &leaf_n, leaf_lm);
-      CO_PROF_ADD(w, 3, CO_CLK() - te);
-      CO_PH(10);
       if (nb == CO_NONE) return;
       if (w.analyse) {
         /* Node::countNodes (node.cpp:179-187) without a traversal: word z of unit b + 1 counts the
@@ -694,6 +709,7 @@ CO_DEV void co_search(CoWave &w, CoTree &t, CoRoot &rc) {
         }
       }
       WAVE_SYNC();
+      CO_PH(10);
       break;
     }
     /* kVisited: descend */
@@ -703,8 +719,7 @@ CO_DEV void co_search(CoWave &w, CoTree &t, CoRoot &rc) {
     h0 = co_load_unit(A, cur);
     h1 = co_load_unit(A, cur + 1);
     FOR_LANES { L(ev) = A[cur + 2 + lane]; }
-    CO_PH_DRAIN();
-    CO_PH(11);
+    CO_PH_MEM(11);
     ++D;
     FOR_LANES {
       if (lane == 0) {
@@ -740,7 +755,6 @@ CO_DEV void co_search(CoWave &w, CoTree &t, CoRoot &rc) {
     co_store_slot(A, cur_slot, cs, rc);
     uint64_t board = (uint64_t)h0.x | ((uint64_t)h0.y << 32);
     co_request(w, board, h0.z, cur, leaf_n, leaf_lm, D, path_slot);
-    CO_PH(13);
   }
 }
 
@@ -795,9 +809,8 @@ CO_DEV int co_mc_do_iteration(CoWave &w, CoTree &t, const float *eval, const flo
 
     if (co_res_known(co_slot_result(rc.cs)) || co_slot_all_visited(rc.cs)) break;
     if (w.gc.error) break;
-    unsigned long long t0 = CO_CLK();
+    CO_PH_MEM(20);
     co_search(w, t, rc);
-    CO_PROF_ADD(w, 1, CO_CLK() - t0);
     CO_PROF_ADD(w, 5, 1ull);
   }
   rs = co_load_unit(t.A, co_load_unit(t.A, t.tc.root + 1).x);
@@ -1238,7 +1251,7 @@ CO_DEV int co_game_step(CoWave &w, const float *eval, const float *probs) {
     skip_iteration = 0;
     ev = pr = (const float *)0;
     /* ---- chooseMoveAndContinue, one ply per pass of the loop */
-    unsigned long long t0 = CO_CLK();
+    CO_PH(20);
     int p = w.gc.to_play;
     int choice, terminal, tres, depth;
     uint64_t board;
@@ -1313,7 +1326,7 @@ CO_DEV int co_game_step(CoWave &w, const float *eval, const float *probs) {
       w.gc.pos_hi = (uint32_t)(board >> 32);
       w.gc.pos_meta = meta & 0x7FFFFu; /* reserves and side to move */
     }
-    CO_PROF_ADD(w, 2, CO_CLK() - t0);
+    CO_PH_MEM(2);
     if (terminal) {
       if (tres == CO_RESULT_DRAW) w.gc.result = CO_RESULT_DRAW;
       else if (p == 1) w.gc.result = CO_RESULT_LOSS;
@@ -1519,7 +1532,7 @@ CO_DEV void co_wave_init(const EngineParams &P, int g, const GameCtl &gc, const 
     const int rec = P.log_index ? P.log_index[gc.gid] : gc.gid < P.num_logged ? gc.gid : -1;
     if (rec >= 0) w.log = P.log + (size_t)rec * CO_LOG_CAP;
   }
-  w.prof = P.prof ? P.prof + (size_t)g * 16 : (unsigned long long *)0;
+  w.prof = P.prof ? P.prof + (size_t)g * CO_NPROF : (unsigned long long *)0;
   w.max_searches = P.max_searches;
   w.spe = P.searches_per_eval;
   w.testing = P.testing;
@@ -1636,12 +1649,14 @@ CO_DEV void co_mcts_step_wave(const EngineParams &P, int g) {
     return;
   }
   CoWave w;
+#if defined(CO_PROF) && !defined(CO_EMU)
+  const unsigned long long t_wave0 = CO_CLK(), t_real0 = __builtin_amdgcn_s_memrealtime();
+  for (int i = 0; i < CO_NPROF; ++i) w.pacc[i] = 0ull;
+  w.tph = t_wave0;
+#endif
   co_wave_init(P, g, gc, tc0, tc1, w);
   CO_PROF_ADD(w, 4, 1ull);
-  unsigned long long t_wave0 = CO_CLK();
-#if defined(CO_PROF) && !defined(CO_EMU)
-  unsigned long long t_real0 = __builtin_amdgcn_s_memrealtime();
-#endif
+  CO_PH_MEM(22);
   int off = co_step_row(P, g, gc);
   const float *step_eval = P.nn_eval + off, *step_probs = P.nn_probs + (size_t)off * CO_NUM_MOVES;
   int done;
@@ -1651,20 +1666,23 @@ CO_DEV void co_mcts_step_wave(const EngineParams &P, int g) {
     if (!co_slot_next_game(P, w)) break;
     step_eval = step_probs = (const float *)0; /* the first step of a game creates the root and asks for its evaluation */
   }
+  CO_PH(20);
   co_step_tail(P, w, g, done);
-  CO_PROF_ADD(w, 7, CO_CLK() - t_wave0);
+  CO_PH_MEM(21);
 #if defined(CO_PROF) && !defined(CO_EMU)
-  if (w.prof && g == 1 && (threadIdx.x & 63) == 0) {
-    unsigned long long dr = __builtin_amdgcn_s_memrealtime() - t_real0;
-    P.prof[(size_t)P.num_games * 16 + 0] += CO_CLK() - t_wave0;
-    P.prof[(size_t)P.num_games * 16 + 1] += dr;
-  }
+  w.pacc[7] = CO_CLK() - t_wave0;
   if (w.prof && (threadIdx.x & 63) == 0) {
-    unsigned long long dt = CO_CLK() - t_wave0;
-    atomicMax(P.prof + (size_t)P.num_games * 16 + 2, dt);
+    for (int i = 0; i < CO_NPROF; ++i) w.prof[i] += w.pacc[i];
+    const unsigned long long dt = w.pacc[7];
+    unsigned long long *glob = P.prof + (size_t)P.num_games * CO_NPROF;
+    if (g == 1) {
+      glob[0] += dt;
+      glob[1] += __builtin_amdgcn_s_memrealtime() - t_real0;
+    }
+    atomicMax(glob + 2, dt);
     int bucket = (int)(dt / 50000ull);
     if (bucket > 15) bucket = 15;
-    atomicAdd(P.prof + (size_t)P.num_games * 16 + 4 + bucket, 1ull);
+    atomicAdd(glob + 4 + bucket, 1ull);
   }
 #endif
   co_wave_store(P, w, g);
@@ -1684,9 +1702,11 @@ CO_DEV void co_search_step_wave(const EngineParams &P, int g) {
     return;
   }
   CoWave w;
+#if defined(CO_PROF) && !defined(CO_EMU)
+  for (int i = 0; i < CO_NPROF; ++i) w.pacc[i] = 0ull; /* (stamps are read from the single-kernel path: tools/prof_phases.py) */
+  w.tph = 0ull;
+#endif
   co_wave_init(P, g, gc, tc0, tc1, w);
-  CO_PROF_ADD(w, 4, 1ull);
-  unsigned long long t_wave0 = CO_CLK();
   const int off = co_step_row(P, g, gc);
   const float *ev = P.nn_eval + off, *pr = P.nn_probs + (size_t)off * CO_NUM_MOVES;
   if (w.gc.resume) { /* continuation of a deferred hand-over (co_game_step): nothing to receive */
@@ -1705,7 +1725,6 @@ CO_DEV void co_search_step_wave(const EngineParams &P, int g) {
   } else {
     co_step_tail(P, w, g, 0);
   }
-  CO_PROF_ADD(w, 7, CO_CLK() - t_wave0);
   /* what this kernel may have changed (the rest of the control block is co_k_turn's) */
   GameCtl *dst = P.games + g;
   TreeCtl *tdst = P.trees + 2 * g + w.gc.to_play;
@@ -1731,6 +1750,10 @@ CO_DEV void co_turn_step_wave(const EngineParams &P, int g) {
   GameCtl gc = P.games[g];
   const TreeCtl tc0 = P.trees[2 * g], tc1 = P.trees[2 * g + 1];
   CoWave w;
+#if defined(CO_PROF) && !defined(CO_EMU)
+  for (int i = 0; i < CO_NPROF; ++i) w.pacc[i] = 0ull;
+  w.tph = 0ull;
+#endif
   co_wave_init(P, g, gc, tc0, tc1, w);
   w.defer_handover = 1;
   int done;

@@ -227,7 +227,7 @@ int ca_trainer_game_info(ca_trainer *t, int game, int32_t out[8]);
 int ca_trainer_trace(ca_trainer *t, int game, int32_t *out, int32_t cap, int32_t *n);
 /* diagnostic builds of the library (-DCO_PROF) only: summed in-kernel cycle stamps of the search kernel
  * (slots documented in csrc/mcts.h); the shipped build returns CA_ERR_STATE */
-int ca_trainer_prof(ca_trainer *t, unsigned long long out[36]);
+int ca_trainer_prof(ca_trainer *t, unsigned long long out[52]);
 
 /* ---- Tourney: replaces `class Tourney` of corintho_ai/cpp/include/tourney.h:13-46
  * consumed by corintho_ai/rating/tourney.pyx:15-31.  One match = one slot of a device pool

@@ -17,24 +17,30 @@ subprocess.check_call(cmd)
 L = _lib.declare(C.CDLL(out))
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 400
-t = Trainer(G, "", 12345, S, 16, 1.0, 0.25, 0, 1, False, stagger=False, _cdll=L)
+os.environ["CORINTHO_SPLIT_STEP"] = "0"  # the stamps are read from the single-kernel path
+pools = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+t = Trainer(G, "", 12345, S, 16, 1.0, 0.25, 0, 1, False, stagger=False, pools=pools, _cdll=L)
 t.set_net(9, nets.init_mlp12x100(0))
 t.run()
 st = t.stats()
-p = (C.c_ulonglong * 36)()
+NP = 32
+p = (C.c_ulonglong * (NP + 20))()
 L.ca_trainer_prof.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
 _lib.check(L, L.ca_trainer_prof(t._t, p))
-rec, srch, choose, expand, steps, nsearch, nrecv = [int(x) for x in p[:7]]
-print("stats", {k: st[k] for k in ("searches", "evals", "iterations", "mcts_ms", "nn_ms", "pack_ms")})
-print("per receive: %.0f cycles   (%d receives)" % (rec / max(nrecv, 1), nrecv))
-print("per search : %.0f cycles   (%d searches), of which expand %.0f" % (srch / max(nsearch, 1), nsearch, expand / max(nsearch, 1)))
-print("choose/hand-over per step: %.0f cycles over %d wave-steps" % (choose / max(steps, 1), steps))
-wave_total = int(p[7])
-print("whole wave-step: %.0f cycles avg; clock of game 1's steps: %.0f MHz" % (wave_total / max(steps, 1), 100.0 * int(p[16]) / max(int(p[17]), 1)))
-print("launch avg %.1f us -> %.0f cycles at that clock" % (1e3 * st["mcts_ms"] / st["iterations"], 1e3 * st["mcts_ms"] / st["iterations"] * int(p[16]) / max(int(p[17]), 1) * 100))
-print("max wave-step %d cycles; histogram of wave-step cycles (50k buckets): %s" % (int(p[18]), [int(x) for x in p[20:36]]))
-print('phases of a simulation (cycles per search): PUCT scans %.0f, slot stores %.0f, expansion %.0f, descent block fetch (waited for) %.0f, '
-      'terminal leaves %.0f, request %.0f' % tuple(int(p[i]) / max(nsearch, 1) for i in range(8, 14)))
-tot = rec + srch + choose
-print("share: receive %.1f%%  search %.1f%%  choose %.1f%%;  stamped cycles per wave-step %.0f" %
-      (100 * rec / tot, 100 * srch / tot, 100 * choose / tot, tot / max(steps, 1)))
+v = [int(x) for x in p]
+steps, nsearch, nrecv, levels, nexp = max(v[4], 1), max(v[5], 1), max(v[6], 1), max(v[23], 1), max(v[24], 1)
+clk_mhz = 100.0 * v[NP + 0] / max(v[NP + 1], 1)
+print("stats", {k: st[k] for k in ("searches", "evals", "iterations", "mcts_ms", "nn_ms", "pack_ms", "pools")})
+print("%d wave-steps, %.1f simulations, %.1f evaluations received, %.2f levels scanned per simulation, %.3f expansions per simulation"
+      % (steps, nsearch / steps, nrecv / steps, levels / nsearch, nexp / nsearch))
+print("whole wave-step: %.0f cycles avg (max %d); clock of game 1's steps: %.0f MHz; launch avg %.1f us = %.0f cycles"
+      % (v[7] / steps, v[NP + 2], clk_mhz, 1e3 * st["mcts_ms"] / st["iterations"], 1e3 * st["mcts_ms"] / st["iterations"] * clk_mhz))
+print("histogram of wave-step cycles (50k buckets):", v[NP + 4:NP + 20])
+names = {22: "wave set-up", 0: "backup: indices", 1: "backup: slot fetch", 3: "backup: sums + stores", 20: "loop control + root load",
+         19: "simulation start (root copy, path)", 8: "PUCT scan", 9: "virtual-loss store + path", 11: "descent: block fetch (waited for)",
+         16: "expansion: doMove", 14: "expansion: legal moves", 15: "expansion: node stores", 10: "expansion: slot + path update",
+         12: "terminal leaf", 17: "request: state row", 18: "request: pending-leaf records", 2: "move choice / hand-over", 21: "step tail"}
+tot = sum(v[i] for i in names)
+print("stamped %.0f cycles per wave-step (%.1f %% of the whole step); per SIMULATION:" % (tot / steps, 100.0 * tot / max(v[7], 1)))
+for i, nm in names.items():
+    print("  %-40s %8.0f cycles  %5.1f %%" % (nm, v[i] / nsearch, 100.0 * v[i] / tot))
