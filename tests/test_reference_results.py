@@ -302,9 +302,12 @@ def test_engine_reproduces_the_real_search_rows():
     z_draw = (d_here - d_ref) / np.sqrt(d_ref * (1 - d_ref) * (1 / tot_here.sum() + 1 / tot_ref.sum()))
     print("win rates: max |z| %.2f, sum z^2 = %.1f over %d rows (p = %.3f); draws %.4f here, %.4f in the reference (z %+.2f)"
           % (np.max(np.abs(zs)), joint, len(zs), p_joint, d_here, d_ref, z_draw))
-    assert np.all(np.abs(zs) < 3.0)
-    assert p_joint > 0.01
-    assert abs(z_draw) < 3.0
+    # The bounds are those of the POPULATION of rows (below: the reference's rows scatter about 4 x wider than independent
+    # binomial samples -- its tournament replays seeds -- with no bias); these 14 happen to sit at sum z^2 = 14.7 at 2000
+    # matches and 24.6 at 8000 (round 3), with `1 0` at -3.8 sigma there.  Not asserted at the level of independent samples.
+    assert np.all(np.abs(zs) < 6.0)
+    assert joint < 7.0 * len(zs) and abs(float(np.mean(zs))) < 3.5 * 2.1 / np.sqrt(len(zs))
+    assert abs(z_draw) < 3.5 * 1.9
 
 
 @pytest.mark.gpu
@@ -329,3 +332,129 @@ def test_the_committed_offset_table_does_not_reproduce_them():
         print("%d %d through the committed table: %s against %s, z %+.1f" % (a, b, got, REF_SEARCH_ROWS[(a, b)], z))
         assert abs(z) > 8.0
         t.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The rows as a POPULATION (round 4).  25 of the reference's checkpoints are committed as data (the five above, the
+# next-strongest two, 18 drawn with a fixed seed before any row was replayed: tools/gen_trained_golden.py
+# population_players) with the 600 rows of results.txt between them (tests/golden/ref_results_pop.json).  All 600 were
+# replayed at 2000 matches (tools/ref_population.py; profiles/r04_reference_rows_population.{md,json}).  What they show:
+#   * no bias: mean z = -0.06 over 600 rows; no checkpoint plays stronger or weaker here than there (largest mean signed
+#     z of a checkpoint over its 48 rows: 2.1 standard errors);
+#   * but the rows scatter 4.3 times wider than two independent binomial samples would (sum z^2 = 2591 over 600 rows;
+#     robustly, median z^2 = 1.65 where 0.455 is expected: 3.6 x), the reference's DRAW counts by the same factor (3.5 x);
+#   * the scatter belongs to the ROW, not to the pairing: z(a, b) and -z(b, a) are uncorrelated (+0.015 over 300
+#     pairings; a strength difference of a pairing would move both rows) -- so round 3's "player 1 moving first" rows were
+#     three draws from this distribution, not a property of that player (its 24 first-mover rows: mean z -0.09);
+#   * and the reference's own rows contradict each other where they deviate most: against model_1 (the second-weakest
+#     checkpoint) every first mover wins 87-95 % here and 85-98 % there -- except the two rows with the MOST reference
+#     games of that column, `51 92` (74.6 % of 799) and `10 92` (79.1 % of 642; z = +14.5 and +11.3).  More games make an
+#     independent sample more accurate; here they mark the rows rating/round.py kept scheduling because their variance
+#     estimate stayed high (:131-192), and it puts the pairs it pops first at the head of every worker's match file
+#     (:196-214), where matches get the first outputs of a default-constructed mt19937 (tourney.cpp:86): the same seeds
+#     for the same pairing round after round.  The one-search pairing above shows what that does when no float enters a
+#     game (exact replicas, reproduced by the oracle at those positions); with a network in the loop the replicas are
+#     partial and show as over-dispersion.
+# The rows therefore pin the search layer as a population: location exactly (no bias, no checkpoint- or pairing-level
+# effect), dispersion at the level the reference's own sampling explains -- and wrong search parameters move the
+# LOCATION by 10 sigma and more (profiles/r03_reference_rows_sweep.md).  The test below replays all 156 rows between 13
+# of the 25 players (fixed in advance: round 3's five, players 2 and 3, the first six of the seeded draw) at 1000 matches
+# and asserts those properties; the rows beyond 6 sigma in the 2000-match run are named, not tuned away.
+POP_PLAYERS = [0, 1, 2, 3, 46, 89, 90, 4, 7, 10, 22, 25, 33]
+POP_KNOWN_OUTLIERS = {(89, 4): -8.3, (3, 25): +6.8}  # |z| > 6 at 2000 matches (of the seven such rows among all 600, those between POP_PLAYERS)
+
+
+def _population_weights():
+    W = _checkpoints()
+    d = np.load(os.path.join(GOLDEN, "ref_models_pop.npz"))
+    for k in d.files:
+        W[int(k.split("_")[1])] = d[k]
+    return W
+
+
+def _population_rows():
+    import json
+
+    d = json.load(open(os.path.join(GOLDEN, "ref_results_pop.json")))
+    return {(r[0], r[1]): tuple(r[2:]) for r in d["rows"] if r[0] in POP_PLAYERS and r[1] in POP_PLAYERS}
+
+
+def test_the_population_rows_are_the_reference_rows():
+    path = os.path.join(REFERENCE, "corintho_ai/rating/results.txt")
+    if not os.path.exists(path):
+        pytest.skip("reference tree not mounted")
+    import json
+
+    rows = {tuple(map(int, l.split()[:2])): tuple(map(int, l.split()[2:])) for l in open(path) if l.strip()}
+    d = json.load(open(os.path.join(GOLDEN, "ref_results_pop.json")))
+    assert len(d["rows"]) == 600 and len(d["players"]) == 25
+    for a, b, w, dr, l in d["rows"]:
+        assert rows[(a, b)] == (w, dr, l)
+    players = open(os.path.join(REFERENCE, "corintho_ai/rating/tourney/players.txt")).read().split("\n")
+    for p in d["players"]:
+        assert players[1 + p] == "%d 1600 16 3.0 0.25 0" % (93 - p)
+    assert len(_population_rows()) == 156
+
+
+@pytest.mark.gpu
+def test_engine_reproduces_the_reference_rows_as_a_population():
+    from corintho_ai_amd import NET_MLP12X100_X6
+
+    W = _population_weights()
+    ref = _population_rows()
+    n = 1000
+    zs, zh, table = {}, [], []
+    tot_here, tot_ref = np.zeros(3), np.zeros(3)
+    for (a, b), r in sorted(ref.items()):
+        t = Tourney(1, "")
+        for p in (a, b):
+            t.addPlayer(p, 93 - p, 1600, 16, 3.0, 0.25, False)
+        for _ in range(n):
+            t.addMatch(a, b, False)
+        t.set_exact_offsets(True)
+        for p in (a, b):
+            t.set_net(93 - p, NET_MLP12X100_X6, W[93 - p])
+        assert t.run()
+        sc = [t.match_score(i) for i in range(n)]
+        t.close()
+        got = _wdl(sc)
+        zs[(a, b)] = _z_win(got, r)
+        zh.append(_z_win(_wdl(sc[: n // 2]), _wdl(sc[n // 2:])))  # this side against itself: two halves of fresh seeds
+        tot_here += got
+        tot_ref += r
+        table.append("%2d %2d  here %4d/%3d/%4d = %.3f  reference %4d/%2d/%4d = %.3f  z %+.2f" % ((a, b) + got + (got[0] / n,) + r + (r[0] / sum(r), zs[(a, b)])))
+    print("\n".join(table))
+    z = np.array([zs[k] for k in sorted(zs)])
+    zh = np.array(zh)
+    k = len(z)
+    phi_mean, phi_med = float(np.mean(z ** 2)), float(np.median(z ** 2) / 0.455)
+    pairs = np.array([(zs[(a, b)], -zs[(b, a)]) for (a, b) in zs if a < b])
+    rho = float(np.corrcoef(pairs[:, 0], pairs[:, 1])[0, 1])
+    by_first = {p: float(np.mean([zs[(a, b)] for (a, b) in zs if a == p])) for p in (0, 1, 2, 3)}
+    shift = {p: float(np.mean([zs[(a, b)] for (a, b) in zs if a == p] + [-zs[(a, b)] for (a, b) in zs if b == p])) for p in POP_PLAYERS}
+    d_here, d_ref = tot_here[1] / tot_here.sum(), tot_ref[1] / tot_ref.sum()
+    print("%d rows x %d matches: mean z %+.3f, median z %+.3f; dispersion mean z^2 %.2f, robust %.2f; this side against itself %.2f; "
+          "rows of a pairing: correlation %+.3f over %d pairings; first movers 0-3: %s; draws %.4f here, %.4f in the reference"
+          % (k, n, z.mean(), np.median(z), phi_mean, phi_med, float(np.mean(zh ** 2)), rho, len(pairs),
+             {p: round(v, 2) for p, v in by_first.items()}, d_here, d_ref))
+    # (1) this side's games are independent samples: two halves of a row agree like binomial samples
+    assert 0.7 < float(np.mean(zh ** 2)) < 1.4
+    # (2) location: no bias over the population, for no checkpoint, and not for "a strong checkpoint moving first"
+    se = np.sqrt(phi_mean)
+    assert abs(z.mean()) < 3.5 * se / np.sqrt(k) and abs(np.median(z)) < 0.6
+    for p, v in shift.items():
+        assert abs(v) < 3.5 * se / np.sqrt(2 * (len(POP_PLAYERS) - 1)), (p, v)
+    for p, v in by_first.items():
+        assert abs(v) < 3.5 * se / np.sqrt(len(POP_PLAYERS) - 1), (p, v)
+    # (3) the excess scatter is the rows' (the reference's sampling), not the pairings' (a difference in playing strength)
+    assert abs(rho) < 3.0 / np.sqrt(len(pairs))
+    # (4) and it is the size the 600-row replay found (3.6 robust / 4.3 mean at 2000 matches; a little less at 1000): a
+    #     search that differed from the reference's would add to it (c_puct 2 or 4 instead of 3: 12 and more per row)
+    assert 1.5 < phi_med < 5.5 and phi_mean < 7.0
+    # (5) the rows beyond 6 sigma are the named ones, on the side they were found
+    for key, zz in zs.items():
+        if abs(zz) > 6.0:
+            assert key in POP_KNOWN_OUTLIERS and zz * POP_KNOWN_OUTLIERS[key] > 0, (key, zz)
+    # (6) draws: the pooled rate agrees
+    z_draw = (d_here - d_ref) / np.sqrt(d_ref * (1 - d_ref) * (1 / tot_here.sum() + 1 / tot_ref.sum()) * 3.5)
+    assert abs(z_draw) < 3.5

@@ -116,6 +116,33 @@ def report(paths):
     here = np.sum([r["here"] for r in rows], axis=0)
     ref = np.sum([r["ref"] for r in rows], axis=0)
     print("| pooled draws | %.4f here, %.4f in the reference | |" % (here[1] / here.sum(), ref[1] / ref.sum()))
+    # ---- what kind of disagreement is it?  (a) A real strength difference of a pairing on this side would show in BOTH
+    # of its rows with opposite signs (if a is too strong here it wins more moving first, and b wins less moving first against
+    # it): z(a, b) and -z(b, a) would correlate.  Sampling noise of the reference's rows -- they are not independent games:
+    # tests/test_reference_results.py, the seeding of rating/round.py's match files -- leaves them uncorrelated.
+    zmap = {(r["a"], r["b"]): r["z"] for r in rows}
+    pairs = [(zmap[(a, b)], -zmap[(b, a)]) for (a, b) in zmap if a < b and (b, a) in zmap]
+    if len(pairs) > 10:
+        pa = np.array(pairs)
+        rho = float(np.corrcoef(pa[:, 0], pa[:, 1])[0, 1])
+        print("| correlation of z(a, b) with -z(b, a) over %d pairings | %+.3f | 0 +- %.3f if the excess is sampling noise; "
+              "near +1 if pairings differed in strength |" % (len(pairs), rho, 1 / np.sqrt(len(pairs))))
+    # (b) a checkpoint that plays differently here (import, evaluation) would shift all its rows one way
+    phi = s2 / k
+    worst = 0.0
+    for pl in sorted({r["a"] for r in rows}):
+        zz = np.array([r["z"] for r in rows if r["a"] == pl] + [-r["z"] for r in rows if r["b"] == pl])
+        worst = max(worst, abs(zz.mean()) / np.sqrt(phi / len(zz)))
+    print("| largest |mean signed z| of one checkpoint over all its rows, in units of its standard error at the observed "
+          "dispersion | %.2f | < 3.3 for 25 checkpoints |" % worst)
+    # (c) is the excess the same for draws?  expected draws of a reference row from this side's draw rate of the row
+    qs = np.array([(r["here"][1] + 0.5) / (sum(r["here"]) + 1.0) for r in rows])
+    nr = np.array([sum(r["ref"]) for r in rows], float)
+    dr = np.array([r["ref"][1] for r in rows], float)
+    var = nr * qs * (1 - qs) * (1 + nr / n)
+    print("| dispersion of the reference's DRAW counts about this side's draw rates (Pearson chi^2 / rows) | %.2f | 1 |"
+          % float(np.mean((dr - nr * qs) ** 2 / var)))
+    print("| dispersion of the win counts (sum z^2 / rows) | %.2f | 1 |" % phi)
     print("\n## By first mover\n\n| first mover (player: checkpoint) | rows | sum z^2 | mean z | max abs z |\n|---|---|---|---|---|")
     for a in sorted({r["a"] for r in rows}):
         za = np.array([r["z"] for r in rows if r["a"] == a])
