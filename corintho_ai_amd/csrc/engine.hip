@@ -983,7 +983,7 @@ struct ca_trainer {
   bool run_pools(int64_t max_iterations, int npools) {
     const int poll = CO_POOL_POLL;
 #ifndef CO_SPLIT_STEP_DEFAULT
-#define CO_SPLIT_STEP_DEFAULT 1
+#define CO_SPLIT_STEP_DEFAULT 0
 #endif
     const char *env_split = getenv("CORINTHO_SPLIT_STEP"); /* diagnostic: 0 = the whole step in one kernel always, 1 = in two while the pool is full */
     const bool split_step = env_split ? env_split[0] != '0' : CO_SPLIT_STEP_DEFAULT != 0;

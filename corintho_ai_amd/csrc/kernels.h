@@ -268,7 +268,9 @@ CO_KERNEL co_k_domove_batch(uint64_t *boards, uint32_t *metas, const int32_t *mo
   if (i >= n) return;
   uint64_t b = boards[i];
   uint32_t m = metas[i];
-  if (moves[i] >= 0) co_do_move(&b, &m, moves[i]);
+  CoLanes K;
+  co_lanes_init(K);
+  if (moves[i] >= 0) co_do_move(&b, &m, moves[i], K);
   WAVE_SYNC();
   FOR_LANES {
     if (lane == 0) {

@@ -540,13 +540,18 @@ CO_DEV double co_div_small(double x, float df) {
  * rewrite several path slots in memory (terminal leaf, dead end) drop the copy (valid = 0). */
 struct CoRoot {
   uint4 h0, h1, cs;
+  float vs;       /* c_puct sqrt(visits) of the root as it stands (co_vsqrt): computed one simulation ahead, in the
+                   * shadow of that simulation's block fetch */
   int valid;
   uint4 *ev;      /* LDS: edge slots 0..63 of the root */
   uint32_t e0;    /* unit offset of the root's edge slot 0 */
   uint32_t ne;    /* edge slots held: min(edges, 64) */
 };
 
-CO_DEV void co_root_load(CoTree &t, CoRoot &rc) {
+/* the exploration factor of a PUCT scan (trainmc.cpp:549): float(double(c_puct) * sqrt(double(float(visits)))) */
+CO_DEV float co_vsqrt(float c_puct, int visits) { return (float)((double)c_puct * co_sqrt_f64((double)(float)visits)); }
+
+CO_DEV void co_root_load(CoTree &t, CoRoot &rc, float c_puct) {
   rc.h0 = co_load_unit(t.A, t.tc.root);
   rc.h1 = co_load_unit(t.A, t.tc.root + 1);
   rc.cs = co_load_unit(t.A, rc.h1.x);
@@ -556,6 +561,7 @@ CO_DEV void co_root_load(CoTree &t, CoRoot &rc) {
   const uint4 *A = t.A;
   FOR_LANES { rc.ev[lane] = A[rc.e0 + lane]; } /* arena is padded: lanes >= n read unused units */
   WAVE_SYNC();
+  rc.vs = co_vsqrt(c_puct, co_slot_visits(rc.cs));
   rc.valid = 1;
 }
 
@@ -589,6 +595,7 @@ CO_DEV void co_search(CoWave &w, CoTree &t, CoRoot &rc) {
   LV(uint4, ev);
   FOR_LANES { L(ev) = rc.ev[lane]; }
   int D = 0;
+  float vs = rc.vs; /* exploration factor of the node about to be scanned */
   int leaf_n = 0; /* legal moves of the node this simulation creates */
   uint32_t leaf_lm[3] = {0u, 0u, 0u};
   FOR_LANES {
@@ -603,7 +610,7 @@ CO_DEV void co_search(CoWave &w, CoTree &t, CoRoot &rc) {
     int n = (int)CO_META_NEDGES(h0.z);
     float denom = co_u2f(h1.y);
     int visits = co_slot_visits(cs);
-    float v_sqrt = (float)((double)w.c_puct * co_sqrt_f64((double)(float)visits));
+    const float v_sqrt = vs;
     /* ---- chooseNext: u for every edge, strict first maximum */
     float best_u = CO_NEG_INF;
     int best_e = -1;
@@ -679,10 +686,11 @@ CO_DEV void co_search(CoWave &w, CoTree &t, CoRoot &rc) {
     CO_PH(9);
     if (best_slot.x == CO_NONE) {
       /* kNew: expand (Node ctor from parent, node.cpp:31-39) */
+      if (D == 0) rc.vs = co_vsqrt(w.c_puct, visits + 1);
       uint64_t board = (uint64_t)h0.x | ((uint64_t)h0.y << 32);
       uint32_t meta = h0.z;
       int move = (int)(best_slot.z & 127u);
-      co_do_move(&board, &meta, move);
+      co_do_move(&board, &meta, move, w.K);
       int res;
       int depth = (int)CO_META_DEPTH(h0.z) + 1;
       CO_PH(16);
@@ -719,6 +727,11 @@ CO_DEV void co_search(CoWave &w, CoTree &t, CoRoot &rc) {
     h0 = co_load_unit(A, cur);
     h1 = co_load_unit(A, cur + 1);
     FOR_LANES { L(ev) = A[cur + 2 + lane]; }
+    /* while the block is on its way: the child's exploration factor (its visits are in the slot just scanned) and, leaving
+     * the root, the root's for the NEXT simulation (its visits have just been counted up) -- two independent chains of a
+     * double-precision square root that would otherwise stand between the fetch and the scan */
+    vs = co_vsqrt(w.c_puct, co_slot_visits(cs));
+    if (D == 0) rc.vs = co_vsqrt(w.c_puct, visits + 1);
     CO_PH_MEM(11);
     ++D;
     FOR_LANES {
@@ -805,7 +818,7 @@ CO_DEV int co_mc_do_iteration(CoWave &w, CoTree &t, const float *eval, const flo
   rc.ne = 0u;
   for (;;) {
     if (!(w.gc.n_pending < w.spe && t.tc.searches_done < w.max_searches)) break;
-    if (!rc.valid) co_root_load(t, rc);
+    if (!rc.valid) co_root_load(t, rc, w.c_puct);
 
     if (co_res_known(co_slot_result(rc.cs)) || co_slot_all_visited(rc.cs)) break;
     if (w.gc.error) break;
@@ -835,7 +848,7 @@ CO_DEV void co_reset_tree_to_child(CoWave &w, CoTree &t, int choice) {
   uint64_t board = (uint64_t)h0.x | ((uint64_t)h0.y << 32);
   uint32_t meta = h0.z;
   int depth = (int)CO_META_DEPTH(meta) + 1;
-  co_do_move(&board, &meta, choice);
+  co_do_move(&board, &meta, choice, w.K);
   int res;
   uint32_t b = co_create_node(w, t, board, meta, depth, CO_NONE, CO_NONE, &res);
   if (b == CO_NONE) return;
@@ -1266,7 +1279,7 @@ CO_DEV int co_game_step(CoWave &w, const float *eval, const float *probs) {
       co_trace_push(w, -2);
       co_trace_push(w, choice);
       w.gc.plies++;
-      co_do_move(&board, &meta, choice);
+      co_do_move(&board, &meta, choice, w.K);
       int lines = co_legal_moves(board, meta, lm, w.K);
       terminal = (lm[0] | lm[1] | lm[2]) == 0u;
       tres = lines ? CO_RESULT_LOSS : CO_RESULT_DRAW;

@@ -27,6 +27,7 @@
 // feeds 16 MFMAs), 16 positions per workgroup.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -873,6 +874,272 @@ __global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_h3_small(Rc3Params
 #define RCH_LDS_WORDS(NP) RCS_LDS_WORDS(2, NP)
 #define RCH_THREADS 512
 
+/* ======================================================================
+ * K6p: the f16x3 throughput kernel in PIXEL-MAJOR form (round 4).
+ *
+ * rcs_forward makes an MFMA column a (position, pixel) pair: a tap is a DPP shift of the activation registers, and the
+ * 44 of 144 (pixel, tap) pairs that fall outside the 4x4 board multiply zeros -- 31 % of the matrix work of every 3x3
+ * convolution.  Here a column is a POSITION (32 per workgroup) and every output pixel has its own accumulators,
+ *     D_p[co, pos] += W_tap[co, ci] . X_q[ci, pos]        for the taps whose source pixel q = p + tap lies on the board,
+ * so only the 100 real pairs are multiplied: 300 MFMAs per wave and convolution on average instead of 432.  The price:
+ * the neighbour pixel's activations are another wave's registers, so activations travel through LDS -- 16 pixels x 4 K
+ * steps x 2 fp16 terms x 1 KiB = 128 KB per workgroup, written by the epilogue of every convolution and read back as B
+ * fragments -- and weights stream one tap (16 KB) at a time through the remaining 32 KB (a barrier per tap).
+ * Waves 0-3 own an interior pixel (9 taps) and a corner (4), waves 4-7 two edge pixels of one side (6 + 6).
+ *
+ * Results are BIT-IDENTICAL to rcs_forward<.., 2, .., true>: the same weight fragments (same k-slot order), the same
+ * products in the same order per accumulator (tap ascending, K step ascending, w0 x0, w0 x1, w1 x0), the same epilogue
+ * expressions; the taps rcs_forward multiplies with zero padding add exact zeros there and are skipped here.  So a row
+ * is evaluated to the same bits whichever kernel its batch size selects (SURVEY 8e invariant;
+ * tests/test_net_precision.py::test_bf16x6_rows_do_not_depend_on_their_batch compares them). */
+#define RCP_X_WORDS (16 * 4 * 2 * 256)   /* pixel x K step x term fragments: 128 KB */
+#define RCP_TAP_WORDS RCS_CONV_CHUNK(2)   /* 16 KB */
+#define RCP_LDS_WORDS (RCP_X_WORDS + 2 * RCP_TAP_WORDS)
+#define RCP_NUM_TAPS 82                   /* 9 stem taps, 72 trunk taps, the 1x1 head fragments */
+
+/* stream item g into weight buffer g & 1: a stem tap (4 KB), a trunk tap (16 KB) or the head fragments (8 KB) */
+__device__ __forceinline__ void rcp_stage(const Rc3Params &Q, uint32_t lds_w_addr, int g, int wave, int lane) {
+  const uint32_t dst = lds_w_addr + (uint32_t)(g & 1) * (RCP_TAP_WORDS * 4u);
+  if (g < 9) rcs_stage_words(Q.wtrunk + g * RCS_STEM_CHUNK(2), dst, RCS_STEM_CHUNK(2), wave, lane);
+  else if (g < 81) rcs_stage_words(Q.wtrunk + 9 * RCS_STEM_CHUNK(2) + (g - 9) * RCS_CONV_CHUNK(2), dst, RCS_CONV_CHUNK(2), wave, lane);
+  else rcs_stage_words(Q.whead3, dst, RCS_FRAG1_WORDS(2), wave, lane);
+}
+
+/* one 3x3 convolution of this wave's two output pixels.  CS = K steps (1: stem, whose inputs are exact in fp16 -- only
+ * their first term exists; 4: trunk) */
+template <int CS>
+__device__ __forceinline__ void rcp_conv3x3(f32x16 (&acc)[2][2], int &g, const Rc3Params &Q, const uint32_t *X, const uint32_t *Wb,
+                                            uint32_t lds_w_addr, int P0, int P1, int valid0, int valid1, int wave, int lane) {
+  constexpr int XT = CS == 1 ? 1 : 2;
+#pragma unroll
+  for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+    for (int to = 0; to < 2; ++to)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[pi][to][i] = 0.0f;
+  for (int tap = 0; tap < 9; ++tap, ++g) {
+    CO_WAIT_VMCNT(0); /* this wave's pieces of item g have landed (requested one item ago) */
+    co_wg_barrier();  /* ... every wave's; everyone has left the other buffer and, at tap 0, has written its activations */
+    rcp_stage(Q, lds_w_addr, g + 1, wave, lane);
+    const bool v0 = (valid0 >> tap) & 1, v1 = (valid1 >> tap) & 1;
+    if (!v0 && !v1) continue;
+    const uint32_t *wb = Wb + (g & 1) * RCP_TAP_WORDS + lane * 4;
+    const int dq = (tap / 3 - 1) * 4 + (tap % 3 - 1);
+    const uint32_t *x0 = X + ((P0 + dq) * 4 * 2) * 256 + lane * 4, *x1 = X + ((P1 + dq) * 4 * 2) * 256 + lane * 4;
+#pragma unroll
+    for (int s = 0; s < CS; ++s) {
+      u32x4 a[2][2];
+#pragma unroll
+      for (int to = 0; to < 2; ++to)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) a[t][to] = *reinterpret_cast<const u32x4 *>(wb + ((s * 2 + to) * 2 + t) * 256);
+      if (v0) {
+        u32x4 b[XT];
+#pragma unroll
+        for (int t = 0; t < XT; ++t) b[t] = *reinterpret_cast<const u32x4 *>(x0 + (s * 2 + t) * 256);
+#pragma unroll
+        for (int sum = 0; sum < 2; ++sum)
+#pragma unroll
+          for (int i = 0; i <= sum; ++i)
+            if (sum - i < XT) {
+#pragma unroll
+              for (int to = 0; to < 2; ++to) acc[0][to] = rcs_mfma<true>(a[i][to], b[sum - i], acc[0][to]);
+            }
+      }
+      if (v1) {
+        u32x4 b[XT];
+#pragma unroll
+        for (int t = 0; t < XT; ++t) b[t] = *reinterpret_cast<const u32x4 *>(x1 + (s * 2 + t) * 256);
+#pragma unroll
+        for (int sum = 0; sum < 2; ++sum)
+#pragma unroll
+          for (int i = 0; i <= sum; ++i)
+            if (sum - i < XT) {
+#pragma unroll
+              for (int to = 0; to < 2; ++to) acc[1][to] = rcs_mfma<true>(a[i][to], b[sum - i], acc[1][to]);
+            }
+      }
+    }
+  }
+}
+
+/* conv bias -> BatchNorm affine (-> + skip) -> ReLU (rc3_epilogue's expressions), then the two fp16 terms of the result
+ * go to LDS as the B fragments of the next convolution.  KEEP: the fp32 result replaces `x` (the skip of the block). */
+template <bool ADD_SKIP, bool KEEP>
+__device__ __forceinline__ void rcp_epilogue(float (&x)[2][2][16], const f32x16 (&acc)[2][2], const float *epi, uint32_t *X, int P0, int P1,
+                                             int h, int lane, float &amax) {
+  co_wg_barrier(); /* every wave has read the activations this convolution consumed: they may be overwritten */
+#pragma unroll
+  for (int T = 0; T < 2; ++T) {
+    float out[2][16];
+#pragma unroll
+    for (int gg = 0; gg < 4; ++gg) {
+      const int chn = 32 * T + 8 * gg + 4 * h;
+      const float4 b4 = *reinterpret_cast<const float4 *>(epi + chn);
+      const float4 a4 = *reinterpret_cast<const float4 *>(epi + 64 + chn);
+      const float4 c4 = *reinterpret_cast<const float4 *>(epi + 128 + chn);
+      const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+      const float aa[4] = {a4.x, a4.y, a4.z, a4.w};
+      const float cc[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float cb = __builtin_fmaf(aa[i], bb[i], cc[i]);
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi) {
+          float v = __builtin_fmaf(aa[i], acc[pi][T][4 * gg + i], cb);
+          if (ADD_SKIP) v = x[pi][T][4 * gg + i] + v;
+          v = v > 0.0f ? v : 0.0f;
+          out[pi][4 * gg + i] = v;
+        }
+      }
+    }
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi) {
+      const int p = pi ? P1 : P0;
+#pragma unroll
+      for (int a2 = 0; a2 < 2; ++a2) {
+        u32x4 hi, lo;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const float u0 = out[pi][8 * a2 + 2 * m], u1 = out[pi][8 * a2 + 2 * m + 1];
+          amax = __builtin_fmaxf(amax, __builtin_fmaxf(u0, u1));
+          uint32_t t[2];
+          rcs_split<2, true>(u0, u1, t);
+          hi[m] = t[0];
+          lo[m] = t[1];
+        }
+        const int sidx = 2 * T + a2;
+        *reinterpret_cast<u32x4 *>(X + ((p * 4 + sidx) * 2 + 0) * 256 + lane * 4) = hi;
+        *reinterpret_cast<u32x4 *>(X + ((p * 4 + sidx) * 2 + 1) * 256 + lane * 4) = lo;
+      }
+      if (KEEP) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) x[pi][T][i] = out[pi][i];
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_h3p(Rc3Params Q) {
+  const RcParams &P = Q.base;
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
+  const int rows = *P.d_rows;
+  if (rows <= RC3_SMALL_ROWS) return; /* the small-batch kernel takes this batch */
+  const int row0 = blockIdx.x * 32;
+  if (row0 >= rows) return;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, h = lane >> 5, n = lane & 31;
+  uint32_t *X = lds_dyn;
+  const uint32_t *Wb = lds_dyn + RCP_X_WORDS;
+  const uint32_t lds_w_addr = co_lds_addr(lds_dyn) + RCP_X_WORDS * 4u;
+  /* this wave's two output pixels and their taps on the board */
+  const int P0 = wave < 4 ? (wave == 0 ? 5 : wave == 1 ? 6 : wave == 2 ? 9 : 10) : (wave == 4 ? 1 : wave == 5 ? 4 : wave == 6 ? 7 : 13);
+  const int P1 = wave < 4 ? (wave == 0 ? 0 : wave == 1 ? 3 : wave == 2 ? 12 : 15) : (wave == 4 ? 2 : wave == 5 ? 8 : wave == 6 ? 11 : 14);
+  int valid0 = 0, valid1 = 0;
+  for (int tap = 0; tap < 9; ++tap) {
+    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+    if ((P0 >> 2) + dy >= 0 && (P0 >> 2) + dy < 4 && (P0 & 3) + dx >= 0 && (P0 & 3) + dx < 4) valid0 |= 1 << tap;
+    if ((P1 >> 2) + dy >= 0 && (P1 >> 2) + dy < 4 && (P1 & 3) + dx >= 0 && (P1 & 3) + dx < 4) valid1 |= 1 << tap;
+  }
+  /* input planes of this wave's pixels as the stem's B fragments (K step 0, first term: board bits and k / 4 are exact in
+   * fp16).  k-slot (h, j) <-> channel 8 (j / 4) + 4 h + j % 4: h 0 = the cell's four board bits, reserves 4..5 and padding;
+   * h 1 = reserves 0..3 and zeros (rcs_forward's planes) */
+  {
+    const int pos = row0 + n;
+    float4 vq[2], v1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    vq[0] = vq[1] = v1;
+    if (pos < rows) {
+      const float *row = P.in + rc_in_row(P, pos) * CO_STATE_STRIDE;
+      vq[0] = *reinterpret_cast<const float4 *>(row + (h == 0 ? 4 * P0 : 64));
+      vq[1] = *reinterpret_cast<const float4 *>(row + (h == 0 ? 4 * P1 : 64));
+      v1 = *reinterpret_cast<const float4 *>(row + (h == 0 ? 68 : 72));
+    }
+    rcp_stage(Q, lds_w_addr, 0, wave, lane); /* behind the input loads: vmcnt retires in issue order */
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi) {
+      const int p = pi ? P1 : P0;
+      uint32_t t[1];
+      u32x4 f;
+      rcs_split<1, true>(vq[pi].x, vq[pi].y, t);
+      f[0] = t[0];
+      rcs_split<1, true>(vq[pi].z, vq[pi].w, t);
+      f[1] = t[0];
+      rcs_split<1, true>(v1.x, v1.y, t);
+      f[2] = t[0];
+      rcs_split<1, true>(v1.z, v1.w, t);
+      f[3] = t[0];
+      *reinterpret_cast<u32x4 *>(X + ((p * 4 + 0) * 2 + 0) * 256 + lane * 4) = f;
+    }
+  }
+  float amax = 0.0f;
+  f32x16 acc[2][2];
+  float x[2][2][16];
+#pragma unroll
+  for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+    for (int T = 0; T < 2; ++T)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) x[pi][T][i] = 0.0f;
+  const float *epi = P.epi; /* (global: the 160 KB of LDS hold activations and weights) */
+  int g = 0;
+  rcp_conv3x3<1>(acc, g, Q, X, Wb, lds_w_addr, P0, P1, valid0, valid1, wave, lane);
+  rcp_epilogue<false, true>(x, acc, epi, X, P0, P1, h, lane, amax);
+  for (int b = 0; b < 4; ++b) {
+    rcp_conv3x3<4>(acc, g, Q, X, Wb, lds_w_addr, P0, P1, valid0, valid1, wave, lane);
+    rcp_epilogue<false, false>(x, acc, epi + (1 + 2 * b) * 192, X, P0, P1, h, lane, amax);
+    rcp_conv3x3<4>(acc, g, Q, X, Wb, lds_w_addr, P0, P1, valid0, valid1, wave, lane);
+    rcp_epilogue<true, true>(x, acc, epi + (2 + 2 * b) * 192, X, P0, P1, h, lane, amax);
+  }
+  if (!(amax <= CO_F16_MAX)) atomicOr(Q.range_flag, 1u); /* (never in range: no lane enters) */
+  /* heads: item 81 = the 1x1 convolutions' fragments (rows 0..3 policy planes, 4..5 value planes), in buffer 1; the head
+   * features of the 32 positions go to buffer 0, which tap 80 has left */
+  CO_WAIT_VMCNT(0);
+  co_wg_barrier();
+  {
+    const uint32_t *hwb = Wb + (81 & 1) * RCP_TAP_WORDS + lane * 4;
+    float *feat = reinterpret_cast<float *>(lds_dyn + RCP_X_WORDS); /* buffer 0: [32 positions][96] */
+    u32x4 hw[2][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) hw[t][s] = *reinterpret_cast<const u32x4 *>(hwb + (s * 2 + t) * 256);
+    const float4 b4 = *reinterpret_cast<const float4 *>(P.head_epi + 4 * h);
+    const float4 a4 = *reinterpret_cast<const float4 *>(P.head_epi + 16 + 4 * h);
+    const float4 c4 = *reinterpret_cast<const float4 *>(P.head_epi + 32 + 4 * h);
+    const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+    const float aa[4] = {a4.x, a4.y, a4.z, a4.w};
+    const float cc[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi) {
+      const int p = pi ? P1 : P0;
+      f32x16 h1;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) h1[i] = 0.0f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const u32x4 b0 = *reinterpret_cast<const u32x4 *>(X + ((p * 4 + s) * 2 + 0) * 256 + lane * 4);
+        const u32x4 b1 = *reinterpret_cast<const u32x4 *>(X + ((p * 4 + s) * 2 + 1) * 256 + lane * 4);
+        h1 = rcs_mfma<true>(hw[0][s], b0, h1);
+        h1 = rcs_mfma<true>(hw[0][s], b1, h1);
+        h1 = rcs_mfma<true>(hw[1][s], b0, h1);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = h1[r] + bb[r];
+        v = aa[r] * v + cc[r];
+        v = v > 0.0f ? v : 0.0f;
+        if (h == 0) feat[n * 96 + p * 4 + r] = v;
+        if (h == 1 && r < 2) feat[n * 96 + 64 + p * 2 + r] = v;
+      }
+    }
+    __syncthreads();
+    /* 32 positions = two column tiles: waves 0, 1 their policy heads, waves 2, 3 their value heads; the dense weights
+     * straight from global memory (fp32, MFMA order, shared by every workgroup: L2) */
+    if (wave < 2) rc_dense_policy(P, P.wpol, feat + wave * 16 * 96, rows, row0 + wave * 16, lane, 16);
+    else if (wave < 4) rc_dense_value(P, P.wv1, P.wv2, feat + (wave - 2) * 16 * 96, rows, row0 + (wave - 2) * 16, lane, 16);
+  }
+}
+
 /* ------------------------------------------------------------------ host */
 struct ResCnnNet : CoNet {
   std::vector<float *> bufs;
@@ -1023,6 +1290,7 @@ static inline void rc_bf16_terms(float v, int nt, uint16_t *t, bool f16 = false)
 struct ResCnnSplitNet : ResCnnNet {
   int nt;
   bool f16;
+  bool pixmajor = false; /* f16: batches beyond RC3_SMALL_ROWS on the pixel-major kernel (K6p) */
   uint32_t *d_trunk3 = nullptr;
   uint32_t *d_whead3 = nullptr;
   uint32_t *d_epi3 = nullptr;
@@ -1094,6 +1362,14 @@ struct ResCnnSplitNet : ResCnnNet {
                                    RCS_LDS_WORDS(2, 1) * 4));
       RT_CHECK(hipFuncSetAttribute((const void *)co_k_rescnn_forward_h3, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    RCH_LDS_WORDS(2) * 4));
+      RT_CHECK(hipFuncSetAttribute((const void *)co_k_rescnn_forward_h3p, hipFuncAttributeMaxDynamicSharedMemorySize, RCP_LDS_WORDS * 4));
+#ifndef CO_RESCNN_PIXMAJOR_DEFAULT
+#define CO_RESCNN_PIXMAJOR_DEFAULT 1
+#endif
+      {
+        const char *e = getenv("CORINTHO_RESCNN_PIXMAJOR"); /* diagnostic: 0 = the (position, pixel)-column kernel for every batch size */
+        pixmajor = f16 && (e ? e[0] != '0' : CO_RESCNN_PIXMAJOR_DEFAULT != 0);
+      }
       RT_CHECK(hipFuncSetAttribute((const void *)co_k_rescnn_forward_h3_small, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    RCH_LDS_WORDS(1) * 4));
     } else {
@@ -1140,9 +1416,13 @@ struct ResCnnSplitNet : ResCnnNet {
       const int small_grid = f16 && (thin_rows + 7) / 8 > (small_rows + 15) / 16 ? (thin_rows + 7) / 8 : (small_rows + 15) / 16;
       hipLaunchKernelGGL(f16 ? co_k_rescnn_forward_h3_small : co_k_rescnn_forward_x3_small, dim3(small_grid), dim3(512),
                          (f16 ? RCH_LDS_WORDS(1) : RCS_LDS_WORDS(2, 1)) * 4, s, q);
-      if (rows_cap > RC3_SMALL_ROWS)
-        hipLaunchKernelGGL(f16 ? co_k_rescnn_forward_h3 : co_k_rescnn_forward_x3, dim3((rows_cap + 31) / 32), dim3(f16 ? RCH_THREADS : 512),
-                           (f16 ? RCH_LDS_WORDS(2) : RCS_LDS_WORDS(2, 2)) * 4, s, q);
+      if (rows_cap > RC3_SMALL_ROWS) {
+        if (pixmajor)
+          hipLaunchKernelGGL(co_k_rescnn_forward_h3p, dim3((rows_cap + 31) / 32), dim3(512), RCP_LDS_WORDS * 4, s, q);
+        else
+          hipLaunchKernelGGL(f16 ? co_k_rescnn_forward_h3 : co_k_rescnn_forward_x3, dim3((rows_cap + 31) / 32), dim3(f16 ? RCH_THREADS : 512),
+                             (f16 ? RCH_LDS_WORDS(2) : RCS_LDS_WORDS(2, 2)) * 4, s, q);
+      }
     } else {
       /* enough workgroups for either path: 16 positions each in the throughput path, 8 in the thin one (<= 2048 rows) */
       const int thin_rows = rows_cap < RC6_THIN_ROWS ? rows_cap : RC6_THIN_ROWS;

@@ -206,21 +206,20 @@ CO_DEV int co_legal_moves(uint64_t board, uint32_t meta, uint32_t out[3], const 
   return is_lines;
 }
 
-/* game.cpp:60-96.  Uniform. */
-CO_DEV void co_do_move(uint64_t *board, uint32_t *meta, int id) {
-  int is_place, piece, from, to;
-  co_decode_move(id, &is_place, &piece, &from, &to);
+/* game.cpp:60-96.  Uniform.  The cells of a stack move are lane `id`'s constants (no decoding, no division). */
+CO_DEV void co_do_move(uint64_t *board, uint32_t *meta, int id, const CoLanes &K) {
   uint64_t b = *board & ~0x8888888888888888ull;
   uint32_t m = *meta;
-  uint32_t tp = CO_META_TO_PLAY(m);
-  if (is_place) {
-    m -= 1u << (3 * (tp * 3 + piece));
-    b |= (uint64_t)((1u << piece) | 8u) << (4 * to);
+  if (id >= 48) {
+    const uint32_t piece = (uint32_t)(id - 48) >> 4, to4 = 4u * ((uint32_t)id & 15u);
+    m -= 1u << (3u * (CO_META_TO_PLAY(m) * 3u + piece));
+    b |= (uint64_t)((1u << piece) | 8u) << to4;
   } else {
-    uint64_t src = (b >> (4 * from)) & 7ull;
-    b |= src << (4 * to);
-    b &= ~(15ull << (4 * from));
-    b |= 8ull << (4 * to);
+    const uint32_t from4 = WAVE_BCAST(K.from_sh, id) + 32u * WAVE_BCAST(K.from_hi, id);
+    const uint32_t to4 = WAVE_BCAST(K.to_sh, id) + 32u * WAVE_BCAST(K.to_hi, id);
+    const uint64_t src = (b >> from4) & 7ull;
+    b &= ~(15ull << from4);
+    b |= (src | 8ull) << to4;
   }
   *board = b;
   *meta = m ^ (1u << 18);

@@ -145,6 +145,32 @@ extern thread_local int co_emu_block_idx;
 #define CO_DPP_MIRROR 0x140
 #define CO_DPP_I(v, ctrl) __builtin_amdgcn_mov_dpp((v), (ctrl), 0xF, 0xF, false)
 #define CO_DPP_F(v, ctrl) __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), (ctrl), 0xF, 0xF, false))
+/* Wave maximum of a float that is never NaN (PUCT values: finite or -inf), result wave-uniform and bit-equal to one
+ * lane's input (+0 / -0 aside, which compare equal).  Six v_max_f32 with a DPP source: four steps inside each row of 16
+ * lanes, then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3 leave the wave's maximum in lane 63.
+ * (As v_mov_dpp + v_cmp + v_cndmask per step, then four v_readlane and scalar selects, the reduction was ~30 dependent
+ * instructions in the middle of every PUCT scan.)  The s_nop 1 in front of each step are the two wait states a DPP read
+ * needs behind the VALU write of its source, which the assembler does not insert. */
+#ifndef CO_WAVE_MAX_PLAIN
+__device__ __forceinline__ float co_wave_max_f32(float v) {
+  float r;
+  asm("s_nop 1\n\t"
+      "v_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+      : "=&v"(r)
+      : "v"(v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r), 63));
+}
+#else
 __device__ __forceinline__ float co_fmaxsel(float a, float b) { return b > a ? b : a; }
 __device__ __forceinline__ float co_wave_max_f32(float v) {
   v = co_fmaxsel(v, CO_DPP_F(v, CO_DPP_XOR1));
@@ -157,6 +183,7 @@ __device__ __forceinline__ float co_wave_max_f32(float v) {
   float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
   return co_fmaxsel(co_fmaxsel(r0, r1), co_fmaxsel(r2, r3));
 }
+#endif
 __device__ __forceinline__ int co_wave_sum_i32(int v) {
   v += CO_DPP_I(v, CO_DPP_XOR1);
   v += CO_DPP_I(v, CO_DPP_XOR2);
