@@ -135,7 +135,6 @@ struct ca_trainer {
   bool logs_written = false;
   DevBuf<float> req, nn_in, nn_in70, nn_eval, nn_probs, samples;
   DevBuf<unsigned long long> row_counter, pack_counter, prof, next_game;
-  DevBuf<uint32_t> turn_list, turn_count; /* fused training in two kernels: EngineParams::turn_list [R], ::turn_count [2 per pool] */
   DevBuf<GameCtl> results;   /* [G] finished games by index (recycling pools) */
   DevBuf<uint32_t> seeds_dev; /* [G] per-game generator seeds (recycling pools) */
   DevBuf<int32_t> ctl;
@@ -316,8 +315,6 @@ struct ca_trainer {
     all_done.alloc(1, stream);
     row_counter.alloc(1, stream);
     pack_counter.alloc(2 * CO_MAX_POOLS, stream);
-    turn_list.alloc((size_t)R, stream);
-    turn_count.alloc(2 * CO_MAX_POOLS, stream);
     arena_state.alloc(8, stream);
     if (tourney) {
       pcfg.alloc(host_pcfg.size(), stream);
@@ -392,7 +389,6 @@ struct ca_trainer {
     rt_h2d(next_game.p, &first_unstarted, 8, stream);
     rt_memset(row_counter.p, 0, 8, stream);
     rt_memset(pack_counter.p, 0, 16 * CO_MAX_POOLS, stream);
-    rt_memset(turn_count.p, 0, 8 * CO_MAX_POOLS, stream);
     rt_memset(arena_state.p, 0, 32, stream);
     rt_sync(stream);
     iterations = 0;
@@ -538,8 +534,6 @@ struct ca_trainer {
     P.pool_n = R;
     P.pool_row_base = 0;
     P.pack_counter = pack_counter.p;
-    P.turn_list = nullptr;
-    P.turn_count = nullptr;
 #ifdef CO_PROF
     prof.alloc((size_t)R * CO_NPROF + 24, stream);
     P.prof = prof.p;
@@ -982,11 +976,6 @@ struct ca_trainer {
    * kernel and fills launch tails.  Per-game results do not depend on the pooling. */
   bool run_pools(int64_t max_iterations, int npools) {
     const int poll = CO_POOL_POLL;
-#ifndef CO_SPLIT_STEP_DEFAULT
-#define CO_SPLIT_STEP_DEFAULT 0
-#endif
-    const char *env_split = getenv("CORINTHO_SPLIT_STEP"); /* diagnostic: 0 = the whole step in one kernel always, 1 = in two while the pool is full */
-    const bool split_step = env_split ? env_split[0] != '0' : CO_SPLIT_STEP_DEFAULT != 0;
     if ((int)pools.size() != npools) {
       free_pools();
       pools.resize(npools);
@@ -1129,19 +1118,7 @@ struct ca_trainer {
         rt_event_t *e = q.ev[parity];
         if (timed) rt_event_record(e[0], q.st);
         RT_LAUNCH(co_k_priors, ((q.n) * pp.searches_per_eval + CO_WAVES_PER_BLOCK - 1) / CO_WAVES_PER_BLOCK, CO_WAVE * CO_WAVES_PER_BLOCK, q.st, pp);
-        /* The step in two kernels while the pool is full (self-play training only): the hot loop on its own, then the
-         * once-per-ply work for the games whose turn ended (kernels.h).  Both hands of the split end a step at the
-         * hand-over, which is this branch's defer_handover; once the pool has thinned out the single kernel plays the
-         * new mover's first searches in the same step.  The counters of both iterations' parities are kept clear by
-         * whichever kernel runs (co_pool_housekeeping). */
-        pp.turn_list = turn_list.p + q.lo;
-        pp.turn_count = turn_count.p + 2 * p;
-        if (split_step && pp.defer_handover && !cfg.analyse && !cfg.testing) {
-          RT_LAUNCH(co_k_search, ((q.n) + CO_K3_WAVES - 1) / CO_K3_WAVES, CO_WAVE * CO_K3_WAVES, q.st, pp);
-          RT_LAUNCH(co_k_turn, (q.n + CO_WAVES_PER_BLOCK - 1) / CO_WAVES_PER_BLOCK, CO_WAVE * CO_WAVES_PER_BLOCK, q.st, pp);
-        } else {
-          RT_LAUNCH(co_k_mcts_step, ((q.n) + CO_K3_WAVES - 1) / CO_K3_WAVES, CO_WAVE * CO_K3_WAVES, q.st, pp);
-        }
+        RT_LAUNCH(co_k_mcts_step, ((q.n) + CO_K3_WAVES - 1) / CO_K3_WAVES, CO_WAVE * CO_K3_WAVES, q.st, pp);
         if (timed) rt_event_record(e[1], q.st);
         if (q.cache.hdr) {
           /* the search kernel has resolved every request row to an element of the cache's value array; the network

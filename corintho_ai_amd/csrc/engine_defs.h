@@ -78,8 +78,7 @@ struct GameCtl {
   uint32_t nodes;     /* ... nodes created */
   int32_t trace_len;
   int32_t row_off;    /* fused mode: first row of this game's requests in the compact batch */
-  int32_t resume;     /* fused mode: 1 = the new mover's first searches of a turn were deferred to the next step;
-                       * 2 = (within one iteration only) the turn ended in co_k_search, co_k_turn chooses the move */
+  int32_t resume;     /* fused mode: the new mover's first searches of a turn were deferred to the next step */
   /* tournament matches only: Match::root_, the position on the board (match.h:91) */
   uint32_t pos_lo, pos_hi, pos_meta;
   /* the game this slot plays (index within this trainer's games; = the slot index unless the pool recycles
@@ -199,11 +198,6 @@ struct EngineParams {
    * pool_n) and its batch rows start at row pool_row_base of nn_in / nn_eval / nn_probs */
   int32_t pool_lo, pool_n, pool_row_base;
   unsigned long long *pack_counter; /* [2] */
-  /* fused training, the step in two kernels (mcts.h co_search_step_wave / co_turn_step_wave): the games of the pool whose
-   * turn ended in this iteration's search kernel -- slot indices, in any order -- and their number by iteration parity
-   * (the other one is cleared for the next iteration).  Null: the whole step runs in co_k_mcts_step. */
-  uint32_t *turn_list;   /* [pool_n] */
-  uint32_t *turn_count;  /* [2] */
   /* Resident-slot pool (ca_config.resident < num_games, training only): the trainer's `total_local` games are
    * played on num_games slots.  A slot whose game ends stores the game's control block in results[gid], takes
    * the next unstarted game from next_game[0] and seeds its generator from seeds[gid] (the Trainer stream in

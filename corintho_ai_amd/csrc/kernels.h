@@ -26,26 +26,6 @@ CO_KERNEL co_k_mcts_step(EngineParams P) {
   if (i < P.pool_n && g < P.num_games) co_mcts_step_wave(P, g);
 }
 
-/* K3 of fused training in two kernels (mcts.h "the step of one game's wavefront, in pieces"): co_k_search is the hot loop
- * -- the backups of the received evaluations and the simulations of every game of the pool, one wavefront per game;
- * co_k_turn is everything that happens once per ply (move choice, logs, re-root, hand-over, end of game, slot
- * recycling), for the games whose turn ended in this iteration (a few dozen as a rule): one wavefront per entry of
- * the pool's turn list.  Kept apart, the hot kernel holds none of the cold paths' registers or instructions. */
-CO_KERNEL co_k_search(EngineParams P) {
-  const int i = CO_BLOCK_IDX * CO_K3_WAVES + CO_K3_WAVE_IN_BLOCK;
-  const int g = P.pool_lo + i;
-  if (i < P.pool_n && g < P.num_games) co_search_step_wave(P, g);
-}
-
-CO_KERNEL co_k_turn(EngineParams P) {
-  /* One wavefront per list entry; the launch has a wavefront for every game of the pool, because games that start
-   * together end their turns together (a generation's first plies: the whole pool in one iteration) -- the others
-   * leave at once.  (A few wavefronts walking the list in a loop also sent this compiler's simplifycfg into a crash.) */
-  const uint32_t n = P.turn_count[P.iteration & 1]; /* written by the search kernel in front of this launch */
-  const uint32_t k = (uint32_t)(CO_BLOCK_IDX * CO_WAVES_PER_BLOCK + CO_WAVE_IN_BLOCK);
-  if (k < n) co_turn_step_wave(P, (int)P.turn_list[k]);
-}
-
 /* K2b: the priors of every pending leaf whose evaluation this launch consumes -- one wavefront per
  * (game, pending leaf), before the search kernel (mcts.h "receiveEval, split in two").
  * getFilteredProbs + generateDirichlet + setProbs, trainmc.cpp:212-267. */

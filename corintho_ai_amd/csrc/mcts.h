@@ -540,18 +540,18 @@ CO_DEV double co_div_small(double x, float df) {
  * rewrite several path slots in memory (terminal leaf, dead end) drop the copy (valid = 0). */
 struct CoRoot {
   uint4 h0, h1, cs;
-  float vs;       /* c_puct sqrt(visits) of the root as it stands (co_vsqrt): computed one simulation ahead, in the
-                   * shadow of that simulation's block fetch */
   int valid;
   uint4 *ev;      /* LDS: edge slots 0..63 of the root */
   uint32_t e0;    /* unit offset of the root's edge slot 0 */
   uint32_t ne;    /* edge slots held: min(edges, 64) */
 };
 
-/* the exploration factor of a PUCT scan (trainmc.cpp:549): float(double(c_puct) * sqrt(double(float(visits)))) */
+/* the exploration factor of a PUCT scan (trainmc.cpp:549): float(double(c_puct) * sqrt(double(float(visits)))).
+ * (Computing it one step ahead, in the shadow of the descent's block fetch, was measured in round 4: the generation 5 %
+ * SLOWER -- two more values live across the scan loop cost more than the hidden chain saves.) */
 CO_DEV float co_vsqrt(float c_puct, int visits) { return (float)((double)c_puct * co_sqrt_f64((double)(float)visits)); }
 
-CO_DEV void co_root_load(CoTree &t, CoRoot &rc, float c_puct) {
+CO_DEV void co_root_load(CoTree &t, CoRoot &rc) {
   rc.h0 = co_load_unit(t.A, t.tc.root);
   rc.h1 = co_load_unit(t.A, t.tc.root + 1);
   rc.cs = co_load_unit(t.A, rc.h1.x);
@@ -561,7 +561,6 @@ CO_DEV void co_root_load(CoTree &t, CoRoot &rc, float c_puct) {
   const uint4 *A = t.A;
   FOR_LANES { rc.ev[lane] = A[rc.e0 + lane]; } /* arena is padded: lanes >= n read unused units */
   WAVE_SYNC();
-  rc.vs = co_vsqrt(c_puct, co_slot_visits(rc.cs));
   rc.valid = 1;
 }
 
@@ -595,7 +594,6 @@ CO_DEV void co_search(CoWave &w, CoTree &t, CoRoot &rc) {
   LV(uint4, ev);
   FOR_LANES { L(ev) = rc.ev[lane]; }
   int D = 0;
-  float vs = rc.vs; /* exploration factor of the node about to be scanned */
   int leaf_n = 0; /* legal moves of the node this simulation creates */
   uint32_t leaf_lm[3] = {0u, 0u, 0u};
   FOR_LANES {
@@ -610,7 +608,7 @@ CO_DEV void co_search(CoWave &w, CoTree &t, CoRoot &rc) {
     int n = (int)CO_META_NEDGES(h0.z);
     float denom = co_u2f(h1.y);
     int visits = co_slot_visits(cs);
-    const float v_sqrt = vs;
+    const float v_sqrt = co_vsqrt(w.c_puct, visits);
     /* ---- chooseNext: u for every edge, strict first maximum */
     float best_u = CO_NEG_INF;
     int best_e = -1;
@@ -686,7 +684,6 @@ CO_DEV void co_search(CoWave &w, CoTree &t, CoRoot &rc) {
     CO_PH(9);
     if (best_slot.x == CO_NONE) {
       /* kNew: expand (Node ctor from parent, node.cpp:31-39) */
-      if (D == 0) rc.vs = co_vsqrt(w.c_puct, visits + 1);
       uint64_t board = (uint64_t)h0.x | ((uint64_t)h0.y << 32);
       uint32_t meta = h0.z;
       int move = (int)(best_slot.z & 127u);
@@ -727,11 +724,6 @@ CO_DEV void co_search(CoWave &w, CoTree &t, CoRoot &rc) {
     h0 = co_load_unit(A, cur);
     h1 = co_load_unit(A, cur + 1);
     FOR_LANES { L(ev) = A[cur + 2 + lane]; }
-    /* while the block is on its way: the child's exploration factor (its visits are in the slot just scanned) and, leaving
-     * the root, the root's for the NEXT simulation (its visits have just been counted up) -- two independent chains of a
-     * double-precision square root that would otherwise stand between the fetch and the scan */
-    vs = co_vsqrt(w.c_puct, co_slot_visits(cs));
-    if (D == 0) rc.vs = co_vsqrt(w.c_puct, visits + 1);
     CO_PH_MEM(11);
     ++D;
     FOR_LANES {
@@ -818,7 +810,7 @@ CO_DEV int co_mc_do_iteration(CoWave &w, CoTree &t, const float *eval, const flo
   rc.ne = 0u;
   for (;;) {
     if (!(w.gc.n_pending < w.spe && t.tc.searches_done < w.max_searches)) break;
-    if (!rc.valid) co_root_load(t, rc, w.c_puct);
+    if (!rc.valid) co_root_load(t, rc);
 
     if (co_res_known(co_slot_result(rc.cs)) || co_slot_all_visited(rc.cs)) break;
     if (w.gc.error) break;
@@ -1240,17 +1232,12 @@ CO_DEV void co_analyse_finish(CoWave &w, CoTree &t, int choice) {
  * (250 KB of instructions in front of a 64 KB instruction cache).  Returns "game over". */
 CO_DEV int co_game_step(CoWave &w, const float *eval, const float *probs) {
   const float *ev = eval, *pr = probs;
-  if (w.gc.resume == 1) {
+  if (w.gc.resume) {
     /* continuation of a deferred hand-over: selfplayer.cpp:287-288 */
     w.gc.resume = 0;
     ev = pr = (const float *)0;
   }
   int skip_iteration = (w.pc && w.pc[w.gc.to_play].random) /* match.cpp:68-70 */ || w.force_choose;
-  if (w.gc.resume == 2) { /* the turn ended in co_k_search (fused training in two kernels): enter at the move choice */
-    w.gc.resume = 0;
-    skip_iteration = 1;
-    ev = pr = (const float *)0;
-  }
   int fresh_root = 0;
   for (;;) {
     if (!skip_iteration) {
@@ -1487,12 +1474,13 @@ CO_DEV void co_cache_resolve(const EngineParams &P, CoWave &w, int g, int n, int
   }
 }
 
-/* ---- the step of one game's wavefront, in pieces shared by the three search kernels (kernels.h):
- *   co_k_mcts_step  the whole step in one kernel (compat protocol, arena, tournaments, analysis, and fused training
- *                   once a pool has thinned out);
- *   co_k_search     fused training: the receive + simulate half of the step -- the hot loop and nothing else;
- *   co_k_turn       fused training: the rest (move choice, logs, re-root, hand-over, end of game, slot recycling) for
- *                   the games whose turn ended in this iteration's co_k_search. */
+/* ---- the step of one game's wavefront (co_k_mcts_step), in pieces.
+ * (Round 4 also ran fused training as TWO kernels -- the receive + simulate half as a hot kernel of its own, 62 spilled
+ * SGPRs instead of 260 and a third of the instructions, and the once-per-ply work (move choice, logs, re-root, hand-over,
+ * slot recycling) as a second launch over a list of the games whose turn had ended.  Measured on the same box,
+ * alternating libraries: 4096 games x 400 simulations, mlp12x100 f16x3, 168.0 against 160.5 ms per generation, rescnn4
+ * 518.4 against 512.8 -- the second launch per iteration costs more than the spills and the instruction-cache misses
+ * of the cold paths, which are not executed in the hot loop anyway.  Removed; commit 28aee16 has it.) */
 
 /* first wave of a pool's launch: clear the counters of the NEXT iteration (nobody reads them before the next launch) */
 CO_DEV void co_pool_housekeeping(const EngineParams &P, int g) {
@@ -1500,7 +1488,6 @@ CO_DEV void co_pool_housekeeping(const EngineParams &P, int g) {
     FOR_LANES {
       if (lane == 0) {
         P.pack_counter[(P.iteration + 1) & 1] = 0ull;
-        if (P.turn_count) P.turn_count[(P.iteration + 1) & 1] = 0u;
         if (P.cache.hdr) {
           /* the other parity's counter of rows to evaluate was the previous iteration's (its network launch is
            * over): book it, clear it for the next iteration */
@@ -1650,7 +1637,7 @@ CO_DEV void co_wave_store(const EngineParams &P, const CoWave &w, int g) {
 }
 
 /* Trainer::doIteration for game g (trainer.cpp:164-236): the body of the
- * `omp parallel for`, one wavefront per game -- the whole step (co_k_mcts_step). */
+ * `omp parallel for`, one wavefront per game. */
 CO_DEV void co_mcts_step_wave(const EngineParams &P, int g) {
   co_pool_housekeeping(P, g);
   GameCtl gc = P.games[g];
@@ -1698,86 +1685,5 @@ CO_DEV void co_mcts_step_wave(const EngineParams &P, int g) {
     atomicAdd(glob + 4 + bucket, 1ull);
   }
 #endif
-  co_wave_store(P, w, g);
-}
-
-/* ---- fused training, the step in two kernels.  The receive + simulate half (co_k_search): TrainMC::doIteration of the
- * player to move and nothing else.  A turn that ends here (`done`) is handed to co_k_turn through the pool's turn list;
- * its move is chosen there, in the same iteration.  The game's own sequence of operations -- tree updates, generator
- * draws -- is the single kernel's: per-game results do not depend on which kernels played it. */
-CO_DEV void co_search_step_wave(const EngineParams &P, int g) {
-  co_pool_housekeeping(P, g);
-  GameCtl gc = P.games[g];
-  const TreeCtl tc0 = P.trees[2 * g], tc1 = P.trees[2 * g + 1];
-  const int gate = co_step_gate(P, g, gc);
-  if (gate != 1) {
-    if (gate == 2) co_atomic_add_u64(P.pack_counter + (P.iteration & 1), 1ull << 32); /* still running */
-    return;
-  }
-  CoWave w;
-#if defined(CO_PROF) && !defined(CO_EMU)
-  for (int i = 0; i < CO_NPROF; ++i) w.pacc[i] = 0ull; /* (stamps are read from the single-kernel path: tools/prof_phases.py) */
-  w.tph = 0ull;
-#endif
-  co_wave_init(P, g, gc, tc0, tc1, w);
-  const int off = co_step_row(P, g, gc);
-  const float *ev = P.nn_eval + off, *pr = P.nn_probs + (size_t)off * CO_NUM_MOVES;
-  if (w.gc.resume) { /* continuation of a deferred hand-over (co_game_step): nothing to receive */
-    w.gc.resume = 0;
-    ev = pr = (const float *)0;
-  }
-  const int turn_over = co_mc_do_iteration(w, w.me, ev, pr);
-  if (turn_over && !w.gc.error) {
-    /* the move choice is co_k_turn's: queue the game (nothing is pending: a turn ends with every leaf received) */
-    w.gc.resume = 2;
-    const uint32_t at = co_atomic_add_u32(P.turn_count + (P.iteration & 1), 1u);
-    uint32_t *lst = P.turn_list;
-    FOR_LANES {
-      if (lane == 0) lst[at] = (uint32_t)g;
-    }
-  } else {
-    co_step_tail(P, w, g, 0);
-  }
-  /* what this kernel may have changed (the rest of the control block is co_k_turn's) */
-  GameCtl *dst = P.games + g;
-  TreeCtl *tdst = P.trees + 2 * g + w.gc.to_play;
-  FOR_LANES {
-    if (lane == 0) {
-      dst->error = w.gc.error;
-      dst->n_pending = w.gc.n_pending;
-      dst->rng_idx = w.gc.rng_idx;
-      dst->searches = w.gc.searches;
-      dst->evals = w.gc.evals;
-      dst->nodes = w.gc.nodes;
-      dst->row_off = w.gc.row_off;
-      dst->resume = w.gc.resume;
-      *tdst = w.me.tc;
-    }
-  }
-}
-
-/* The other half (co_k_turn), for a game whose turn ended in this iteration's co_k_search: co_game_step entered at the
- * move choice (resume == 2), always ending its step at the hand-over (the new mover's searches are the next
- * iteration's co_k_search: lock-step scheduling, see co_game_step). */
-CO_DEV void co_turn_step_wave(const EngineParams &P, int g) {
-  GameCtl gc = P.games[g];
-  const TreeCtl tc0 = P.trees[2 * g], tc1 = P.trees[2 * g + 1];
-  CoWave w;
-#if defined(CO_PROF) && !defined(CO_EMU)
-  for (int i = 0; i < CO_NPROF; ++i) w.pacc[i] = 0ull;
-  w.tph = 0ull;
-#endif
-  co_wave_init(P, g, gc, tc0, tc1, w);
-  w.defer_handover = 1;
-  int done;
-  for (;;) { /* one pass, unless the slot's game ends and the pool hands it the next one */
-    /* (no evaluation is pending on any path through here -- a turn ends with every leaf received, a fresh game has
-     * none -- so the pointers are never read; real ones rather than null constants, on which this compiler's
-     * simplifycfg crashes after inlining) */
-    done = co_game_step(w, P.nn_eval, P.nn_probs);
-    if (!done) break;
-    if (!co_slot_next_game(P, w)) break;
-  }
-  co_step_tail(P, w, g, done);
   co_wave_store(P, w, g);
 }

@@ -405,7 +405,8 @@ def test_engine_reproduces_the_reference_rows_as_a_population():
     n = 1000
     zs, zh, table = {}, [], []
     tot_here, tot_ref = np.zeros(3), np.zeros(3)
-    for (a, b), r in sorted(ref.items()):
+    def play(key):
+        a, b = key
         t = Tourney(1, "")
         for p in (a, b):
             t.addPlayer(p, 93 - p, 1600, 16, 3.0, 0.25, False)
@@ -417,6 +418,17 @@ def test_engine_reproduces_the_reference_rows_as_a_population():
         assert t.run()
         sc = [t.match_score(i) for i in range(n)]
         t.close()
+        return sc
+
+    # a row is a tournament of its own (two networks), as long as its longest game whatever its size: four at a time, each on
+    # its own streams (the engine keeps no state outside a trainer; ctypes releases the interpreter lock during a call)
+    from concurrent.futures import ThreadPoolExecutor
+
+    keys = sorted(ref)
+    with ThreadPoolExecutor(4) as ex:
+        scores = dict(zip(keys, ex.map(play, keys)))
+    for (a, b) in keys:
+        r, sc = ref[(a, b)], scores[(a, b)]
         got = _wdl(sc)
         zs[(a, b)] = _z_win(got, r)
         zh.append(_z_win(_wdl(sc[: n // 2]), _wdl(sc[n // 2:])))  # this side against itself: two halves of fresh seeds

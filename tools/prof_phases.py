@@ -17,7 +17,6 @@ subprocess.check_call(cmd)
 L = _lib.declare(C.CDLL(out))
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 400
-os.environ["CORINTHO_SPLIT_STEP"] = "0"  # the stamps are read from the single-kernel path
 pools = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 t = Trainer(G, "", 12345, S, 16, 1.0, 0.25, 0, 1, False, stagger=False, pools=pools, _cdll=L)
 t.set_net(9, nets.init_mlp12x100(0))
