@@ -933,6 +933,38 @@ __device__ __forceinline__ void rcp_conv3x3(f32x16 (&acc)[2][2], int &g, const R
       for (int to = 0; to < 2; ++to)
 #pragma unroll
         for (int t = 0; t < 2; ++t) a[t][to] = *reinterpret_cast<const u32x4 *>(wb + ((s * 2 + to) * 2 + t) * 256);
+#ifdef CO_RCP_BOTH_LOADS
+      /* both pixels' activation fragments are requested before either pixel's MFMAs issue */
+      u32x4 bq[2][XT];
+      if (v0) {
+#pragma unroll
+        for (int t = 0; t < XT; ++t) bq[0][t] = *reinterpret_cast<const u32x4 *>(x0 + (s * 2 + t) * 256);
+      }
+      if (v1) {
+#pragma unroll
+        for (int t = 0; t < XT; ++t) bq[1][t] = *reinterpret_cast<const u32x4 *>(x1 + (s * 2 + t) * 256);
+      }
+      if (v0) {
+#pragma unroll
+        for (int sum = 0; sum < 2; ++sum)
+#pragma unroll
+          for (int i = 0; i <= sum; ++i)
+            if (sum - i < XT) {
+#pragma unroll
+              for (int to = 0; to < 2; ++to) acc[0][to] = rcs_mfma<true>(a[i][to], bq[0][sum - i], acc[0][to]);
+            }
+      }
+      if (v1) {
+#pragma unroll
+        for (int sum = 0; sum < 2; ++sum)
+#pragma unroll
+          for (int i = 0; i <= sum; ++i)
+            if (sum - i < XT) {
+#pragma unroll
+              for (int to = 0; to < 2; ++to) acc[1][to] = rcs_mfma<true>(a[i][to], bq[1][sum - i], acc[1][to]);
+            }
+      }
+#else
       if (v0) {
         u32x4 b[XT];
 #pragma unroll
@@ -959,6 +991,7 @@ __device__ __forceinline__ void rcp_conv3x3(f32x16 (&acc)[2][2], int &g, const R
               for (int to = 0; to < 2; ++to) acc[1][to] = rcs_mfma<true>(a[i][to], b[sum - i], acc[1][to]);
             }
       }
+#endif
     }
   }
 }
@@ -1033,8 +1066,19 @@ __global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_h3p(Rc3Params Q) {
   const uint32_t *Wb = lds_dyn + RCP_X_WORDS;
   const uint32_t lds_w_addr = co_lds_addr(lds_dyn) + RCP_X_WORDS * 4u;
   /* this wave's two output pixels and their taps on the board */
+#ifdef CO_RCP_OLD_PIXELS
   const int P0 = wave < 4 ? (wave == 0 ? 5 : wave == 1 ? 6 : wave == 2 ? 9 : 10) : (wave == 4 ? 1 : wave == 5 ? 4 : wave == 6 ? 7 : 13);
   const int P1 = wave < 4 ? (wave == 0 ? 0 : wave == 1 ? 3 : wave == 2 ? 12 : 15) : (wave == 4 ? 2 : wave == 5 ? 8 : wave == 6 ? 11 : 14);
+#else
+  /* Waves w and w + 4 share a SIMD (a workgroup's waves go round the four SIMDs), and every tap ends at a barrier: what
+   * a tap costs is the SIMD with the most (pixel, tap) pairs on the board at THAT tap.  The four pixels of a SIMD are
+   * chosen so that every tap is spread evenly -- {0, 5, 6, 15}, {1, 4, 7, 13}, {2, 8, 11, 14}, {3, 9, 10, 12}: at most
+   * 4, 3 or 3 pairs per SIMD at the centre, side and diagonal taps, 28 slots per convolution where the board has 25 per
+   * SIMD on average (the optimum over all 2.6 M partitions; an interior + a corner and two neighbouring edge pixels per
+   * wave: 34; the (position, pixel)-column kernel multiplies all 36). */
+  const int P0 = wave == 0 ? 5 : wave == 1 ? 1 : wave == 2 ? 2 : wave == 3 ? 9 : wave == 4 ? 6 : wave == 5 ? 4 : wave == 6 ? 8 : 10;
+  const int P1 = wave == 0 ? 15 : wave == 1 ? 13 : wave == 2 ? 14 : wave == 3 ? 12 : wave == 4 ? 0 : wave == 5 ? 7 : wave == 6 ? 11 : 3;
+#endif
   int valid0 = 0, valid1 = 0;
   for (int tap = 0; tap < 9; ++tap) {
     const int dy = tap / 3 - 1, dx = tap % 3 - 1;
