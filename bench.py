@@ -56,7 +56,9 @@ MLP_FLOP = 2.0 * (70 * 100 + 11 * 100 * 100 + 100 + 100 * 96)
 # name -> (kind constant name, architecture, dtype label, matrix peak, MFMA products issued per algorithmic
 #          product, kernel name as in the rocprof summaries)
 NETS = {
-    "rescnn4h3": ("NET_RESCNN4_H3", "rescnn4", "f32(f16x3)", BF16_MFMA_PEAK_TFLOPS, 3.0, "co_k_rescnn_forward_h3"),
+    # (the throughput kernel is pixel-major since round 4: it multiplies only the (pixel, tap) pairs on the board, 6.71 of the
+    #  9.65 MFLOP per row that the algorithmic count -- SURVEY 8d, padding included -- holds: 3 x 6.71 / 9.65 products issued)
+    "rescnn4h3": ("NET_RESCNN4_H3", "rescnn4", "f32(f16x3)", BF16_MFMA_PEAK_TFLOPS, 2.086, "co_k_rescnn_forward_h3p"),
     "mlp12x100h3": ("NET_MLP12X100_H3", "mlp12x100", "f32(f16x3)", BF16_MFMA_PEAK_TFLOPS, 3.0, "co_k_mlp_forward_h3"),
     "rescnn4x6": ("NET_RESCNN4_X6", "rescnn4", "f32(bf16x6)", BF16_MFMA_PEAK_TFLOPS, 6.0, "co_k_rescnn_forward_x6"),
     "rescnn4": ("NET_RESCNN4", "rescnn4", "f32", FP32_MFMA_PEAK_TFLOPS, 1.0, "co_k_rescnn_forward"),
@@ -188,9 +190,10 @@ def measured_traffic(kernel, args, net, npools):
     if (args.games, args.sims, args.spe) != (4096, 400, 16):
         return None
     try:
-        path = os.path.join(ROOT, "profiles", "r03_%s_pmc.json" % net)
-        if not os.path.exists(path):
-            path = os.path.join(ROOT, "profiles", "r02_%s_pmc.json" % net)
+        for rnd in ("r04", "r03", "r02"):
+            path = os.path.join(ROOT, "profiles", "%s_%s_pmc.json" % (rnd, net))
+            if os.path.exists(path):
+                break
         with open(path) as f:
             k = json.load(f)["kernels"]
             t = k[kernel]["traffic_bytes_per_launch"]
@@ -474,9 +477,9 @@ def main():
               "issued_frac": issued * achieved / peak,
               # products of a 3x3 tap with the zero padding of the 4x4 board (44 of 144) not counted as work
               "algorithmic_useful": {"achieved": achieved * useful, "frac": achieved * useful / peak},
-              "algorithmic": "%.1f KFLOP/row x %d rows in %d timed launches of %d (x%d MFMA products issued per algorithmic one)"
+              "algorithmic": "%.1f KFLOP/row x %d rows in %d timed launches of %d (x%.2f MFMA products issued per algorithmic one)"
                              % (flop_per_row / 1e3, totals["nn_timed_rows"] if tl else totals["nn_rows_evaluated"],
-                                tl if tl else totals["nn_launches"], totals["nn_launches"], int(issued)),
+                                tl if tl else totals["nn_launches"], totals["nn_launches"], issued),
               "avg_launch_ms": (totals["nn_timed_ms"] / tl) if tl else totals["nn_ms"] / max(totals["nn_launches"], 1)}
         sims_per_launch = totals["searches"] / max(totals["mcts_launches"], 1)
         s_launch_ms = (totals["mcts_timed_ms"] / tl) if tl else totals["mcts_ms"] / max(totals["mcts_launches"], 1)

@@ -670,14 +670,15 @@ __device__ __forceinline__ void rc3_epilogue(float (&out)[NP][2][16], const f32x
 
 #ifdef CO_PROF
 /* diagnostic builds: cycles of wave 0 of every workgroup by phase (tools/prof_nn.py) */
-__device__ unsigned long long rc3_prof[9]; /* 0..5 phases, 6 whole pass, 7 passes, 8 whole pass in 100 MHz ticks */
+__device__ unsigned long long rc3_prof[12]; /* 0..5 phases, 6 whole pass, 7 passes, 8 whole pass in 100 MHz ticks; K6p only: 9 waited for the
+                                             * weight DMA, 10 waited at the tap barrier, 11 multiplied (inside phases 1 and 3) */
 #define RC3_STAMP(slot)                                                              \
   {                                                                                  \
     unsigned long long now_ = __builtin_readcyclecounter();                          \
     if (tid == 0) atomicAdd(&rc3_prof[slot], now_ - stamp_);                         \
     stamp_ = now_;                                                                   \
   }
-extern "C" int ca_net_prof(unsigned long long out[9]) {
+extern "C" int ca_net_prof(unsigned long long out[12]) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(rc3_prof), sizeof(rc3_prof)) == hipSuccess ? 0 : 1;
 }
 #else
@@ -907,9 +908,29 @@ __device__ __forceinline__ void rcp_stage(const Rc3Params &Q, uint32_t lds_w_add
 
 /* one 3x3 convolution of this wave's two output pixels.  CS = K steps (1: stem, whose inputs are exact in fp16 -- only
  * their first term exists; 4: trunk) */
+#ifdef CO_PROF
+/* (sums in registers, written once at the end of the kernel: a stamp that touches memory would itself be waited for
+ * by the loop's vmcnt wait) */
+__device__ unsigned long long rcp_acc_dummy;
+#define RCP_STAMP(slot)                                          \
+  {                                                              \
+    unsigned long long now_ = __builtin_readcyclecounter();      \
+    pa[slot - 9] += now_ - tstamp;                               \
+    tstamp = now_;                                               \
+  }
+#define RCP_PROF_ARG , unsigned long long (&pa)[3]
+#define RCP_PROF_PASS , pa
+#else
+#define RCP_STAMP(slot)
+#define RCP_PROF_ARG
+#define RCP_PROF_PASS
+#endif
 template <int CS>
 __device__ __forceinline__ void rcp_conv3x3(f32x16 (&acc)[2][2], int &g, const Rc3Params &Q, const uint32_t *X, const uint32_t *Wb,
-                                            uint32_t lds_w_addr, int P0, int P1, int valid0, int valid1, int wave, int lane) {
+                                            uint32_t lds_w_addr, int P0, int P1, int valid0, int valid1, int wave, int lane RCP_PROF_ARG) {
+#ifdef CO_PROF
+  unsigned long long tstamp = __builtin_readcyclecounter();
+#endif
   constexpr int XT = CS == 1 ? 1 : 2;
 #pragma unroll
   for (int pi = 0; pi < 2; ++pi)
@@ -918,8 +939,11 @@ __device__ __forceinline__ void rcp_conv3x3(f32x16 (&acc)[2][2], int &g, const R
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[pi][to][i] = 0.0f;
   for (int tap = 0; tap < 9; ++tap, ++g) {
+    RCP_STAMP(11)
     CO_WAIT_VMCNT(0); /* this wave's pieces of item g have landed (requested one item ago) */
+    RCP_STAMP(9)
     co_wg_barrier();  /* ... every wave's; everyone has left the other buffer and, at tap 0, has written its activations */
+    RCP_STAMP(10)
     rcp_stage(Q, lds_w_addr, g + 1, wave, lane);
     const bool v0 = (valid0 >> tap) & 1, v1 = (valid1 >> tap) & 1;
     if (!v0 && !v1) continue;
@@ -994,14 +1018,18 @@ __device__ __forceinline__ void rcp_conv3x3(f32x16 (&acc)[2][2], int &g, const R
 #endif
     }
   }
+  RCP_STAMP(11)
 }
 
 /* conv bias -> BatchNorm affine (-> + skip) -> ReLU (rc3_epilogue's expressions), then the two fp16 terms of the result
- * go to LDS as the B fragments of the next convolution.  KEEP: the fp32 result replaces `x` (the skip of the block). */
+ * go to LDS as the B fragments of the next convolution.  KEEP: the fp32 result replaces `x` (the skip of the block).
+ * Everything that does not touch LDS -- the constants' loads, the arithmetic, the split -- runs BEFORE the barrier that
+ * waits for the other waves to finish reading the old activations: a wave that is done with its taps works on its
+ * epilogue while the slower SIMDs still multiply, and only the sixteen stores per pixel stand behind the barrier. */
 template <bool ADD_SKIP, bool KEEP>
 __device__ __forceinline__ void rcp_epilogue(float (&x)[2][2][16], const f32x16 (&acc)[2][2], const float *epi, uint32_t *X, int P0, int P1,
                                              int h, int lane, float &amax) {
-  co_wg_barrier(); /* every wave has read the activations this convolution consumed: they may be overwritten */
+  u32x4 hi[2][2][2], lo[2][2][2]; /* [pixel][tile][half of the tile's registers] */
 #pragma unroll
   for (int T = 0; T < 2; ++T) {
     float out[2][16];
@@ -1028,28 +1056,36 @@ __device__ __forceinline__ void rcp_epilogue(float (&x)[2][2][16], const f32x16 
     }
 #pragma unroll
     for (int pi = 0; pi < 2; ++pi) {
-      const int p = pi ? P1 : P0;
 #pragma unroll
       for (int a2 = 0; a2 < 2; ++a2) {
-        u32x4 hi, lo;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
           const float u0 = out[pi][8 * a2 + 2 * m], u1 = out[pi][8 * a2 + 2 * m + 1];
           amax = __builtin_fmaxf(amax, __builtin_fmaxf(u0, u1));
           uint32_t t[2];
           rcs_split<2, true>(u0, u1, t);
-          hi[m] = t[0];
-          lo[m] = t[1];
+          hi[pi][T][a2][m] = t[0];
+          lo[pi][T][a2][m] = t[1];
         }
-        const int sidx = 2 * T + a2;
-        *reinterpret_cast<u32x4 *>(X + ((p * 4 + sidx) * 2 + 0) * 256 + lane * 4) = hi;
-        *reinterpret_cast<u32x4 *>(X + ((p * 4 + sidx) * 2 + 1) * 256 + lane * 4) = lo;
       }
       if (KEEP) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) x[pi][T][i] = out[pi][i];
       }
     }
+  }
+  co_wg_barrier(); /* every wave has read the activations this convolution consumed: they may be overwritten */
+#pragma unroll
+  for (int pi = 0; pi < 2; ++pi) {
+    const int p = pi ? P1 : P0;
+#pragma unroll
+    for (int T = 0; T < 2; ++T)
+#pragma unroll
+      for (int a2 = 0; a2 < 2; ++a2) {
+        const int sidx = 2 * T + a2;
+        *reinterpret_cast<u32x4 *>(X + ((p * 4 + sidx) * 2 + 0) * 256 + lane * 4) = hi[pi][T][a2];
+        *reinterpret_cast<u32x4 *>(X + ((p * 4 + sidx) * 2 + 1) * 256 + lane * 4) = lo[pi][T][a2];
+      }
   }
 }
 
@@ -1062,6 +1098,19 @@ __global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_h3p(Rc3Params Q) {
   if (row0 >= rows) return;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, h = lane >> 5, n = lane & 31;
+#ifdef CO_PROF
+  unsigned long long stamp_ = __builtin_readcyclecounter();
+  const unsigned long long start_ = stamp_, real_ = __builtin_amdgcn_s_memrealtime();
+  unsigned long long pa[3] = {0ull, 0ull, 0ull}, ph[6] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+#define RCP_PHASE(slot)                                      \
+  {                                                          \
+    unsigned long long now_ = __builtin_readcyclecounter();  \
+    ph[slot] += now_ - stamp_;                               \
+    stamp_ = now_;                                           \
+  }
+#else
+#define RCP_PHASE(slot)
+#endif
   uint32_t *X = lds_dyn;
   const uint32_t *Wb = lds_dyn + RCP_X_WORDS;
   const uint32_t lds_w_addr = co_lds_addr(lds_dyn) + RCP_X_WORDS * 4u;
@@ -1126,13 +1175,20 @@ __global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_h3p(Rc3Params Q) {
       for (int i = 0; i < 16; ++i) x[pi][T][i] = 0.0f;
   const float *epi = P.epi; /* (global: the 160 KB of LDS hold activations and weights) */
   int g = 0;
-  rcp_conv3x3<1>(acc, g, Q, X, Wb, lds_w_addr, P0, P1, valid0, valid1, wave, lane);
+  RCP_PHASE(0)
+  rcp_conv3x3<1>(acc, g, Q, X, Wb, lds_w_addr, P0, P1, valid0, valid1, wave, lane RCP_PROF_PASS);
+  RCP_PHASE(1)
   rcp_epilogue<false, true>(x, acc, epi, X, P0, P1, h, lane, amax);
+  RCP_PHASE(2)
   for (int b = 0; b < 4; ++b) {
-    rcp_conv3x3<4>(acc, g, Q, X, Wb, lds_w_addr, P0, P1, valid0, valid1, wave, lane);
+    rcp_conv3x3<4>(acc, g, Q, X, Wb, lds_w_addr, P0, P1, valid0, valid1, wave, lane RCP_PROF_PASS);
+    RCP_PHASE(3)
     rcp_epilogue<false, false>(x, acc, epi + (1 + 2 * b) * 192, X, P0, P1, h, lane, amax);
-    rcp_conv3x3<4>(acc, g, Q, X, Wb, lds_w_addr, P0, P1, valid0, valid1, wave, lane);
+    RCP_PHASE(2)
+    rcp_conv3x3<4>(acc, g, Q, X, Wb, lds_w_addr, P0, P1, valid0, valid1, wave, lane RCP_PROF_PASS);
+    RCP_PHASE(3)
     rcp_epilogue<true, true>(x, acc, epi + (2 + 2 * b) * 192, X, P0, P1, h, lane, amax);
+    RCP_PHASE(2)
   }
   if (!(amax <= CO_F16_MAX)) atomicOr(Q.range_flag, 1u); /* (never in range: no lane enters) */
   /* heads: item 81 = the 1x1 convolutions' fragments (rows 0..3 policy planes, 4..5 value planes), in buffer 1; the head
@@ -1179,8 +1235,21 @@ __global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_h3p(Rc3Params Q) {
     __syncthreads();
     /* 32 positions = two column tiles: waves 0, 1 their policy heads, waves 2, 3 their value heads; the dense weights
      * straight from global memory (fp32, MFMA order, shared by every workgroup: L2) */
+    RCP_PHASE(4)
     if (wave < 2) rc_dense_policy(P, P.wpol, feat + wave * 16 * 96, rows, row0 + wave * 16, lane, 16);
     else if (wave < 4) rc_dense_value(P, P.wv1, P.wv2, feat + (wave - 2) * 16 * 96, rows, row0 + (wave - 2) * 16, lane, 16);
+    RCP_PHASE(5)
+#ifdef CO_PROF
+    if (tid == 0) {
+      atomicAdd(&rc3_prof[6], __builtin_readcyclecounter() - start_);
+      atomicAdd(&rc3_prof[7], 1ull);
+      atomicAdd(&rc3_prof[8], __builtin_amdgcn_s_memrealtime() - real_);
+      for (int i = 0; i < 6; ++i) atomicAdd(&rc3_prof[i], ph[i]);
+      atomicAdd(&rc3_prof[9], pa[0]);
+      atomicAdd(&rc3_prof[10], pa[1]);
+      atomicAdd(&rc3_prof[11], pa[2]);
+    }
+#endif
   }
 }
 

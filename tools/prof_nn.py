@@ -28,7 +28,7 @@ st = np.zeros((rows, 70), np.float32)
 st[:, :64] = rng.integers(0, 2, (rows, 64))
 st[:, 64:] = rng.integers(0, 5, (rows, 6)) * 0.25
 ms = t.net_bench(st, reps=int(os.environ.get("NN_REPS", "20")))
-p = (C.c_ulonglong * 9)()
+p = (C.c_ulonglong * 12)()
 L.ca_net_prof.argtypes = [C.POINTER(C.c_ulonglong)]
 assert L.ca_net_prof(p) == 0
 v = [int(x) for x in p]
@@ -38,3 +38,6 @@ print("%s, %d rows: %.3f ms per launch; %d workgroup passes stamped" % (kind, ro
 for i, nm in enumerate(names):
     print("  %-24s %9.0f cycles  %5.1f%%" % (nm, v[i] / n, 100.0 * v[i] / max(v[6], 1)))
 print("  %-24s %9.0f cycles in %.1f us: in-kernel clock %.2f GHz" % ("whole workgroup", v[6] / n, v[8] / n / 100.0, v[6] / max(v[8], 1) * 0.1))
+if v[9] + v[10] + v[11]:
+    print("  pixel-major kernel, inside the convolutions: waited for the weight DMA %.0f, at the tap barrier %.0f, multiplied %.0f cycles"
+          % (v[9] / n, v[10] / n, v[11] / n))
