@@ -197,8 +197,9 @@ def measured_traffic(kernel, args, net, npools):
         with open(path) as f:
             k = json.load(f)["kernels"]
             t = k[kernel]["traffic_bytes_per_launch"]
-            if kernel + "_small" in k:  # the network launch queues both instances of the kernel; one of them works
-                t += k[kernel + "_small"]["traffic_bytes_per_launch"]
+            twin = "co_k_rescnn_forward_h3_small" if kernel == "co_k_rescnn_forward_h3p" else kernel + "_small"
+            if twin in k:  # the network launch queues both instances of the kernel; one of them works
+                t += k[twin]["traffic_bytes_per_launch"]
             return t
     except Exception:
         return None

@@ -53,7 +53,8 @@ for name, calls, total, avg, pct in db.execute("select name, total_calls, total_
     rows[kname(name)] = (calls, total, pct)
 # a network launch queues two instances of some kernels (the row count on the device picks the one that works, the other
 # returns at once): one row per pair = what bench.py times as one launch
-for main, twin in (("co_k_rescnn_forward_x3", "co_k_rescnn_forward_x3_small"), ("co_k_rescnn_forward_h3", "co_k_rescnn_forward_h3_small")):
+for main, twin in (("co_k_rescnn_forward_x3", "co_k_rescnn_forward_x3_small"), ("co_k_rescnn_forward_h3", "co_k_rescnn_forward_h3_small"),
+                   ("co_k_rescnn_forward_h3p", "co_k_rescnn_forward_h3_small")):
     if main in rows and twin in rows:
         calls, total, pct = rows[main][0], rows[main][1] + rows[twin][1], rows[main][2] + rows[twin][2]
         lines.append("| `%s` + `%s` (one network launch) | %d | %.1f | %.3f | %.2f |" % (main, twin.replace(main, ""), calls, total, total / max(calls, 1), pct))

@@ -3,6 +3,10 @@
 # usage: tools/profile_round.sh <tag> <bench.py arguments...>
 set -e
 tag=$1; shift
+# (a heartbeat: the GPU pool takes a command that writes nothing for seven minutes to be hung)
+(while sleep 60; do echo -n "."; done) &
+HB=$!
+trap "kill $HB 2>/dev/null" EXIT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 A="--steps 1 --warmup 0 --cpu-games 0 --no-variants --no-unshared --recycle-games 0 $*"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d /tmp/prof/prof_${tag}_stats -o stats -- python3 bench.py $A > gpurun_out/prof_${tag}_stats.log 2>&1
