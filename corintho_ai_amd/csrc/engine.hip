@@ -1115,6 +1115,11 @@ struct ca_trainer {
           q.c_inserted_est = 0;
           ++cache_clears;
         }
+        /* The network launch is sized by what the batch can hold: the games still running at the pool's last poll (they
+         * only become fewer) times the searches per evaluation.  In a generation's thin tail the throughput kernel is
+         * then not launched at all and the small-batch kernel's grid shrinks -- a launch whose workgroups all leave at
+         * once still costs their dispatch (for the pixel-major kernel: one 160 KB LDS allocation per 32 rows of capacity). */
+        const int cap_rows = (q.running < q.n ? (q.running > 0 ? q.running : 1) : q.n) * spe;
         rt_event_t *e = q.ev[parity];
         if (timed) rt_event_record(e[0], q.st);
         RT_LAUNCH(co_k_priors, ((q.n) * pp.searches_per_eval + CO_WAVES_PER_BLOCK - 1) / CO_WAVES_PER_BLOCK, CO_WAVE * CO_WAVES_PER_BLOCK, q.st, pp);
@@ -1130,13 +1135,13 @@ struct ca_trainer {
           io.out_idx = q.c_out_idx;
           io.eval_stride = CO_CACHE_VAL_FLOATS;
           io.probs_stride = CO_CACHE_VAL_FLOATS;
-          nets[0]->forward(nn_in.p + (size_t)q.row_base * CO_STATE_STRIDE, q.n * spe,
+          nets[0]->forward(nn_in.p + (size_t)q.row_base * CO_STATE_STRIDE, cap_rows,
                            (const int32_t *)(q.c_count + 4 * (trainer_iteration & 1)), q.c_val, q.c_val + 4, q.st, io);
           if (timed) rt_event_record(e[3], q.st);
         } else {
           if (timed) rt_event_record(e[2], q.st);
           const int32_t *d_rows = (const int32_t *)(pack_counter.p + 2 * p + (trainer_iteration & 1));
-          nets[0]->forward(nn_in.p + (size_t)q.row_base * CO_STATE_STRIDE, q.n * spe, d_rows, nn_eval.p + q.row_base,
+          nets[0]->forward(nn_in.p + (size_t)q.row_base * CO_STATE_STRIDE, cap_rows, d_rows, nn_eval.p + q.row_base,
                            nn_probs.p + (size_t)q.row_base * CO_NUM_MOVES, q.st);
           if (timed) rt_event_record(e[3], q.st);
         }
