@@ -1135,14 +1135,17 @@ struct ca_trainer {
           io.out_idx = q.c_out_idx;
           io.eval_stride = CO_CACHE_VAL_FLOATS;
           io.probs_stride = CO_CACHE_VAL_FLOATS;
+          io.alone = npools == 1;
           nets[0]->forward(nn_in.p + (size_t)q.row_base * CO_STATE_STRIDE, cap_rows,
                            (const int32_t *)(q.c_count + 4 * (trainer_iteration & 1)), q.c_val, q.c_val + 4, q.st, io);
           if (timed) rt_event_record(e[3], q.st);
         } else {
           if (timed) rt_event_record(e[2], q.st);
           const int32_t *d_rows = (const int32_t *)(pack_counter.p + 2 * p + (trainer_iteration & 1));
+          CoNetIO io;
+          io.alone = npools == 1;
           nets[0]->forward(nn_in.p + (size_t)q.row_base * CO_STATE_STRIDE, cap_rows, d_rows, nn_eval.p + q.row_base,
-                           nn_probs.p + (size_t)q.row_base * CO_NUM_MOVES, q.st);
+                           nn_probs.p + (size_t)q.row_base * CO_NUM_MOVES, q.st, io);
           if (timed) rt_event_record(e[3], q.st);
         }
         if (timed) q.timed[parity] = 1;

@@ -46,6 +46,10 @@ struct CoNetIO {
   const int32_t *out_idx = nullptr;
   int32_t eval_stride = 1;
   int32_t probs_stride = CO_NET_NUM_MOVES;
+  /* Does this launch have the GPU to itself?  False when other streams keep it busy too (fused training in several pools:
+   * the other pools' search and network kernels): a kernel family may then choose for throughput per CU rather than for
+   * the latency of this launch (nn_rescnn.hip rcp_small_begin). */
+  int32_t alone = 1;
 };
 
 struct CoNet {

@@ -423,7 +423,25 @@ struct Rc3Params {
                            * then the fp32 dense weights wpol, wv1, wv2 as in RcParams */
   const uint32_t *epi3;   /* RC3_EPI_WORDS: RcParams::epi, padded */
   uint32_t *range_flag;   /* f16x3: raised when an activation beyond fp16's range was split (nn.h range_exceeded) */
+  int32_t pass_rows;      /* f16x3 with the pixel-major kernel: rows of one pass of that kernel over the chip (32 per CU);
+                           * 0 = batches are not split between the kernels (rcp_small_begin) */
 };
+
+/* Which rows of a batch does the small-batch kernel take?  Without the pixel-major kernel: all of a batch of up to
+ * RC3_SMALL_ROWS rows, none of a larger one.  With it the batch is SPLIT on the device: the pixel-major kernel runs one
+ * workgroup of 32 rows per CU and a pass costs its full time however few of its workgroups have rows, so it takes the
+ * whole passes of the batch, plus a remainder of more than RC3_SMALL_ROWS rows; a smaller remainder -- half of all
+ * batches -- goes to the small-batch kernel (16 rows per workgroup; 8 on its thin path), which is through in a third to two
+ * thirds of a pass.  A row's result does not depend on the kernel that evaluates it.  -> the small kernel's first row
+ * (Only for a launch that has the GPU to itself, CoNetIO::alone: measured in round 4, 10 000 / 12 288 / 20 000 rows alone
+ * 0.185 / 0.217 / 0.345 ms against 0.27 / 0.26 / 0.40 unsplit -- but beside the other pool's kernels, where CUs and not
+ * latency are scarce, the pixel-major kernel's 32 rows per 160 us of a CU beat the small kernel's 16 per 110: a
+ * two-pool generation 438.7 ms split against 434.0 unsplit.) */
+__device__ __forceinline__ int rcp_small_begin(const Rc3Params &Q, int rows) {
+  if (Q.pass_rows <= 0) return rows <= RC3_SMALL_ROWS ? 0 : rows;
+  const int full = rows / Q.pass_rows * Q.pass_rows;
+  return rows - full > RC3_SMALL_ROWS ? rows : full;
+}
 
 template <int NT>
 __device__ __forceinline__ const uint32_t *rcs_group_ptr(const uint32_t *wtrunk, int gi) {
@@ -687,16 +705,16 @@ extern "C" int ca_net_prof(unsigned long long out[12]) {
 
 /* NW = waves per workgroup: 8 (two per SIMD), or 4 in the thin-batch kernel of NT = 3 (below) */
 template <int NP, int NT, int NW = 8, bool F16 = false>
-__device__ __forceinline__ void rcs_forward(const Rc3Params &Q) {
+__device__ __forceinline__ void rcs_forward(const Rc3Params &Q, const int rbase = 0) {
   const RcParams &P = Q.base;
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
   uint32_t *lds_w = lds_dyn;
   /* NT = 3: the features reuse the buffer of the last group (RC3_NUM_GROUPS - 1 = 26 -> buffer 0), free behind
    * the barrier in front of the heads */
   float *lds_feat = reinterpret_cast<float *>(NT == 2 ? lds_dyn + 2 * RCS_GROUP_WORDS(NT) : lds_dyn);
-  const int rows = *P.d_rows;
-  if (NT == 2 && (rows <= RC3_SMALL_ROWS) != (NP == 1)) return; /* the other kernel takes this batch */
-  const int row0 = blockIdx.x * (2 * NP * NW);
+  const int rows = *P.d_rows; /* this launch works on rows rbase .. rows - 1 */
+  if (NT == 2 && (rows - rbase <= RC3_SMALL_ROWS) != (NP == 1)) return; /* the other kernel takes this batch */
+  const int row0 = rbase + blockIdx.x * (2 * NP * NW);
   if (row0 >= rows) return;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, h = lane >> 5, p2 = (lane >> 4) & 1, c = lane & 15;
@@ -865,11 +883,13 @@ __global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_x6(Rc3Params Q) {
  * SIMD, 8 positions per workgroup, waves 4..7 leave at once; see co_k_rescnn_forward_x6). */
 __global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_h3(Rc3Params Q) { rcs_forward<2, 2, 8, true>(Q); }
 __global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_h3_small(Rc3Params Q) {
-  if (*Q.base.d_rows <= RC6_THIN_ROWS) {
+  const int rows = *Q.base.d_rows, rbase = rcp_small_begin(Q, rows);
+  if (rows - rbase <= 0) return; /* the whole batch is the throughput kernel's */
+  if (rows - rbase <= RC6_THIN_ROWS) {
     if (threadIdx.x >= 256) return;
-    rcs_forward<1, 2, 4, true>(Q);
+    rcs_forward<1, 2, 4, true>(Q, rbase);
   } else {
-    rcs_forward<1, 2, 8, true>(Q);
+    rcs_forward<1, 2, 8, true>(Q, rbase);
   }
 }
 #define RCH_LDS_WORDS(NP) RCS_LDS_WORDS(2, NP)
@@ -957,38 +977,6 @@ __device__ __forceinline__ void rcp_conv3x3(f32x16 (&acc)[2][2], int &g, const R
       for (int to = 0; to < 2; ++to)
 #pragma unroll
         for (int t = 0; t < 2; ++t) a[t][to] = *reinterpret_cast<const u32x4 *>(wb + ((s * 2 + to) * 2 + t) * 256);
-#ifdef CO_RCP_BOTH_LOADS
-      /* both pixels' activation fragments are requested before either pixel's MFMAs issue */
-      u32x4 bq[2][XT];
-      if (v0) {
-#pragma unroll
-        for (int t = 0; t < XT; ++t) bq[0][t] = *reinterpret_cast<const u32x4 *>(x0 + (s * 2 + t) * 256);
-      }
-      if (v1) {
-#pragma unroll
-        for (int t = 0; t < XT; ++t) bq[1][t] = *reinterpret_cast<const u32x4 *>(x1 + (s * 2 + t) * 256);
-      }
-      if (v0) {
-#pragma unroll
-        for (int sum = 0; sum < 2; ++sum)
-#pragma unroll
-          for (int i = 0; i <= sum; ++i)
-            if (sum - i < XT) {
-#pragma unroll
-              for (int to = 0; to < 2; ++to) acc[0][to] = rcs_mfma<true>(a[i][to], bq[0][sum - i], acc[0][to]);
-            }
-      }
-      if (v1) {
-#pragma unroll
-        for (int sum = 0; sum < 2; ++sum)
-#pragma unroll
-          for (int i = 0; i <= sum; ++i)
-            if (sum - i < XT) {
-#pragma unroll
-              for (int to = 0; to < 2; ++to) acc[1][to] = rcs_mfma<true>(a[i][to], bq[1][sum - i], acc[1][to]);
-            }
-      }
-#else
       if (v0) {
         u32x4 b[XT];
 #pragma unroll
@@ -1015,7 +1003,6 @@ __device__ __forceinline__ void rcp_conv3x3(f32x16 (&acc)[2][2], int &g, const R
               for (int to = 0; to < 2; ++to) acc[1][to] = rcs_mfma<true>(a[i][to], b[sum - i], acc[1][to]);
             }
       }
-#endif
     }
   }
   RCP_STAMP(11)
@@ -1093,9 +1080,8 @@ __global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_h3p(Rc3Params Q) {
   const RcParams &P = Q.base;
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
   const int rows = *P.d_rows;
-  if (rows <= RC3_SMALL_ROWS) return; /* the small-batch kernel takes this batch */
   const int row0 = blockIdx.x * 32;
-  if (row0 >= rows) return;
+  if (row0 >= rcp_small_begin(Q, rows)) return; /* beyond the batch, or in the share of the small-batch kernel */
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, h = lane >> 5, n = lane & 31;
 #ifdef CO_PROF
@@ -1115,10 +1101,6 @@ __global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_h3p(Rc3Params Q) {
   const uint32_t *Wb = lds_dyn + RCP_X_WORDS;
   const uint32_t lds_w_addr = co_lds_addr(lds_dyn) + RCP_X_WORDS * 4u;
   /* this wave's two output pixels and their taps on the board */
-#ifdef CO_RCP_OLD_PIXELS
-  const int P0 = wave < 4 ? (wave == 0 ? 5 : wave == 1 ? 6 : wave == 2 ? 9 : 10) : (wave == 4 ? 1 : wave == 5 ? 4 : wave == 6 ? 7 : 13);
-  const int P1 = wave < 4 ? (wave == 0 ? 0 : wave == 1 ? 3 : wave == 2 ? 12 : 15) : (wave == 4 ? 2 : wave == 5 ? 8 : wave == 6 ? 11 : 14);
-#else
   /* Waves w and w + 4 share a SIMD (a workgroup's waves go round the four SIMDs), and every tap ends at a barrier: what
    * a tap costs is the SIMD with the most (pixel, tap) pairs on the board at THAT tap.  The four pixels of a SIMD are
    * chosen so that every tap is spread evenly -- {0, 5, 6, 15}, {1, 4, 7, 13}, {2, 8, 11, 14}, {3, 9, 10, 12}: at most
@@ -1127,7 +1109,6 @@ __global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_h3p(Rc3Params Q) {
    * wave: 34; the (position, pixel)-column kernel multiplies all 36). */
   const int P0 = wave == 0 ? 5 : wave == 1 ? 1 : wave == 2 ? 2 : wave == 3 ? 9 : wave == 4 ? 6 : wave == 5 ? 4 : wave == 6 ? 8 : 10;
   const int P1 = wave == 0 ? 15 : wave == 1 ? 13 : wave == 2 ? 14 : wave == 3 ? 12 : wave == 4 ? 0 : wave == 5 ? 7 : wave == 6 ? 11 : 3;
-#endif
   int valid0 = 0, valid1 = 0;
   for (int tap = 0; tap < 9; ++tap) {
     const int dy = tap / 3 - 1, dx = tap % 3 - 1;
@@ -1404,6 +1385,7 @@ struct ResCnnSplitNet : ResCnnNet {
   int nt;
   bool f16;
   bool pixmajor = false; /* f16: batches beyond RC3_SMALL_ROWS on the pixel-major kernel (K6p) */
+  int num_cus = 256;     /* (a pass of that kernel = one workgroup per CU) */
   uint32_t *d_trunk3 = nullptr;
   uint32_t *d_whead3 = nullptr;
   uint32_t *d_epi3 = nullptr;
@@ -1482,6 +1464,10 @@ struct ResCnnSplitNet : ResCnnNet {
       {
         const char *e = getenv("CORINTHO_RESCNN_PIXMAJOR"); /* diagnostic: 0 = the (position, pixel)-column kernel for every batch size */
         pixmajor = f16 && (e ? e[0] != '0' : CO_RESCNN_PIXMAJOR_DEFAULT != 0);
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+          num_cus = prop.multiProcessorCount;
       }
       RT_CHECK(hipFuncSetAttribute((const void *)co_k_rescnn_forward_h3_small, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    RCH_LDS_WORDS(1) * 4));
@@ -1520,6 +1506,7 @@ struct ResCnnSplitNet : ResCnnNet {
     q.whead3 = d_whead3;
     q.epi3 = d_epi3;
     q.range_flag = d_range;
+    q.pass_rows = pixmajor && io.alone ? 32 * num_cus : 0;
     if (nt == 2) {
       /* both kernels are queued; the row count on the device decides which one works (the other's
        * workgroups return at once).  Batches that can exceed RC3_SMALL_ROWS need the throughput kernel. */

@@ -151,7 +151,6 @@ extern thread_local int co_emu_block_idx;
  * (As v_mov_dpp + v_cmp + v_cndmask per step, then four v_readlane and scalar selects, the reduction was ~30 dependent
  * instructions in the middle of every PUCT scan.)  The s_nop 1 in front of each step are the two wait states a DPP read
  * needs behind the VALU write of its source, which the assembler does not insert. */
-#ifndef CO_WAVE_MAX_PLAIN
 __device__ __forceinline__ float co_wave_max_f32(float v) {
   float r;
   asm("s_nop 1\n\t"
@@ -170,20 +169,6 @@ __device__ __forceinline__ float co_wave_max_f32(float v) {
       : "v"(v));
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r), 63));
 }
-#else
-__device__ __forceinline__ float co_fmaxsel(float a, float b) { return b > a ? b : a; }
-__device__ __forceinline__ float co_wave_max_f32(float v) {
-  v = co_fmaxsel(v, CO_DPP_F(v, CO_DPP_XOR1));
-  v = co_fmaxsel(v, CO_DPP_F(v, CO_DPP_XOR2));
-  v = co_fmaxsel(v, CO_DPP_F(v, CO_DPP_HALF_MIRROR));
-  v = co_fmaxsel(v, CO_DPP_F(v, CO_DPP_MIRROR));
-  float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
-  float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
-  float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
-  float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
-  return co_fmaxsel(co_fmaxsel(r0, r1), co_fmaxsel(r2, r3));
-}
-#endif
 __device__ __forceinline__ int co_wave_sum_i32(int v) {
   v += CO_DPP_I(v, CO_DPP_XOR1);
   v += CO_DPP_I(v, CO_DPP_XOR2);

@@ -28,7 +28,7 @@ for pm in ("0", "1"):
     t.set_net(NET_RESCNN4_H3, w)
     ev, pr = t.net_forward(st[:20000])
     out[pm] = (ev, pr)
-    for rows in (8192, 12288, 16384, 32768, 65536):
+    for rows in (8192, 10000, 12288, 14000, 16384, 20000, 32768, 65536):
         for _ in range(2):
             ms = t.net_bench(st[:rows], reps=200)
         print("pixel-major %s: %6d rows %.4f ms" % (pm, rows, ms), flush=True)
