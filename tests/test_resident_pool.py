@@ -237,3 +237,36 @@ def test_eval_cache_argument_is_explicit():
     for bad in (0, 1, 5, 31, "on", 2.5):
         with pytest.raises(ValueError):
             _eval_cache_cfg(bad)
+
+
+@pytest.mark.gpu
+def test_a_network_that_toggles_the_evaluation_cache_is_refused_in_mid_generation():
+    """automatic cache: off for the 0.25 MFLOP MLP, on for the residual CNN.  Replacing one by the other between two capped
+    runs would free (or create) the tables the pending leaves point into: refused, and the generation goes on as it was"""
+    from corintho_ai_amd import NET_MLP12X100_H3, NET_RESCNN4_H3
+
+    G, S_, spe = 64, 40, 8
+    t = make_trainer("hip", G, "", 5, S_, spe, 1.0, 0.25, 0, 1, False, stagger=False)
+    t.set_net(NET_MLP12X100_H3, nets.init_mlp12x100(0))
+    assert not t.run(max_iterations=10)
+    with pytest.raises(RuntimeError, match="evaluation cache"):
+        t.set_net(NET_RESCNN4_H3, nets.init_rescnn4(0))
+    assert t.run()  # ... with the network it had
+    ref = make_trainer("hip", G, "", 5, S_, spe, 1.0, 0.25, 0, 1, False, stagger=False)
+    ref.set_net(NET_MLP12X100_H3, nets.init_mlp12x100(0))
+    assert ref.run()
+    assert _digest(t, G) == _digest(ref, G)
+    # between generations the change is allowed
+    t.reset(6)
+    t.set_net(NET_RESCNN4_H3, nets.init_rescnn4(0))
+    assert t.run() and 0 < t.stats()["nn_rows_evaluated"] < t.stats()["nn_rows"]
+
+
+@pytest.mark.parametrize("engine", ENGINES)
+def test_more_logged_games_than_resident_slots_is_an_error(engine, tmp_path):
+    """a logged game must start in its own slot: asking for more log files than the pool has slots would write fewer
+    files than the reference does -- refused instead of clamped"""
+    with pytest.raises(RuntimeError, match="resident"):
+        make_trainer(engine, 12, str(tmp_path), 3, 30, 8, 1.0, 0.25, 6, 1, False, stagger=False, resident=4)
+    t = make_trainer(engine, 12, str(tmp_path), 3, 30, 8, 1.0, 0.25, 4, 1, False, stagger=False, resident=4)  # 4 on 4: fine
+    t.close()
