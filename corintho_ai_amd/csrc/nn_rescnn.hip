@@ -699,6 +699,12 @@ __device__ unsigned long long rc3_prof[12]; /* 0..5 phases, 6 whole pass, 7 pass
 extern "C" int ca_net_prof(unsigned long long out[12]) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(rc3_prof), sizeof(rc3_prof)) == hipSuccess ? 0 : 1;
 }
+/* K6p: the core-clock stamps of workgroup 0's eight waves at the nine tap barriers of ONE trunk convolution (the fifth
+ * convolution of the kernel): [wave][tap][arrived, left], [wave][18] = the convolution's end (tools/prof_nn.py with NN_TRACE=1) */
+__device__ unsigned rc3_trace[8 * 20];
+extern "C" int ca_net_trace(unsigned out[160]) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(rc3_trace), sizeof(rc3_trace)) == hipSuccess ? 0 : 1;
+}
 #else
 #define RC3_STAMP(slot)
 #endif
@@ -938,12 +944,17 @@ __device__ unsigned long long rcp_acc_dummy;
     pa[slot - 9] += now_ - tstamp;                               \
     tstamp = now_;                                               \
   }
-#define RCP_PROF_ARG , unsigned long long (&pa)[3]
-#define RCP_PROF_PASS , pa
+#define RCP_TRACE(i) \
+  if (trace_on) tr[i] = (unsigned)__builtin_readcyclecounter();
+#define RCP_PROF_ARG , unsigned long long (&pa)[3], unsigned (&tr)[20], bool trace_on
+#define RCP_PROF_PASS , pa, tr, false
+#define RCP_PROF_PASS_TRACED , pa, tr, b == 1
 #else
 #define RCP_STAMP(slot)
+#define RCP_TRACE(i)
 #define RCP_PROF_ARG
 #define RCP_PROF_PASS
+#define RCP_PROF_PASS_TRACED
 #endif
 template <int CS>
 __device__ __forceinline__ void rcp_conv3x3(f32x16 (&acc)[2][2], int &g, const Rc3Params &Q, const uint32_t *X, const uint32_t *Wb,
@@ -960,11 +971,13 @@ __device__ __forceinline__ void rcp_conv3x3(f32x16 (&acc)[2][2], int &g, const R
       for (int i = 0; i < 16; ++i) acc[pi][to][i] = 0.0f;
   for (int tap = 0; tap < 9; ++tap, ++g) {
     RCP_STAMP(11)
+    RCP_TRACE(2 * tap)
     CO_WAIT_VMCNT(0); /* this wave's pieces of item g have landed (requested one item ago) */
     RCP_STAMP(9)
     co_wg_barrier();  /* ... every wave's; everyone has left the other buffer and, at tap 0, has written its activations */
     RCP_STAMP(10)
-    rcp_stage(Q, lds_w_addr, g + 1, wave, lane);
+    RCP_TRACE(2 * tap + 1)
+    rcp_stage(Q, lds_w_addr, g + 1, wave, lane); /* (behind the first K step's MFMAs instead: 10 % slower, measured) */
     const bool v0 = (valid0 >> tap) & 1, v1 = (valid1 >> tap) & 1;
     if (!v0 && !v1) continue;
     const uint32_t *wb = Wb + (g & 1) * RCP_TAP_WORDS + lane * 4;
@@ -1006,6 +1019,7 @@ __device__ __forceinline__ void rcp_conv3x3(f32x16 (&acc)[2][2], int &g, const R
     }
   }
   RCP_STAMP(11)
+  RCP_TRACE(18)
 }
 
 /* conv bias -> BatchNorm affine (-> + skip) -> ReLU (rc3_epilogue's expressions), then the two fp16 terms of the result
@@ -1088,6 +1102,7 @@ __global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_h3p(Rc3Params Q) {
   unsigned long long stamp_ = __builtin_readcyclecounter();
   const unsigned long long start_ = stamp_, real_ = __builtin_amdgcn_s_memrealtime();
   unsigned long long pa[3] = {0ull, 0ull, 0ull}, ph[6] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+  unsigned tr[20] = {};
 #define RCP_PHASE(slot)                                      \
   {                                                          \
     unsigned long long now_ = __builtin_readcyclecounter();  \
@@ -1166,7 +1181,7 @@ __global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_h3p(Rc3Params Q) {
     RCP_PHASE(3)
     rcp_epilogue<false, false>(x, acc, epi + (1 + 2 * b) * 192, X, P0, P1, h, lane, amax);
     RCP_PHASE(2)
-    rcp_conv3x3<4>(acc, g, Q, X, Wb, lds_w_addr, P0, P1, valid0, valid1, wave, lane RCP_PROF_PASS);
+    rcp_conv3x3<4>(acc, g, Q, X, Wb, lds_w_addr, P0, P1, valid0, valid1, wave, lane RCP_PROF_PASS_TRACED);
     RCP_PHASE(3)
     rcp_epilogue<true, true>(x, acc, epi + (2 + 2 * b) * 192, X, P0, P1, h, lane, amax);
     RCP_PHASE(2)
@@ -1230,6 +1245,8 @@ __global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_h3p(Rc3Params Q) {
       atomicAdd(&rc3_prof[10], pa[1]);
       atomicAdd(&rc3_prof[11], pa[2]);
     }
+    if (blockIdx.x == 0 && lane == 0)
+      for (int i = 0; i < 20; ++i) rc3_trace[wave * 20 + i] = tr[i];
 #endif
   }
 }

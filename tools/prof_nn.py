@@ -41,3 +41,16 @@ print("  %-24s %9.0f cycles in %.1f us: in-kernel clock %.2f GHz" % ("whole work
 if v[9] + v[10] + v[11]:
     print("  pixel-major kernel, inside the convolutions: waited for the weight DMA %.0f, at the tap barrier %.0f, multiplied %.0f cycles"
           % (v[9] / n, v[10] / n, v[11] / n))
+if os.environ.get("NN_TRACE"):
+    tr = (C.c_uint * 160)()
+    L.ca_net_trace.argtypes = [C.POINTER(C.c_uint)]
+    assert L.ca_net_trace(tr) == 0
+    T = np.array(list(tr), dtype=np.int64).reshape(8, 20)
+    t0 = T[:, 0].min()
+    print("  workgroup 0, one trunk convolution: core cycles since the first wave reached tap 0's barrier")
+    print("  tap   " + "".join("   wave %d: arrived, left " % w for w in range(8)))
+    for tap in range(9):
+        print("  %d     " % tap + "".join("   %9d %9d     " % ((T[w, 2 * tap] - t0) & 0xFFFFFFFF, (T[w, 2 * tap + 1] - t0) & 0xFFFFFFFF) for w in range(8)))
+    print("  end   " + "".join("   %9d               " % ((T[w, 18] - t0) & 0xFFFFFFFF) for w in range(8)))
+    last = [(int(np.argmax([(T[w, 2 * tap] - t0) & 0xFFFFFFFF for w in range(8)]))) for tap in range(9)]
+    print("  the wave that arrived last at each tap's barrier:", last)
