@@ -109,6 +109,30 @@ def test_bf16x6_rows_do_not_depend_on_their_batch(kind, make):
         assert np.array_equal(e1, ev[lo:hi]) and np.array_equal(p1, pr[lo:hi]), (lo, hi)
 
 
+def test_a_batch_split_between_the_two_f16x3_kernels_is_the_same_rows():
+    """A batch that has the GPU to itself (CoNetIO::alone: net_forward, a one-pool trainer) is split on the device: the
+    pixel-major kernel takes its whole passes over the chip (32 rows per CU), the small-batch kernel a remainder of up to
+    4096 rows STARTING AT A ROW OFFSET (nn_rescnn.hip rcp_small_begin; its thin path below 2048 rows).  Every row must come
+    out as it does when its kernel has the batch to itself."""
+    pass_rows = 32 * 256  # an MI355X's 256 CUs (on a device with another count the assertions hold all the same, the split falls elsewhere)
+    t = make_trainer("hip", (2 * pass_rows + 4096) // 16 + 1, "", 1, 50, 16, 1.0, 0.25, 0, 1, False)
+    t.set_net(NET_RESCNN4_H3, nets.init_rescnn4(0, bn_noise=True))
+    states = _states(2 * pass_rows + 4096, 11)
+    # whole passes only, and a remainder too large for the small kernel: the pixel-major kernel alone
+    ev, pr = t.net_forward(states[:2 * pass_rows])
+    e1, p1 = t.net_forward(states[:pass_rows + 4097])
+    assert np.array_equal(e1, ev[:pass_rows + 4097]) and np.array_equal(p1, pr[:pass_rows + 4097])
+    ref_e = np.concatenate([ev, t.net_forward(states[2 * pass_rows:])[0]])  # (the tail: the small kernel from row 0)
+    ref_p = np.concatenate([pr, t.net_forward(states[2 * pass_rows:])[1]])
+    for n in (pass_rows + 1, pass_rows + 5, pass_rows + 16, pass_rows + 17, pass_rows + 1808, pass_rows + 2047, pass_rows + 2049,
+              pass_rows + 4096, 2 * pass_rows + 1, 2 * pass_rows + 333, 2 * pass_rows + 4096):
+        e1, p1 = t.net_forward(states[:n])
+        assert np.array_equal(e1, ref_e[:n]) and np.array_equal(p1, ref_p[:n]), n
+    # ... and shifted, so that the remainder's rows are other rows
+    e1, p1 = t.net_forward(states[77:77 + pass_rows + 1000])
+    assert np.array_equal(e1, ref_e[77:77 + pass_rows + 1000]) and np.array_equal(p1, ref_p[77:77 + pass_rows + 1000])
+
+
 @pytest.mark.parametrize("kind,make", [(NET_RESCNN4_X6, lambda: nets.init_rescnn4(0, bn_noise=True)),
                                        (NET_MLP12X100_X6, lambda: nets.init_mlp12x100(2, bn_noise=True)),
                                        (NET_RESCNN4_H3, lambda: nets.init_rescnn4(0, bn_noise=True)),
