@@ -161,7 +161,7 @@ def test_evaluation_cache_changes_nothing_but_the_rows_evaluated(engine):
     # 18: a table of 2^18 entries per pool (an explicit size switches the cache on for any network; automatic = only for
     # networks whose rows are expensive); 6: 64 entries -- full at once, emptied again and again
     for cache in (False, 18, 6):
-        for R, pools in ((-1, 1), (-1, 2), (7, 2)):
+        for R, pools in ((-1, 1), (-1, 2), (7, 2), (-1, 3)):
             t = make_trainer(engine, G, "", seed, S_, spe, 1.0, 0.25, 0, 1, False, stagger=False, trace=True, resident=R, pools=pools,
                              eval_cache=cache)
             t.set_net(1, nets.init_mlp12x100(seed=3, bn_noise=True))
