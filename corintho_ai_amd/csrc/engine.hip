@@ -103,14 +103,16 @@ struct Pool {
   int timed[2] = {0, 0};     /* the window's last iteration carries the events */
   unsigned long long *word = nullptr; /* pinned: [parity] counter word copied at the end of window parity 0 / 1, [2 + parity] rows the
                              * network evaluated in that iteration (evaluation cache) */
-  /* evaluation cache of the pool (EvalCache) */
+  /* the pool's view of the evaluation cache (EvalCache).  The table (c_hdr, c_val, c_done) is ONE for the trainer and
+   * belongs to pool 0 -- the other pools hold copies of the pointers, not buffers of their own */
   EvalCache cache = {};
-  uint32_t *c_hdr = nullptr, *c_count = nullptr;
+  uint32_t *c_hdr = nullptr, *c_count = nullptr, *c_done = nullptr;
   float *c_val = nullptr;
   int32_t *c_in_idx = nullptr, *c_out_idx = nullptr;
   unsigned long long *c_totals = nullptr;
   size_t c_entries = 0;
   double c_inserted_est = 0; /* entries taken since the table was last emptied (estimate: timed iteration x window) */
+  rt_event_t quiet = {};     /* emptying the shared table: the pool's stream has reached the iteration boundary */
 };
 
 struct ca_trainer {
@@ -194,8 +196,10 @@ struct ca_trainer {
         rt_event_destroy(q.polled[w]);
       }
       rt_host_free(q.word);
-      for (void *b : {(void *)q.c_hdr, (void *)q.c_count, (void *)q.c_val, (void *)q.c_in_idx,
-                      (void *)q.c_out_idx, (void *)q.c_totals})
+      rt_event_destroy(q.quiet);
+      const bool owner = &q == &pools[0]; /* the shared table is pool 0's */
+      for (void *b : {owner ? (void *)q.c_hdr : nullptr, (void *)q.c_count, owner ? (void *)q.c_val : nullptr, (void *)q.c_in_idx,
+                      (void *)q.c_out_idx, (void *)q.c_totals, owner ? (void *)q.c_done : nullptr})
         rt_free(b);
       rt_stream_destroy(q.st);
     }
@@ -992,30 +996,43 @@ struct ca_trainer {
         rt_host_alloc((void **)&q.word, 32);
         memset(q.word, 0, 32);
         memset(&q.cache, 0, sizeof q.cache);
+        rt_event_create(&q.quiet);
         if (use_cache()) {
-          /* table: a power of two of at least 8192 entries per slot (a 4096-game generation at 400 simulations asks
-           * for ~4100 distinct positions per game), within 1/12 of the free device memory per pool */
-          size_t want = (size_t)q.n * 8192, n = 1;
-          while (n < want) n <<= 1;
-          const size_t per = 16 + CO_CACHE_VAL_FLOATS * 4;
-          while (n > 1024 && n * per > rt_mem_free() / 12) n >>= 1;
-          if (cfg.eval_cache > 0) { /* given */
-            n = (size_t)1 << (cfg.eval_cache < 6 ? 6 : cfg.eval_cache > 30 ? 30 : cfg.eval_cache);
-            if (n * per > rt_mem_free() / 2)
-              throw EngineError(CA_ERR_ARG, "ca_config.eval_cache: a table of 2^" + std::to_string(cfg.eval_cache) +
-                                                " entries per pool does not fit in the free device memory");
+          if (p == 0) {
+            /* ONE table for all pools: a power of two of at least 8192 entries per slot (a 4096-game generation at 400
+             * simulations asks for ~4100 distinct positions per game), within 1/6 of the free device memory */
+            size_t want = (size_t)R * 8192, n = 1;
+            while (n < want) n <<= 1;
+            const size_t per = 16 + CO_CACHE_VAL_FLOATS * 4;
+            while (n > 1024 && n * per > rt_mem_free() / 6) n >>= 1;
+            if (cfg.eval_cache > 0) { /* given */
+              n = (size_t)1 << (cfg.eval_cache < 6 ? 6 : cfg.eval_cache > 30 ? 30 : cfg.eval_cache);
+              if (n * per > rt_mem_free() / 2)
+                throw EngineError(CA_ERR_ARG, "ca_config.eval_cache: a table of 2^" + std::to_string(cfg.eval_cache) +
+                                                  " entries does not fit in the free device memory");
+            }
+            q.c_entries = n;
+            rt_malloc((void **)&q.c_hdr, n * 16, q.st);
+            /* table values + one scratch element per request row of every pool */
+            rt_malloc((void **)&q.c_val, (n + (size_t)R * spe) * CO_CACHE_VAL_FLOATS * 4, q.st);
+            rt_malloc((void **)&q.c_done, 4 * CO_MAX_POOLS, q.st);
+          } else {
+            q.c_entries = pools[0].c_entries;
+            q.c_hdr = pools[0].c_hdr;
+            q.c_val = pools[0].c_val;
+            q.c_done = pools[0].c_done;
           }
-          q.c_entries = n;
           const size_t rows = (size_t)q.n * spe;
-          rt_malloc((void **)&q.c_hdr, n * 16, q.st);
-          rt_malloc((void **)&q.c_val, (n + rows) * CO_CACHE_VAL_FLOATS * 4, q.st); /* table values + one scratch element per row */
           rt_malloc((void **)&q.c_in_idx, rows * 4, q.st);
           rt_malloc((void **)&q.c_out_idx, rows * 4, q.st);
           rt_malloc((void **)&q.c_count, 32, q.st);
           rt_malloc((void **)&q.c_totals, 16, q.st);
           q.cache.hdr = q.c_hdr;
           q.cache.val = q.c_val;
-          q.cache.mask = (uint32_t)(n - 1);
+          q.cache.mask = (uint32_t)(q.c_entries - 1);
+          q.cache.scratch_base = (uint32_t)q.row_base;
+          q.cache.pool_bits = (uint32_t)p << CO_CACHE_POOL_SHIFT;
+          q.cache.done = q.c_done;
           q.cache.in_idx = q.c_in_idx;
           q.cache.out_idx = q.c_out_idx;
           q.cache.count = q.c_count;
@@ -1029,7 +1046,10 @@ struct ca_trainer {
     if (use_cache() && !cache_clean) {
       /* a generation starts with an empty table: nothing evaluated in an earlier generation is carried over */
       for (auto &q : pools) {
-        rt_memset(q.c_hdr, 0, q.c_entries * 16, q.st);
+        if (&q == &pools[0]) {
+          rt_memset(q.c_hdr, 0, q.c_entries * 16, q.st);
+          rt_memset(q.c_done, 0, 4 * CO_MAX_POOLS, q.st); /* (the iteration count starts again with the generation) */
+        }
         rt_memset(q.c_count, 0, 32, q.st);
         rt_memset(q.c_totals, 0, 16, q.st);
         rt_sync(q.st);
@@ -1088,8 +1108,32 @@ struct ca_trainer {
         q.idle = 0;
       }
     };
+    /* the table was emptied in mid-generation (a new network, set_net): pending leaves point into its old contents */
+    bool emptied_before_resuming = cache_clean_now && iterations > 0;
     while (!all_finished && (max_iterations <= 0 || it < max_iterations)) {
       const int parity = window & 1;
+      bool emptied = emptied_before_resuming; /* (EvalCache::no_claim) */
+      emptied_before_resuming = false;
+      if (pools[0].cache.hdr) {
+        double taken = 0;
+        for (auto &q : pools) taken += q.c_inserted_est;
+        if (taken > 0.5 * (double)pools[0].c_entries) {
+          /* the table is half full: start over (a long generation asks for far more positions than any table holds;
+           * what is asked for again is mostly recent -- the trees of the games in play).  Between two iterations of
+           * EVERY pool, when no entry is pending: each stream has the same iterations queued at this point; pool 0's
+           * stream waits for the others to get here, empties the table, and the others wait for that. */
+          for (int p = 1; p < npools; ++p) {
+            rt_event_record(pools[p].quiet, pools[p].st);
+            rt_stream_wait(pools[0].st, pools[p].quiet);
+          }
+          rt_memset(pools[0].c_hdr, 0, pools[0].c_entries * 16, pools[0].st);
+          rt_event_record(pools[0].quiet, pools[0].st);
+          for (int p = 1; p < npools; ++p) rt_stream_wait(pools[p].st, pools[0].quiet);
+          for (auto &q : pools) q.c_inserted_est = 0;
+          ++cache_clears;
+          emptied = true;
+        }
+      }
       for (int p = 0; p < npools; ++p) {
         Pool &q = pools[p];
         if (q.finished) continue;
@@ -1106,15 +1150,8 @@ struct ca_trainer {
         pp.pool_row_base = q.row_base;
         pp.pack_counter = pack_counter.p + 2 * p;
         pp.cache = q.cache; /* (hdr null: no cache) */
+        pp.cache.no_claim = emptied ? 1u : 0u;
         const bool timed = in_window == poll - 1 || (max_iterations > 0 && it + 1 == max_iterations);
-        if (q.cache.hdr && q.c_inserted_est > 0.5 * (double)q.c_entries) {
-          /* the table is half full: start over (a long generation asks for far more positions than any table holds;
-           * what is asked for again is mostly recent -- the trees of the games in play).  In stream order between two
-           * iterations, when no entry is pending. */
-          rt_memset(q.c_hdr, 0, q.c_entries * 16, q.st);
-          q.c_inserted_est = 0;
-          ++cache_clears;
-        }
         /* The network launch is sized by what the batch can hold: the games still running at the pool's last poll (they
          * only become fewer) times the searches per evaluation.  In a generation's thin tail the throughput kernel is
          * then not launched at all and the small-batch kernel's grid shrinks -- a launch whose workgroups all leave at

@@ -100,7 +100,8 @@ struct TreeCtl {
   uint32_t peak_units;
 };
 
-/* Evaluation cache of a pool in fused training (mcts.h co_cache_resolve): a network's outputs are a function of
+/* Evaluation cache of fused training (mcts.h co_cache_resolve), ONE table for all pools of a trainer (round 4; a table
+ * per pool until then: 2.3 % of a generation's rows are positions the OTHER pool has evaluated): a network's outputs are a function of
  * the request row alone, and a generation asks for the same positions again and again (the two players' trees of a
  * game overlap, thousands of games leave the same opening: 29 % of the rows of a 4096-game generation with
  * random-init weights, 44 % with a trained checkpoint, tools/exp/dup_rows.py).  The outputs of every evaluated row
@@ -111,10 +112,20 @@ struct TreeCtl {
  * priors kernel and the search kernel read through pend_src.  Nothing is copied. */
 #define CO_CACHE_VAL_FLOATS 100 /* value, 3 pad, 96 priors */
 #define CO_CACHE_PROBES 16
+#define CO_CACHE_POOL_SHIFT 28        /* bits 28..29 of an entry's claim word: the pool whose network launch writes it */
+#define CO_CACHE_POOL_MASK 0x30000000u
 struct EvalCache {
-  uint32_t *hdr;       /* [mask + 1][4]; null = no cache */
-  float *val;          /* [mask + 1 + pool rows][CO_CACHE_VAL_FLOATS] */
+  uint32_t *hdr;       /* [mask + 1][4], shared by the pools; null = no cache.  Word 3: iteration of the claim + 1 */
+  float *val;          /* [mask + 1 + rows of all pools][CO_CACHE_VAL_FLOATS], shared */
   uint32_t mask;
+  uint32_t scratch_base; /* this pool's first scratch element behind the table = its first batch row */
+  uint32_t pool_bits;    /* this pool's index << CO_CACHE_POOL_SHIFT */
+  uint32_t no_claim;     /* the iteration behind an emptying of the table: no entry is claimed (rows go to scratch).  The
+                          * pending leaves of EVERY pool still point at elements of the old contents, which a pool reads
+                          * during this iteration -- an entry claimed now could be another pool's network launch writing
+                          * into an element a third party has yet to read.  One iteration later nothing points there. */
+  uint32_t *done;      /* [CO_MAX_POOLS] shared: the network launches of pool p's iterations < done[p] have completed
+                        * (stored by the first wave of p's next search launch, which stream order puts behind them) */
   int32_t *in_idx;     /* [pool rows] request rows the network evaluates this iteration, compact ... */
   int32_t *out_idx;    /* ... and the element of val each one writes */
   uint32_t *count;     /* [2][4] by iteration parity: {rows to evaluate, 0, 0, 0} */

@@ -1391,8 +1391,11 @@ CO_DEV int co_step_row(const EngineParams &P, int g, const GameCtl &gc) {
 
 /* ---- evaluation cache (engine_defs.h EvalCache), fused training: the tail of a game's step resolves its new request
  * rows to elements of the cache's value array, ONE LANE per row:
- *   the position has an entry (evaluated in an earlier iteration, or claimed by another row of this batch, whose
- *   outputs this iteration's network launch writes)            -> that entry;
+ *   the position has an entry of this pool (evaluated in an earlier iteration, or claimed by another row of this
+ *   batch, whose outputs this iteration's network launch writes: stream order)   -> that entry;
+ *   an entry of ANOTHER pool: its outputs are there once that pool's network launch of the claiming iteration has
+ *   completed, which the pool's next search launch publishes (EvalCache::done)     -> that entry, if published;
+ *   else the row is evaluated into its scratch element (nothing is waited for, no second entry is made);
  *   no entry, an empty slot in the probe window                -> the lane claims it, the row is evaluated into it;
  *   neither (the window is full)                               -> the row is evaluated into its scratch element.
  * Rows to evaluate are numbered with one atomic per game.  Correctness does not depend on who wins a race: every
@@ -1428,26 +1431,42 @@ CO_DEV void co_cache_resolve(const EngineParams &P, CoWave &w, int g, int n, int
        * never equals a stored word, so the three words of an entry may become visible in any order -- a reader
        * takes an entry for its position only when all three are there.  The third word is the claim: empty = 0. */
       const uint32_t x0 = key.x ^ 0x88888888u, x1 = key.y ^ 0x88888888u;
+      /* The claim word also names the claiming pool (bits the key leaves free), so whose entry it is is known with
+       * the claim itself; the iteration of the claim follows in word 3 and matters to the OTHER pools only. */
+      const uint32_t mine = key.z | C.pool_bits;
       for (int probe = 0; probe < CO_CACHE_PROBES; ++probe) {
         const uint32_t s = (h + (uint32_t)probe) & C.mask;
         uint32_t *H = C.hdr + (size_t)s * 4;
         uint32_t e0 = co_lane_load_coherent_u32(H + 0), e1 = co_lane_load_coherent_u32(H + 1), e2 = co_lane_load_coherent_u32(H + 2);
         if (e2 == 0u) {
-          e2 = co_lane_cas_u32(H + 2, 0u, key.z);
+          if (C.no_claim) break; /* (EvalCache::no_claim: the row is evaluated into its scratch element) */
+          e2 = co_lane_cas_u32(H + 2, 0u, mine);
           if (e2 == 0u) {
             co_lane_store_coherent_u32(H + 0, x0);
             co_lane_store_coherent_u32(H + 1, x1);
+            co_lane_store_coherent_u32(H + 3, (uint32_t)P.iteration + 1u);
             sl = (int)s; /* ours: this row is evaluated into the entry */
             break;
           }
-          if (e2 == key.z) { /* taken this instant, perhaps for the same position: look again */
+          if ((e2 & ~CO_CACHE_POOL_MASK) == key.z) { /* taken this instant, perhaps for the same position: look again */
             e0 = co_lane_load_coherent_u32(H + 0);
             e1 = co_lane_load_coherent_u32(H + 1);
           }
         }
-        if (e2 == key.z && e0 == x0 && e1 == x1) {
-          sl = (int)s;
-          nd = 0;
+        if ((e2 & ~CO_CACHE_POOL_MASK) == key.z && e0 == x0 && e1 == x1) {
+          if ((e2 & CO_CACHE_POOL_MASK) == C.pool_bits) {
+            sl = (int)s;
+            nd = 0;
+          } else {
+            /* another pool's: usable iff its claiming iteration's network launch is known to be over (a stamp that
+             * is not visible yet reads 0: not usable) */
+            const uint32_t stamp = co_lane_load_coherent_u32(H + 3);
+            const uint32_t dn = co_lane_load_coherent_u32(C.done + ((e2 & CO_CACHE_POOL_MASK) >> CO_CACHE_POOL_SHIFT));
+            if (stamp != 0u && stamp <= dn) {
+              sl = (int)s;
+              nd = 0;
+            }
+          }
           break;
         }
       }
@@ -1465,7 +1484,7 @@ CO_DEV void co_cache_resolve(const EngineParams &P, CoWave &w, int g, int n, int
       int src = L(slot);
       if (L(need)) {
         const uint32_t m = base + (uint32_t)co_popc64(nm & ((1ull << lane) - 1ull));
-        if (src < 0) src = (int)(C.mask + 1u + m); /* scratch element m of this iteration */
+        if (src < 0) src = (int)(C.mask + 1u + C.scratch_base + m); /* this pool's scratch element m of this iteration */
         C.in_idx[m] = row0 + lane;
         C.out_idx[m] = src;
       }
@@ -1494,6 +1513,9 @@ CO_DEV void co_pool_housekeeping(const EngineParams &P, int g) {
           const int op = (P.iteration & 1) ^ 1;
           P.cache.totals[0] += P.cache.count[4 * op];
           P.cache.count[4 * op] = 0u;
+          /* this launch stands behind the pool's network launch of iteration - 1 in its stream: entries the pool
+           * claimed in iterations < iteration (stamps <= iteration) hold their outputs -- tell the other pools */
+          co_lane_store_coherent_u32(P.cache.done + (P.cache.pool_bits >> CO_CACHE_POOL_SHIFT), (uint32_t)P.iteration);
         }
       }
     }

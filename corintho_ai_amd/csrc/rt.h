@@ -36,6 +36,7 @@ inline void rt_event_create(rt_event_t *) {}
 inline void rt_event_destroy(rt_event_t) {}
 inline void rt_event_record(rt_event_t, rt_stream_t) {}
 inline void rt_event_sync(rt_event_t) {}
+inline void rt_stream_wait(rt_stream_t, rt_event_t) {}
 inline float rt_event_elapsed_ms(rt_event_t, rt_event_t) { return 0.0f; }
 inline void rt_host_alloc(void **p, size_t n) { rt_malloc(p, n, 0); }
 inline void rt_host_free(void *p) { free(p); }
@@ -101,6 +102,8 @@ inline void rt_event_destroy(rt_event_t e) {
 }
 inline void rt_event_record(rt_event_t e, rt_stream_t s) { RT_CHECK(hipEventRecord(e, s)); }
 inline void rt_event_sync(rt_event_t e) { RT_CHECK(hipEventSynchronize(e)); }
+/* everything queued on s from here on starts behind what was queued in front of the record of e */
+inline void rt_stream_wait(rt_stream_t s, rt_event_t e) { RT_CHECK(hipStreamWaitEvent(s, e, 0)); }
 inline float rt_event_elapsed_ms(rt_event_t a, rt_event_t b) {
   float ms = 0.0f;
   RT_CHECK(hipEventElapsedTime(&ms, a, b));

@@ -41,7 +41,7 @@ def _f32(a, what):
 
 def _eval_cache_cfg(eval_cache):
     """ca_config.eval_cache from the Python argument: True -> 0 (on where it pays, table sized automatically),
-    False / None -> -1 (off), an int n in 6..30 -> a table of 2**n entries per pool.  Anything else is refused
+    False / None -> -1 (off), an int n in 6..30 -> a table of 2**n entries.  Anything else is refused
     (0 and 1 as plain ints would silently mean something else on each side of the C ABI)."""
     if eval_cache is True:
         return 0

@@ -78,7 +78,7 @@ typedef struct ca_config {
   /* Evaluation cache of fused training (ca_trainer_run): a request row whose position was evaluated earlier in the same
    * generation receives the stored outputs instead of a second evaluation -- bit for bit what the network kernel would
    * write again, since a row's outputs depend on the row only.  Emptied at the start of every generation (and whenever
-   * it is half full).  0 = on, table sized from the pool and the free memory; n > 0 = on with 2^n entries per pool;
+   * it is half full).  0 = on, table sized from the pool and the free memory; n > 0 = on with 2^n entries (one table for all pools of the trainer);
    * negative = off.  (The reference evaluates every request, main.pyx:70-83; results are identical either way.) */
   int32_t eval_cache;
 } ca_config;

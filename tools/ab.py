@@ -46,6 +46,7 @@ for r in range(reps):
         acc[i][0] += dt * 1e3
         acc[i][1] += st["mcts_ms"]
         acc[i][2] += st["nn_ms"]
+        acc[i].append(st.get("nn_rows_evaluated", 0) / max(st.get("nn_rows", 1), 1))
 for path, a in zip(libs, acc):
-    print("%-44s wall %.1f ms  search %.1f ms  network %.1f ms   (%d games, %s, %d pool(s), mean of %d)" %
-          (os.path.basename(path), a[0] / reps, a[1] / reps, a[2] / reps, G, net, pools, reps))
+    print("%-44s wall %.1f ms  search %.1f ms  network %.1f ms   (%d games, %s, %d pool(s), mean of %d; rows evaluated %.4f of the requested)" %
+          (os.path.basename(path), a[0] / reps, a[1] / reps, a[2] / reps, G, net, pools, reps, sum(a[3:]) / max(len(a[3:]), 1)))
