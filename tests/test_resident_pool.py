@@ -151,6 +151,24 @@ def test_reference_production_setting_25000_games_1600_simulations():
 
 
 # ---------------------------------------------------------------------------------------------------------------
+def test_the_pools_share_one_cache_table():
+    """round 4: ONE table for all pools -- a position another pool evaluated in an earlier iteration is not evaluated
+    again (what both reach in the same iteration still is).  On the emulation build the pools of an iteration run one after
+    the other, so the counts are exact: with a table per pool this generation evaluated 31 443 (two pools) and 31 729
+    (three) rows where a single pool evaluates 30 831."""
+    w = nets.init_mlp12x100(seed=3, bn_noise=True)
+    got = {}
+    for pools in (1, 2, 3):
+        t = make_trainer("emu", 48, "", 5, 60, 8, 1.0, 0.25, 0, 1, False, stagger=False, pools=pools, eval_cache=18)
+        t.set_net(1, w)
+        assert t.run()
+        st = t.stats()
+        got[pools] = st["nn_rows_evaluated"]
+        assert st["nn_rows"] == 35584
+        t.close()
+    assert got[1] == 30831 and got[1] < got[2] <= 31185 and got[2] < got[3] <= 31277, got
+
+
 # Evaluation cache (ca_config.eval_cache): a request row whose position was evaluated earlier in the generation gets the
 # stored outputs.  A row's outputs are a function of the row, so nothing a game sees changes: every result equals the
 # uncached run's bit for bit, with fewer rows through the network kernel.
