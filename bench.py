@@ -198,8 +198,11 @@ def measured_traffic(kernel, args, net, npools):
             k = json.load(f)["kernels"]
             t = k[kernel]["traffic_bytes_per_launch"]
             twin = "co_k_rescnn_forward_h3_small" if kernel == "co_k_rescnn_forward_h3p" else kernel + "_small"
-            if twin in k:  # the network launch queues both instances of the kernel; one of them works
-                t += k[twin]["traffic_bytes_per_launch"]
+            if twin in k:
+                # a network launch queues the small-batch instance always and the throughput instance when the batch can
+                # exceed the former's rows; one of them works: bytes of both over the number of network launches
+                n, nt = k[kernel].get("launches", 1), k[twin].get("launches", 1)
+                t = (t * n + k[twin]["traffic_bytes_per_launch"] * nt) / max(n, nt, 1)
             return t
     except Exception:
         return None
