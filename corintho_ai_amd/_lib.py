@@ -71,7 +71,7 @@ EXPORTS = [
     "ca_trainer_num_samples", "ca_trainer_score", "ca_trainer_avg_mate_length", "ca_trainer_write_requests",
     "ca_trainer_write_samples", "ca_trainer_write_scores", "ca_trainer_do_iteration", "ca_trainer_set_net",
     "ca_trainer_run", "ca_trainer_net_forward", "ca_trainer_net_bench", "ca_trainer_export_samples", "ca_trainer_pack_samples_device", "ca_trainer_pin_host", "ca_trainer_unpin_host", "ca_trainer_set_positions", "ca_trainer_analysis", "ca_trainer_finish", "ca_trainer_set_logging", "ca_trainer_reset", "ca_expand_samples", "ca_trainer_stats",
-    "ca_trainer_game_info", "ca_trainer_trace", "ca_trainer_prof", "ca_rules_legal_moves", "ca_rules_do_move", "ca_rng_draw",
+    "ca_trainer_game_info", "ca_trainer_trace", "ca_trainer_prof", "ca_rules_legal_moves", "ca_rules_do_move", "ca_rules_rows", "ca_rng_draw",
     "ca_fp_probe",
     "ca_tourney_create", "ca_tourney_destroy", "ca_tourney_set_log_folder", "ca_tourney_add_player", "ca_tourney_add_match", "ca_tourney_all_done",
     "ca_tourney_num_requests", "ca_tourney_write_requests", "ca_tourney_do_iteration", "ca_tourney_write_scores",
@@ -114,6 +114,7 @@ def declare(L):
     L.ca_trainer_prof.argtypes = [vp, C.POINTER(C.c_ulonglong)]
     L.ca_rules_legal_moves.argtypes = [C.c_int, u64p, u32p, C.c_int32, u32p, i32p]
     L.ca_rules_do_move.argtypes = [C.c_int, u64p, u32p, i32p, C.c_int32, f32p]
+    L.ca_rules_rows.argtypes = [C.c_int, u64p, u32p, i32p, C.c_int32, u32p]
     L.ca_rng_draw.argtypes = [C.c_int, C.c_uint32, C.c_int32, C.c_int32, u32p]
     L.ca_fp_probe.argtypes = [C.c_int, f32p, C.c_int32, f32p]
     L.ca_tourney_create.argtypes = [C.c_int, C.c_uint32, C.c_int, C.POINTER(vp)]

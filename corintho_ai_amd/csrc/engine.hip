@@ -26,6 +26,12 @@
 
 #ifdef CO_EMU
 thread_local int co_emu_block_idx = 0;
+#ifdef CO_SB_STATS
+unsigned long long co_sb_stats[32];
+unsigned long long co_sb_ply[8][8];
+extern "C" unsigned long long *co_emu_sb_stats(void) { return co_sb_stats; }
+extern "C" unsigned long long *co_emu_sb_ply(void) { return &co_sb_ply[0][0]; }
+#endif
 #endif
 
 static thread_local std::string g_last_error;
@@ -136,6 +142,7 @@ struct ca_trainer {
   int num_logged = 0;
   bool logs_written = false;
   DevBuf<float> req, nn_in, nn_in70, nn_eval, nn_probs, samples;
+  DevBuf<int32_t> row_idx;
   DevBuf<unsigned long long> row_counter, pack_counter, prof, next_game;
   DevBuf<GameCtl> results;   /* [G] finished games by index (recycling pools) */
   DevBuf<uint32_t> seeds_dev; /* [G] per-game generator seeds (recycling pools) */
@@ -304,6 +311,7 @@ struct ca_trainer {
     req.alloc((size_t)R * spe * CO_STATE_STRIDE, stream);
     req_offset.alloc((size_t)R + 1, stream);
     nn_in.alloc((size_t)R * spe * CO_STATE_STRIDE, stream);
+    row_idx.alloc((size_t)R * spe, stream);
     nn_in70.alloc((size_t)R * spe * CO_GAME_STATE_SIZE, stream);
     ctl.alloc(4, stream);
     rt_host_alloc((void **)&h_ctl, 16);
@@ -523,6 +531,7 @@ struct ca_trainer {
     P.nn_eval = nn_eval.p;
     P.nn_probs = nn_probs.p;
     P.nn_in = nn_in.p;
+    P.row_idx = row_idx.p;
     P.nn_in70 = nn_in70.p;
     P.ctl = ctl.p;
     P.samples = samples.p;
@@ -539,7 +548,7 @@ struct ca_trainer {
     P.pool_row_base = 0;
     P.pack_counter = pack_counter.p;
 #ifdef CO_PROF
-    prof.alloc((size_t)R * CO_NPROF + 24, stream);
+    prof.alloc((size_t)R * CO_NPROF + 24 + CO_NPROF, stream);
     P.prof = prof.p;
 #else
     P.prof = nullptr;
@@ -1173,16 +1182,15 @@ struct ca_trainer {
           io.eval_stride = CO_CACHE_VAL_FLOATS;
           io.probs_stride = CO_CACHE_VAL_FLOATS;
           io.alone = npools == 1;
-          nets[0]->forward(nn_in.p + (size_t)q.row_base * CO_STATE_STRIDE, cap_rows,
-                           (const int32_t *)(q.c_count + 4 * (trainer_iteration & 1)), q.c_val, q.c_val + 4, q.st, io);
+          nets[0]->forward(req.p, cap_rows, (const int32_t *)(q.c_count + 4 * (trainer_iteration & 1)), q.c_val, q.c_val + 4, q.st, io);
           if (timed) rt_event_record(e[3], q.st);
         } else {
           if (timed) rt_event_record(e[2], q.st);
           const int32_t *d_rows = (const int32_t *)(pack_counter.p + 2 * p + (trainer_iteration & 1));
           CoNetIO io;
           io.alone = npools == 1;
-          nets[0]->forward(nn_in.p + (size_t)q.row_base * CO_STATE_STRIDE, cap_rows, d_rows, nn_eval.p + q.row_base,
-                           nn_probs.p + (size_t)q.row_base * CO_NUM_MOVES, q.st, io);
+          io.in_idx = row_idx.p + q.row_base; /* the rows stay where the games wrote them (co_step_tail) */
+          nets[0]->forward(req.p, cap_rows, d_rows, nn_eval.p + q.row_base, nn_probs.p + (size_t)q.row_base * CO_NUM_MOVES, q.st, io);
           if (timed) rt_event_record(e[3], q.st);
         }
         if (timed) q.timed[parity] = 1;
@@ -1703,19 +1711,18 @@ extern "C" int ca_tourney_stats(ca_tourney *t, ca_stats *out) {
 }
 
 /* diagnostic builds (-DCO_PROF): summed in-kernel cycle stamps, see mcts.h; not in the public header */
-extern "C" int ca_trainer_prof(ca_trainer *t, unsigned long long out[CO_NPROF + 20]) {
+extern "C" int ca_trainer_prof(ca_trainer *t, unsigned long long out[2 * CO_NPROF + 24]) {
   CA_TGUARD({
-    for (int i = 0; i < CO_NPROF + 20; ++i) out[i] = 0;
+    for (int i = 0; i < 2 * CO_NPROF + 24; ++i) out[i] = 0;
     if (!t->prof.p) throw EngineError(CA_ERR_STATE, "not a -DCO_PROF build");
     std::vector<unsigned long long> h((size_t)t->R * CO_NPROF);
     rt_d2h(h.data(), t->prof.p, h.size() * 8, t->stream);
     rt_sync(t->stream);
     for (int g = 0; g < t->R; ++g)
       for (int i = 0; i < CO_NPROF; ++i) out[i] += h[(size_t)g * CO_NPROF + i];
-    unsigned long long clk[20];
-    rt_d2h(clk, t->prof.p + (size_t)t->R * CO_NPROF, sizeof clk, t->stream);
+    /* [CO_NPROF ..): clocks, the histogram of wave-step times, then the phase sums of the slow wave-steps alone */
+    rt_d2h(out + CO_NPROF, t->prof.p + (size_t)t->R * CO_NPROF, (size_t)(24 + CO_NPROF) * 8, t->stream);
     rt_sync(t->stream);
-    for (int i = 0; i < 20; ++i) out[CO_NPROF + i] = clk[i];
   })
 }
 
@@ -1878,6 +1885,26 @@ extern "C" int ca_rules_do_move(int device, uint64_t *boards, uint32_t *metas, c
     rt_sync(ts.s);
     for (int i = 0; i < n; ++i)
       memcpy(states + (size_t)i * CO_GAME_STATE_SIZE, &tmp[(size_t)i * CO_STATE_STRIDE], CO_GAME_STATE_SIZE * 4);
+  })
+}
+
+extern "C" int ca_rules_rows(int device, uint64_t *boards, uint32_t *metas, const int32_t *moves, int32_t n, uint32_t *masks) {
+  int rc = ca_device_check(device);
+  if (rc != CA_OK) return rc;
+  CA_GUARD({
+    TmpStream ts(device);
+    DevBuf<uint64_t> b;
+    DevBuf<uint32_t> m, mk;
+    DevBuf<int32_t> mv;
+    b.alloc(n, ts.s); m.alloc(n, ts.s); mk.alloc((size_t)n * 3, ts.s); mv.alloc(n, ts.s);
+    rt_h2d(b.p, boards, (size_t)n * 8, ts.s);
+    rt_h2d(m.p, metas, (size_t)n * 4, ts.s);
+    rt_h2d(mv.p, moves, (size_t)n * 4, ts.s);
+    RT_LAUNCH(co_k_rules_rows, (n + 3) / 4, CO_WAVE, ts.s, b.p, m.p, (const int32_t *)mv.p, n, mk.p);
+    rt_d2h(boards, b.p, (size_t)n * 8, ts.s);
+    rt_d2h(metas, m.p, (size_t)n * 4, ts.s);
+    rt_d2h(masks, mk.p, (size_t)n * 12, ts.s);
+    rt_sync(ts.s);
   })
 }
 

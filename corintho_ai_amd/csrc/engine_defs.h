@@ -84,6 +84,9 @@ struct GameCtl {
   /* the game this slot plays (index within this trainer's games; = the slot index unless the pool recycles
    * slots, see EngineParams::results) */
   int32_t gid;
+  /* the search's hint to itself: simulations it selects together in this position (mcts.h co_search_rows; 0 = CO_SB).
+   * Positions whose simulations keep ending in terminal leaves get smaller groups; results do not depend on it. */
+  int32_t sb_cap;
 };
 
 /* one side of a tournament match: Player, match.h:13-31 */
@@ -186,7 +189,10 @@ struct EngineParams {
   int32_t *req_offset;  /* [G+1] exclusive prefix of the active games' request counts; [G] = total */
   const float *nn_eval;   /* [rows] compact, row = req_offset[g] + k */
   const float *nn_probs;  /* [rows][96] */
-  float *nn_in;           /* [rows][CO_STATE_STRIDE] compact request rows */
+  float *nn_in;           /* [rows][CO_STATE_STRIDE] compact request rows (host protocol, arena; fused training leaves the
+                           * rows where the games wrote them, `req`, and hands the network their indices: row_idx) */
+  int32_t *row_idx;       /* [rows] fused training: batch row m of this iteration is request row row_idx[m] of `req`
+                           * (= slot * searches_per_eval + pending leaf); the network kernels gather through it (nn.h CoNetIO) */
   float *nn_in70;         /* [rows][70] the same rows as Trainer::writeRequests lays them out (compat mode), or null */
   int32_t *ctl;           /* [4] written by co_k_scan: batch rows, all done, OR of the games' error bits, games not done */
   float *samples;       /* [G][CO_MAX_PLIES][166] */

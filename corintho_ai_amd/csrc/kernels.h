@@ -15,12 +15,15 @@ CO_CONST int32_t CO_MOVE_SYM[8][96] = CO_MOVE_SYM_INIT;
 #ifdef CO_EMU
 #define CO_K3_WAVES 1
 #define CO_K3_WAVE_IN_BLOCK 0
+#define CO_K3_BOUNDS
 #else
+/* the launch has exactly CO_K3_WPB wavefronts per workgroup: say so, or the register budget is that of a 1024-thread workgroup */
+#define CO_K3_BOUNDS __launch_bounds__(CO_K3_WPB * 64)
 #define CO_K3_WAVES CO_K3_WPB
 /* wave-uniform by construction: tell the compiler, or the game index and everything derived from it live in vector registers */
 #define CO_K3_WAVE_IN_BLOCK (CO_K3_WPB > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0)
 #endif
-CO_KERNEL co_k_mcts_step(EngineParams P) {
+CO_K3_BOUNDS CO_KERNEL co_k_mcts_step(EngineParams P) {
   const int i = CO_BLOCK_IDX * CO_K3_WAVES + CO_K3_WAVE_IN_BLOCK;
   const int g = P.pool_lo + i;
   if (i < P.pool_n && g < P.num_games) co_mcts_step_wave(P, g);
@@ -259,6 +262,42 @@ CO_KERNEL co_k_domove_batch(uint64_t *boards, uint32_t *metas, const int32_t *mo
     }
   }
   co_write_state(b, m, states + (size_t)i * CO_STATE_STRIDE);
+}
+
+/* the four-positions-per-wavefront rule layer (rules.h co_do_move_lane, co_legal_moves_rows): position 4 b + r in row r */
+CO_KERNEL co_k_rules_rows(uint64_t *boards, uint32_t *metas, const int32_t *moves, int n, uint32_t *masks) {
+  const int base = CO_BLOCK_IDX * 4;
+  LV(uint32_t, blo);
+  LV(uint32_t, bhi);
+  LV(uint32_t, mt);
+  LV(int, on);
+  FOR_LANES {
+    const int i = base + (lane >> 4);
+    L(on) = i < n;
+    uint64_t b = L(on) ? boards[i] : 0ull;
+    uint32_t m = L(on) ? metas[i] : 0u;
+    if (L(on) && moves[i] >= 0) co_do_move_lane(&b, &m, moves[i]);
+    L(blo) = (uint32_t)b;
+    L(bhi) = (uint32_t)(b >> 32);
+    L(mt) = m;
+  }
+  LV(uint32_t, o0);
+  LV(uint32_t, o1);
+  LV(uint32_t, o2);
+  WG_SHARED(uint32_t, lb, CO_LB_WORDS);
+  co_line_breakers_to_lds(lb);
+  LV(int, lines);
+  co_legal_moves_rows(blo, bhi, mt, on, o0, o1, o2, lines, lb);
+  FOR_LANES {
+    const int i = base + (lane >> 4);
+    if (L(on) && (lane & 15) == 0) {
+      boards[i] = (uint64_t)L(blo) | ((uint64_t)L(bhi) << 32);
+      metas[i] = L(mt);
+      masks[i * 3 + 0] = L(o0);
+      masks[i * 3 + 1] = L(o1);
+      masks[i * 3 + 2] = L(o2);
+    }
+  }
 }
 
 /* mt19937: game 0's generator, `n` outputs through the wave draw path */

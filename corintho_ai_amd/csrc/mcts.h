@@ -42,11 +42,15 @@ CO_CONST uint32_t CO_GAMMA_BITS[CO_NUM_GAMMA] = CO_GAMMA_BITS_INIT;
     w.pacc[slot] += now_ - w.tph;                 \
     w.tph = now_;                                 \
   } while (0)
+#ifdef CO_PROF_LIGHT /* stamps that wait for nothing: a phase is charged the waits the PRODUCT has in it */
+#define CO_PH_MEM(slot) CO_PH(slot)
+#else
 #define CO_PH_MEM(slot)                                               \
   do {                                                                \
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       \
     CO_PH(slot);                                                      \
   } while (0)
+#endif
 #else
 #define CO_CLK() 0ull
 #define CO_PROF_ADD(w, slot, v) ((void)0)
@@ -66,11 +70,13 @@ struct CoWave {
 #if defined(CO_PROF) && !defined(CO_EMU)
   unsigned long long pacc[CO_NPROF], tph;
 #endif
-  CoLanes K; /* per-lane constants of the rule layer (rules.h) */
   /* the tree of the player to move and the opponent's; swapped on hand-over so that
    * no register-resident state is indexed dynamically (that would spill to scratch) */
   CoTree me, opp;
   uint32_t *mt;
+  const uint32_t *lb; /* LDS: line_breakers (rules.h co_line_breakers_to_lds) */
+  int mt_staged;      /* mt_stage holds the generator's current state */
+  uint32_t *mt_stage; /* LDS, CO_MT_STAGE words: staging copy of the generator state for a twist (rng.h co_mt_twist_lds) */
   /* per-game views */
   uint32_t *pend_leaf;
   int32_t *pend_depth;
@@ -135,26 +141,12 @@ CO_DEV void co_trace_push(CoWave &w, int32_t v) {
   w.gc.trace_len++;
 }
 
-/* Create the node for position (board, meta_game) -- Node ctors node.cpp:14-39 +
- * initializeEdges node.cpp:256-283.  self_slot == CO_NONE makes a detached root
- * that carries its own stat slot.  Returns the block offset (CO_NONE on arena
- * overflow); *res_out = kResultLoss / kResultDraw / kResultNone. */
-CO_DEV uint32_t co_create_node(CoWave &w, CoTree &t, uint64_t board, uint32_t meta_game, int depth, uint32_t parent,
-                               uint32_t self_slot, int *res_out, int *n_out = (int *)0, uint32_t *lm_out = (uint32_t *)0) {
-  uint32_t lm[3];
-  int is_lines = co_legal_moves(board, meta_game, lm, w.K);
-  CO_PH(14);
-  if (lm_out) {
-    lm_out[0] = lm[0];
-    lm_out[1] = lm[1];
-    lm_out[2] = lm[2];
-  }
+/* Write the node of a position whose legal moves (lm, n of them) are known -- Node ctors node.cpp:14-39 +
+ * initializeEdges node.cpp:256-283: bump allocation, header, edge slots in ascending move id.  self_slot == CO_NONE
+ * makes a detached root that carries its own stat slot.  Returns the block offset (CO_NONE on arena overflow). */
+CO_DEV uint32_t co_emit_node(CoWave &w, CoTree &t, uint64_t board, uint32_t meta_game, int depth, uint32_t parent,
+                             uint32_t self_slot, const uint32_t lm[3], int n, int res) {
   const int n01 = co_popc32(lm[0]) + co_popc32(lm[1]);
-  int n = n01 + co_popc32(lm[2]);
-  int res = CO_RESULT_NONE;
-  if (n == 0) res = is_lines ? CO_RESULT_LOSS : CO_RESULT_DRAW;
-  *res_out = res;
-  if (n_out) *n_out = n;
   uint32_t units = 2u + (uint32_t)n + (self_slot == CO_NONE ? 1u : 0u);
   if (t.tc.units_used + units > t.cap) {
     w.gc.error |= CO_ERR_ARENA_FULL;
@@ -180,6 +172,26 @@ CO_DEV uint32_t co_create_node(CoWave &w, CoTree &t, uint64_t board, uint32_t me
   WAVE_SYNC();
   CO_PH(15);
   return b;
+}
+
+/* Create the node for position (board, meta_game): legal moves (game.cpp:28-43), terminal result (node.cpp:256-271),
+ * then co_emit_node.  *res_out = kResultLoss / kResultDraw / kResultNone. */
+CO_DEV uint32_t co_create_node(CoWave &w, CoTree &t, uint64_t board, uint32_t meta_game, int depth, uint32_t parent,
+                               uint32_t self_slot, int *res_out, int *n_out = (int *)0, uint32_t *lm_out = (uint32_t *)0) {
+  uint32_t lm[3];
+  int is_lines = co_legal_moves1(board, meta_game, lm);
+  CO_PH(14);
+  if (lm_out) {
+    lm_out[0] = lm[0];
+    lm_out[1] = lm[1];
+    lm_out[2] = lm[2];
+  }
+  int n = co_popc32(lm[0]) + co_popc32(lm[1]) + co_popc32(lm[2]);
+  int res = CO_RESULT_NONE;
+  if (n == 0) res = is_lines ? CO_RESULT_LOSS : CO_RESULT_DRAW;
+  *res_out = res;
+  if (n_out) *n_out = n;
+  return co_emit_node(w, t, board, meta_game, depth, parent, self_slot, lm, n, res);
 }
 
 /* A leaf asks for a network evaluation: TrainMC writes the state into to_eval_
@@ -237,30 +249,58 @@ CO_DEV void co_request(CoWave &w, uint64_t board, uint32_t meta, uint32_t leaf, 
 CO_DEV void co_capture_noise(CoWave &w) {
   int done = 0;
   const int total = w.noise_words;
+  int staged = w.mt_staged; /* the state is in w.mt_stage: fetched when the step began (co_mcts_step_wave), in front of
+                             * the step's stores -- a fetch here would stand behind all of them -- or by a twist below */
   while (done < total) {
     if (w.gc.rng_idx >= CO_MT_N) {
-      co_mt_twist(w.mt);
+      if (!staged) co_mt_stage_load(w.mt, w.mt_stage);
+      CO_PH(30);
+      co_mt_twist_staged(w.mt, w.mt_stage);
+      CO_PH(31);
       w.gc.rng_idx = 0;
+      staged = 1;
     }
     int cnt = total - done;
     if (cnt > CO_MT_N - w.gc.rng_idx) cnt = CO_MT_N - w.gc.rng_idx;
-    const uint32_t *src = w.mt + w.gc.rng_idx;
     uint32_t *dst = w.noise_raw + done;
-    /* four chunks of 64 words at a time, loads first: their latencies overlap (a step owes ~450 words) */
-    for (int base = 0; base < cnt; base += 4 * CO_WAVE) {
-      LV(uint32_t, v[4]);
-      FOR_LANES {
+    if (staged) {
+      /* (LDS reads first, then the stores in one run: see co_mt_twist_staged) */
+      const uint32_t *src = w.mt_stage + w.gc.rng_idx;
+      for (int base = 0; base < cnt; base += 5 * CO_WAVE) {
+        LV(uint32_t, v[5]);
+        FOR_LANES {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int i = base + j * CO_WAVE + lane;
-          L(v[j]) = src[i < cnt ? i : 0];
+          for (int j = 0; j < 5; ++j) {
+            const int i = base + j * CO_WAVE + lane;
+            L(v[j]) = src[i < cnt ? i : 0];
+          }
+        }
+        FOR_LANES {
+#pragma unroll
+          for (int j = 0; j < 5; ++j) {
+            const int i = base + j * CO_WAVE + lane;
+            if (i < cnt) dst[i] = L(v[j]);
+          }
         }
       }
-      FOR_LANES {
+    } else {
+      const uint32_t *src = w.mt + w.gc.rng_idx;
+      /* four chunks of 64 words at a time, loads first: their latencies overlap (a step owes ~450 words) */
+      for (int base = 0; base < cnt; base += 4 * CO_WAVE) {
+        LV(uint32_t, v[4]);
+        FOR_LANES {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int i = base + j * CO_WAVE + lane;
-          if (i < cnt) dst[i] = L(v[j]);
+          for (int j = 0; j < 4; ++j) {
+            const int i = base + j * CO_WAVE + lane;
+            L(v[j]) = src[i < cnt ? i : 0];
+          }
+        }
+        FOR_LANES {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int i = base + j * CO_WAVE + lane;
+            if (i < cnt) dst[i] = L(v[j]);
+          }
         }
       }
     }
@@ -268,6 +308,14 @@ CO_DEV void co_capture_noise(CoWave &w) {
     w.gc.rng_idx += cnt;
     done += cnt;
   }
+  w.mt_staged = staged;
+}
+
+/* one output for the game's own draws (opening moves, trainmc.cpp:407; a random player, match.cpp:199-200), through
+ * memory; a twist there leaves the staging copy behind */
+CO_DEV uint32_t co_wave_mt_next(CoWave &w) {
+  if (w.gc.rng_idx >= CO_MT_N) w.mt_staged = 0;
+  return co_mt_next(w.mt, &w.gc.rng_idx);
 }
 
 /* the id of the r-th legal move (r-th set bit of the 96-bit mask), r < number of set bits */
@@ -577,10 +625,37 @@ CO_DEV void co_store_slot(uint4 *A, uint32_t slot, uint4 v, CoRoot &rc) {
   WAVE_SYNC();
 }
 
+/* u of ONE edge, from its slot (the body of chooseNext's loop, trainmc.cpp:553-579), per lane.  Branch-free: every lane
+ * evaluates both forms and selects (one f64 pair per level whatever the mix of edges; divergent branches here cost more
+ * than they save). */
+CO_DEV float co_puct_u(uint4 s, float denom, float v_sqrt) {
+  float prob = (float)((s.z >> 7) & 511u) * denom;
+  float pv = prob * v_sqrt;
+  int r = (int)(s.w & 0xFFu);
+  int has_child = s.x != CO_NONE;
+  int drawn = (r == CO_RESULT_DRAW) | (r == CO_DEDUCED_DRAW);
+  int searchable = ((r == CO_RESULT_NONE) | drawn) & !((s.w >> 8) & 1u);
+  int vis = co_slot_visits(s);
+  float cv = (float)(vis > 0 ? vis : 1); /* 1 .. 32767 */
+  double a = co_div_small(-(double)co_u2f(s.y), cv);
+  double b = co_div_small((double)pv, cv + 1.0f);
+  float uv = (float)(a + b);
+  float uc = drawn ? pv : uv;           /* visited child (trainmc.cpp:561-569; a drawn one without the /(n + 1): quirk 6) */
+  uc = searchable ? uc : CO_NEG_INF;
+  return has_child ? uc : pv;           /* unvisited edge (:575-577) */
+}
+
+/* a simulation passes through a node: increment_visits + increase_evaluation(1.0) (trainmc.cpp:609-623), on its stat slot */
+CO_DEV uint4 co_slot_pass(uint4 s) {
+  s = co_slot_set_visits(s, co_slot_visits(s) + 1);
+  s.y = co_f2u(co_u2f(s.y) + 1.0f);
+  return s;
+}
+
 /* One simulation: TrainMC::search (trainmc.cpp:602-696) with chooseNext
  * (:540-600) inlined as the lane-parallel edge scan.  A node's header and its
  * first 64 edge slots are requested together (one memory round trip per level). */
-CO_DEV void co_search(CoWave &w, CoTree &t, CoRoot &rc) {
+CO_COLD2 void co_search(CoWave &w, CoTree &t, CoRoot &rc) {
   uint4 *A = t.A;
   WAVE_SHARED(uint32_t, path_block, CO_PATH_MAX);
   WAVE_SHARED(uint32_t, path_slot, CO_PATH_MAX);
@@ -619,26 +694,8 @@ CO_DEV void co_search(CoWave &w, CoTree &t, CoRoot &rc) {
         int e = base + lane;
         float uu = CO_NEG_INF;
         if (base > 0 && e < n) L(ev) = A[cur + 2 + e];
-        {
-          /* branch-free: every lane evaluates both forms and selects (one f64 pair per level
-           * whatever the mix of edges; divergent branches here cost more than they save) */
-          uint4 s = L(ev);
-          float prob = (float)((s.z >> 7) & 511u) * denom;
-          float pv = prob * v_sqrt;
-          int r = (int)(s.w & 0xFFu);
-          int has_child = s.x != CO_NONE;
-          int drawn = (r == CO_RESULT_DRAW) | (r == CO_DEDUCED_DRAW);
-          int searchable = ((r == CO_RESULT_NONE) | drawn) & !((s.w >> 8) & 1u);
-          int vis = co_slot_visits(s);
-          float cv = (float)(vis > 0 ? vis : 1); /* 1 .. 32767 */
-          double a = co_div_small(-(double)co_u2f(s.y), cv);
-          double b = co_div_small((double)pv, cv + 1.0f);
-          float uv = (float)(a + b);
-          float uc = drawn ? pv : uv;           /* visited child (trainmc.cpp:561-569; a drawn one without the /(n + 1): quirk 6) */
-          uc = searchable ? uc : CO_NEG_INF;
-          uu = has_child ? uc : pv;             /* unvisited edge (:575-577) */
-          uu = e < n ? uu : CO_NEG_INF;
-        }
+        uu = co_puct_u(L(ev), denom, v_sqrt);
+        uu = e < n ? uu : CO_NEG_INF;
         L(u) = uu;
       }
       float mx = WAVE_MAX_F32(u);
@@ -687,7 +744,7 @@ CO_DEV void co_search(CoWave &w, CoTree &t, CoRoot &rc) {
       uint64_t board = (uint64_t)h0.x | ((uint64_t)h0.y << 32);
       uint32_t meta = h0.z;
       int move = (int)(best_slot.z & 127u);
-      co_do_move(&board, &meta, move, w.K);
+      co_do_move_lane(&board, &meta, move);
       int res;
       int depth = (int)CO_META_DEPTH(h0.z) + 1;
       CO_PH(16);
@@ -763,6 +820,610 @@ CO_DEV void co_search(CoWave &w, CoTree &t, CoRoot &rc) {
   }
 }
 
+/* ---- Several simulations of a step at a time (round 5).
+ *
+ * The reference runs the simulations of a step one after another (trainmc.cpp:169-173), and so did this kernel: every
+ * simulation a chain of dependent waits -- root scan, block fetch, scan, store, expansion, request -- ~10 k cycles of a
+ * lone wavefront, sixteen times per launch.  But under the virtual loss a simulation that ends the ORDINARY way -- it
+ * descends through visited, non-terminal children and creates one new, non-terminal leaf -- changes the tree in a way
+ * that is known the moment each of its choices is made: the chosen child's slot gets one visit and +1.0 (:609-623;
+ * a new child is born with all_visited set and cannot be chosen again before its evaluation arrives, quirk 3), and nothing
+ * else a later scan of the step looks at.  So CO_SB simulations are SELECTED together, level by level:
+ *   - every simulation scans its node's edge slots in registers; a slot another simulation of the group has changed at
+ *     this level is patched in first (same node <=> same level: it is a tree), in simulation order -- at the root that is
+ *     all of them, deeper down only those that chose the same child;
+ *   - the blocks of all the children descended to are requested together: one memory round trip per LEVEL of the group;
+ *   - nothing is written while selecting.  Then, in simulation order, each leaf is expanded and the simulation's stores are
+ *     issued (path slots, node, request) -- the same values in the same order as one after another, so the arena, the
+ *     pending-leaf records and the generator are bit for bit what the sequential search leaves.
+ * A simulation that turns out NOT to be ordinary (nothing searchable below a node, a terminal child or a terminal new
+ * leaf, a node wider than the wavefront, a path beyond CO_SB_DEPTH, a full arena) ends the group in front of it: the
+ * simulations before it are committed, it is run by co_search on the committed tree, the ones behind it are selected
+ * again in the next group (their selection is discarded -- nothing was written). */
+#define CO_SB_DEPTH 12 /* levels a grouped simulation may pass (a level = a lane of its row when it commits: at most 16) */
+#if CO_SB != 1 && CO_SB != 4
+#error "CO_SB: 1 (one simulation after another) or 4 (one per row of the wavefront)"
+#endif
+
+#if defined(CO_SB_STATS) && defined(CO_EMU)
+/* emulation-build counters of the grouped search (tools/sb_stats.py): 0 groups, 1 simulations asked for, 2 committed,
+ * 3 nothing searchable, 4 terminal child, 5 wide node, 6 too deep, 7 terminal leaf / full arena, 8 sequential simulations,
+ * 9 levels of the groups, 10 scans, 11 patches applied (same node, same level), 12 + k: groups that committed k */
+extern unsigned long long co_sb_stats[32];
+extern unsigned long long co_sb_ply[8][8]; /* by game progress (plies / 4): groups, asked, committed, terminal leaves, nothing searchable, levels, sequential, - */
+#define CO_SBS(i, v) __atomic_fetch_add(&co_sb_stats[i], (unsigned long long)(v), __ATOMIC_RELAXED)
+#define CO_SBP(w, i, v) __atomic_fetch_add(&co_sb_ply[(w).gc.plies / 4 > 7 ? 7 : (w).gc.plies / 4][i], (unsigned long long)(v), __ATOMIC_RELAXED)
+#else
+#define CO_SBS(i, v) ((void)0)
+#define CO_SBP(w, i, v) ((void)0)
+#endif
+
+#if CO_SB > 1
+/* m = simulations that are certainly due (1 < m <= CO_SB = 4: each adds one pending leaf and one search).  Returns how
+ * many were committed; fewer than m: the next one takes co_search.
+ *
+ * The group's four simulations live in the four ROWS of the wavefront (16 lanes each, the rows of the DPP unit):
+ *   root    the root's edge slots in registers (one per lane), scanned once per simulation, the chosen slot patched in
+ *           place -- sequential by nature, wave-wide;
+ *   below   row j descends simulation j: its node's edge slots as up to four per lane (edge = 16 k + column), row maximum
+ *           and first-maximum by DPP, the winner's slot by ds_bpermute -- one instruction stream for the four descents.
+ *           Rows that meet in one node take turns in simulation order, the later one's copy patched with what the
+ *           earlier one changed;
+ *   commit  in simulation order (co_search_commit). */
+CO_DEV int co_search_rows(CoWave &w, CoTree &t, CoRoot &rc, int m) {
+  uint4 *A = t.A;
+  WAVE_SHARED(uint32_t, sb_block, CO_SB * CO_SB_DEPTH);       /* [sim][level] node scanned */
+  WAVE_SHARED(uint32_t, sb_slot, CO_SB * (CO_SB_DEPTH + 1));  /* [sim][level] its stat slot; [leaf level] the new child's */
+  WAVE_SHARED(uint4, sb_cs, CO_SB * CO_SB_DEPTH);             /* [sim][level] that slot after the pass */
+  WAVE_SHARED(uint4, sb_hand, CO_SB * 2);                     /* root -> row j: {child block, child slot, z of the chosen slot, -}, the chosen slot */
+  WAVE_SHARED(uint4, sb_leaf, CO_SB * 2);                     /* row j's leaf: {its parent's board lo, hi, meta, block}, {the chosen slot's move | prior, the leaf's slot, -, -} */
+  int bad = m; /* the first simulation that is not ordinary */
+  /* ---- the root, simulation after simulation; and on down for as long as ALL of them take the same child (a forced
+   * line, a trained network's favourite: rows that share a node would take turns anyway -- one wave-wide scan per
+   * simulation, the chosen slot patched in registers, is half the instructions of a turn in row form) */
+  uint32_t shX = t.tc.root; /* the shared node, its own stat slot and header */
+  uint32_t shown = rc.h1.x;
+  uint4 shh0 = rc.h0;
+  int lev0 = 0;             /* its level */
+  {
+    int n0 = (int)CO_META_NEDGES(rc.h0.z);
+    float denom0 = co_u2f(rc.h1.y);
+    LV(uint4, ev);
+    FOR_LANES_HOT { L(ev) = rc.ev[lane]; }
+    uint4 rcs = rc.cs;
+    for (;;) {
+      const int msel = bad < m ? bad : m;
+      uint32_t same_slot = CO_NONE; /* the child every simulation so far has taken, 0 = not one child (or a new one) */
+      uint4 first_bs = make_uint4(0u, 0u, 0u, 0u);
+      for (int j = 0; j < msel; ++j) {
+        CO_SBS(10, 1);
+        CO_PROF_ADD(w, 23, 1ull);
+        const float v_sqrt = co_vsqrt(w.c_puct, co_slot_visits(rcs));
+        LV(float, u);
+        FOR_LANES_HOT {
+          const float uu = co_puct_u(L(ev), denom0, v_sqrt);
+          L(u) = lane < n0 ? uu : CO_NEG_INF;
+        }
+        const float mx = WAVE_MAX_F32(u);
+        rcs = co_slot_pass(rcs);
+        if (!(mx > CO_NEG_INF)) {
+          CO_SBS(3, 1);
+          bad = j;
+          break;
+        }
+        LV(int, hit);
+        FOR_LANES_HOT { L(hit) = (L(u) == mx); }
+        const int le = co_ffs64(WAVE_BALLOT(hit)) - 1;
+        const uint4 bs = WAVE_BCAST(ev, le);
+        if (bs.x != CO_NONE && co_res_terminal(co_slot_result(bs))) {
+          CO_SBS(4, 1);
+          bad = j;
+          break;
+        }
+        const uint32_t child_slot = shX + 2u + (uint32_t)le;
+        const uint4 nv = bs.x == CO_NONE ? make_uint4(0u, co_f2u(1.0f), (bs.z & 0xFFFFu) | (1u << 16), 0x100u) : co_slot_pass(bs);
+        if (j == 0) {
+          same_slot = bs.x == CO_NONE ? 0u : child_slot;
+          first_bs = bs;
+        } else if (child_slot != same_slot) {
+          same_slot = 0u;
+        }
+        const uint32_t xb = shX, xo = shown;
+        const int lv = lev0;
+        FOR_LANES_HOT {
+          if (lane == le) L(ev) = nv;
+          if (lane == 0) {
+            sb_block[j * CO_SB_DEPTH + lv] = xb;
+            sb_slot[j * (CO_SB_DEPTH + 1) + lv] = xo;
+            sb_slot[j * (CO_SB_DEPTH + 1) + lv + 1] = child_slot;
+            sb_cs[j * CO_SB_DEPTH + lv] = rcs;
+            sb_hand[2 * j] = make_uint4(bs.x, child_slot, bs.z, 0u);
+            sb_hand[2 * j + 1] = bs;
+          }
+        }
+      }
+      WAVE_SYNC();
+      const int left = bad < m ? bad : m;
+      if (left < 2 || same_slot == 0u || same_slot == CO_NONE || lev0 + 3 >= CO_SB_DEPTH) break;
+      /* every simulation left went to the same visited child: that node is shared as well */
+      shX = first_bs.x;
+      shown = same_slot;
+      rcs = first_bs;
+      ++lev0;
+      CO_SBS(9, 1);
+      shh0 = co_load_unit(A, shX);
+      denom0 = co_u2f(co_load_unit(A, shX + 1u).y);
+      {
+        const uint32_t e0 = shX + 2u;
+        FOR_LANES_HOT { L(ev) = A[e0 + lane]; }
+      }
+      n0 = (int)CO_META_NEDGES(shh0.z);
+      if (n0 > CO_WAVE) { /* (a node wider than the wavefront: co_search's) */
+        CO_SBS(5, 1);
+        bad = 0;
+        break;
+      }
+    }
+  }
+  CO_PH(28);
+  /* ---- below the root: row j = simulation j */
+  LV(uint32_t, X);
+  LV(uint32_t, slot);
+  LV(uint4, cs);
+  LV(int, act);
+  LV(int, leafD);      /* level of the new leaf, 0 = none (yet) */
+  {
+    const int nsel = bad < m ? bad : m;
+    const uint4 rh0 = shh0;
+    const uint32_t root = shX;
+    FOR_LANES_HOT {
+      const int r = lane >> 4;
+      const uint4 h = sb_hand[2 * r], c = sb_hand[2 * r + 1];
+      const int valid = r < nsel;
+      const int isnew = valid && h.x == CO_NONE;
+      L(X) = h.x;
+      L(slot) = h.y;
+      L(cs) = c;
+      L(act) = valid && !isnew;
+      L(leafD) = isnew ? lev0 + 1 : 0;
+      if (isnew && (lane & 15) == 0) { /* a new edge of the shared node: the leaf is one level below it */
+        sb_leaf[2 * r] = make_uint4(rh0.x, rh0.y, rh0.z, root);
+        sb_leaf[2 * r + 1] = make_uint4(h.z & 0xFFFFu, h.y, 0u, 0u);
+      }
+    }
+  }
+  for (int lev = lev0 + 1;; ++lev) {
+    if (!WAVE_BALLOT(act)) break;
+    CO_SBS(9, 1);
+    if (lev + 1 >= CO_SB_DEPTH) { /* too deep for the group's records */
+      const int fr = (co_ffs64(WAVE_BALLOT(act)) - 1) >> 4;
+      CO_SBS(6, 1);
+      if (fr < bad) bad = fr;
+      break;
+    }
+    /* the nodes of this level: header and up to 64 edge slots, four per lane */
+    LV(uint4, h0);
+    LV(uint32_t, dnb);
+    LV(uint4, e0);
+    LV(uint4, e1);
+    LV(uint4, e2);
+    LV(uint4, e3);
+    FOR_LANES_HOT {
+      if (L(act)) {
+        const uint32_t b = L(X);
+        const uint32_t c = b + 2u + (uint32_t)(lane & 15);
+        L(h0) = A[b];
+        L(dnb) = A[b + 1u].y;
+        L(e0) = A[c]; /* the arena is padded: slots beyond the node's edges are read and not used */
+        L(e1) = A[c + 16u];
+        L(e2) = A[c + 32u];
+        L(e3) = A[c + 48u];
+      }
+    }
+    CO_PH_MEM(11);
+    LV(int, todo);
+    LV(int, wide);
+    FOR_LANES_HOT {
+      L(wide) = L(act) && (int)CO_META_NEDGES(L(h0).z) > CO_WAVE;
+      L(todo) = L(act) && !L(wide);
+    }
+    {
+      const uint64_t wm = WAVE_BALLOT(wide);
+      if (wm) {
+        const int fr = (co_ffs64(wm) - 1) >> 4;
+        CO_SBS(5, 1);
+        if (fr < bad) bad = fr;
+      }
+    }
+    for (;;) {
+      /* rows behind a simulation that is not ordinary are dropped */
+      FOR_LANES_HOT {
+        if ((lane >> 4) >= bad) {
+          L(todo) = 0;
+          L(act) = 0;
+        }
+      }
+      const uint64_t tm = WAVE_BALLOT(todo);
+      if (!tm) break;
+      /* a row waits while an earlier row of the same node has yet to scan it */
+      const uint32_t x0 = WAVE_BCAST(X, 0), x1 = WAVE_BCAST(X, 16), x2 = WAVE_BCAST(X, 32);
+      const int t0 = (int)(tm & 1ull), t1 = (int)((tm >> 16) & 1ull), t2 = (int)((tm >> 32) & 1ull);
+      LV(int, ready);
+      LV(float, bu);
+      LV(uint32_t, be);
+      LV(uint32_t, bx);
+      LV(uint32_t, by);
+      LV(uint32_t, bz);
+      LV(uint32_t, bw);
+      LV(float, vs);
+      FOR_LANES_HOT {
+        const int r = lane >> 4;
+        const int blocked = (r > 0 && t0 && x0 == L(X)) || (r > 1 && t1 && x1 == L(X)) || (r > 2 && t2 && x2 == L(X));
+        L(ready) = L(todo) && !blocked;
+        L(bu) = CO_NEG_INF;
+        L(be) = 255u;
+        L(bx) = L(by) = L(bz) = L(bw) = 0u;
+        L(vs) = co_vsqrt(w.c_puct, co_slot_visits(L(cs)));
+        if (L(ready)) {
+          CO_SBS(10, (lane & 15) == 0);
+          CO_PROF_ADD(w, 23, 0ull);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        LV(int, more);
+        FOR_LANES_HOT { L(more) = L(ready) && (int)CO_META_NEDGES(L(h0).z) > 16 * k; }
+        if (!WAVE_BALLOT(more)) break;
+        FOR_LANES_HOT {
+          const uint4 sl = k == 0 ? L(e0) : k == 1 ? L(e1) : k == 2 ? L(e2) : L(e3);
+          const int e = 16 * k + (lane & 15);
+          float uu = co_puct_u(sl, co_u2f(L(dnb)), L(vs));
+          uu = (L(ready) && e < (int)CO_META_NEDGES(L(h0).z)) ? uu : CO_NEG_INF;
+          if (uu > L(bu)) { /* strict: a lane keeps its first maximum */
+            L(bu) = uu;
+            L(be) = (uint32_t)e;
+            L(bx) = sl.x;
+            L(by) = sl.y;
+            L(bz) = sl.z;
+            L(bw) = sl.w;
+          }
+        }
+      }
+      LV(float, mx);
+      ROW_MAX_F32(mx, bu);
+      LV(uint32_t, cand);
+      FOR_LANES_HOT { L(cand) = (L(bu) == L(mx) && L(mx) > CO_NEG_INF) ? L(be) : 255u; }
+      LV(uint32_t, emin);
+      ROW_MIN_U32(emin, cand); /* the first maximum in edge order (trainmc.cpp:581: strictly greater) */
+      LV(int, col);
+      FOR_LANES_HOT { L(col) = (int)(L(emin) & 15u); }
+      ROW_SHFL_U32(bx, bx, col);
+      ROW_SHFL_U32(by, by, col);
+      ROW_SHFL_U32(bz, bz, col);
+      ROW_SHFL_U32(bw, bw, col);
+      /* what the scan did: this node's own slot, the records, the leaf or the child, the patch for rows that wait */
+      LV(int, isbad);
+      LV(int, fin);
+      LV(uint32_t, pX);
+      LV(uint4, nv);
+      FOR_LANES_HOT {
+        L(isbad) = 0;
+        L(fin) = L(ready);
+        L(pX) = L(X);
+        L(nv) = make_uint4(0u, 0u, 0u, 0u);
+        if (L(ready)) {
+          const int r = lane >> 4;
+          const uint4 bs = make_uint4(L(bx), L(by), L(bz), L(bw));
+          const int none = L(emin) == 255u;
+          const int isnew = bs.x == CO_NONE;
+          const int term = !isnew && co_res_terminal(co_slot_result(bs));
+          L(cs) = co_slot_pass(L(cs));
+          L(isbad) = none || term;
+          const uint32_t child_slot = L(X) + 2u + L(emin);
+          if (!L(isbad)) {
+            if ((lane & 15) == 0) {
+              sb_block[r * CO_SB_DEPTH + lev] = L(X);
+              sb_slot[r * (CO_SB_DEPTH + 1) + lev] = L(slot);
+              sb_slot[r * (CO_SB_DEPTH + 1) + lev + 1] = child_slot;
+              sb_cs[r * CO_SB_DEPTH + lev] = L(cs);
+            }
+            if (isnew) {
+              L(nv) = make_uint4(0u, co_f2u(1.0f), (bs.z & 0xFFFFu) | (1u << 16), 0x100u);
+              L(leafD) = lev + 1;
+              if ((lane & 15) == 0) {
+                sb_leaf[2 * r] = make_uint4(L(h0).x, L(h0).y, L(h0).z, L(X));
+                sb_leaf[2 * r + 1] = make_uint4(bs.z & 0xFFFFu, child_slot, 0u, 0u);
+              }
+              L(act) = 0;
+            } else {
+              L(nv) = co_slot_pass(bs);
+              L(X) = bs.x;
+              L(slot) = child_slot;
+              L(cs) = bs;
+            }
+          } else {
+            if (none) CO_SBS(3, (lane & 15) == 0);
+            else CO_SBS(4, (lane & 15) == 0);
+            L(act) = 0;
+          }
+          L(todo) = 0;
+        }
+      }
+      {
+        const uint64_t bm = WAVE_BALLOT(isbad);
+        if (bm) {
+          const int fr = (co_ffs64(bm) - 1) >> 4;
+          if (fr < bad) bad = fr;
+        }
+      }
+      /* rows that wait at a node one of the finished rows has just scanned: take its change */
+      const uint64_t fm = WAVE_BALLOT(fin), wm2 = WAVE_BALLOT(todo);
+      if (wm2) {
+#pragma unroll
+        for (int r2 = 0; r2 < CO_SB - 1; ++r2) {
+          if (!((fm >> (16 * r2)) & 1ull)) continue;
+          const uint32_t px = WAVE_BCAST(pX, 16 * r2);
+          const uint32_t pe = WAVE_BCAST(emin, 16 * r2);
+          const uint4 pv = WAVE_BCAST(nv, 16 * r2);
+          FOR_LANES_HOT {
+            if (L(todo) && (lane >> 4) > r2 && L(X) == px && (uint32_t)(lane & 15) == (pe & 15u)) {
+              CO_SBS(11, 1);
+              const uint32_t k = pe >> 4;
+              if (k == 0u) L(e0) = pv;
+              else if (k == 1u) L(e1) = pv;
+              else if (k == 2u) L(e2) = pv;
+              else L(e3) = pv;
+            }
+          }
+        }
+      }
+    }
+    CO_PH(8);
+  }
+  WAVE_SYNC();
+  /* ---- expand: the four leaves at once, one per row (rules.h co_legal_moves_rows) */
+  int nsel = bad < m ? bad : m;
+  LV(int, on);
+  LV(uint32_t, nb0);
+  LV(uint32_t, nb1);
+  LV(uint32_t, nmeta);
+  LV(uint32_t, l0);
+  LV(uint32_t, l1);
+  LV(uint32_t, l2);
+  LV(int, nl); /* legal moves of the row's leaf */
+  LV(uint32_t, lz);    /* the chosen slot's move and prior */
+  LV(uint32_t, lpar);  /* the leaf's parent block, the leaf's slot, the parent's meta word */
+  LV(uint32_t, lslot);
+  LV(uint32_t, lmeta);
+  FOR_LANES_HOT {
+    L(on) = (lane >> 4) < nsel;
+    const uint4 la = sb_leaf[2 * (lane >> 4)], lb = sb_leaf[2 * (lane >> 4) + 1];
+    L(lz) = lb.x;
+    L(lslot) = lb.y;
+    L(lpar) = la.w;
+    L(lmeta) = la.z;
+    uint64_t b = (uint64_t)la.x | ((uint64_t)la.y << 32);
+    uint32_t mm = la.z;
+    if (L(on)) co_do_move_lane(&b, &mm, (int)(L(lz) & 127u));
+    L(nb0) = (uint32_t)b;
+    L(nb1) = (uint32_t)(b >> 32);
+    L(nmeta) = mm;
+  }
+  LV(int, lin);
+  co_legal_moves_rows(nb0, nb1, nmeta, on, l0, l1, l2, lin, w.lb);
+  FOR_LANES_HOT { L(nl) = L(on) ? co_popc32(L(l0)) + co_popc32(L(l1)) + co_popc32(L(l2)) : 0; }
+  int term = -1; /* the simulation whose new leaf is terminal: committed behind the others, ends the group */
+  {
+    /* a terminal leaf ends the group behind it, a full arena in front of it (co_search reports it); the others get
+     * their blocks */
+    uint32_t used = t.tc.units_used;
+    int j = 0;
+    for (; j < nsel; ++j) {
+      const int n = WAVE_BCAST(nl, 16 * j);
+      if (used + 2u + (uint32_t)n > t.cap) break;
+      if (n == 0) {
+        CO_SBS(7, 1);
+        term = j;
+        break;
+      }
+      used += 2u + (uint32_t)n;
+    }
+    if (j < nsel && term < 0) bad = j; /* (not ordinary, and not handled here) */
+    nsel = j;
+  }
+  CO_PH(14);
+  int done = nsel;
+  if (nsel > 0) {
+    const int n0 = WAVE_BCAST(nl, 0), n1 = WAVE_BCAST(nl, 16), n2 = WAVE_BCAST(nl, 32), n3 = WAVE_BCAST(nl, 48);
+    const uint32_t base0 = t.tc.units_used;
+    const int noise0 = w.noise_words, k0 = w.gc.n_pending;
+    /* ---- commit.  (1) the slots the simulations passed through: every (simulation, level) one lane; a slot several
+     * simulations of the group passed takes the LAST one's value (it has the earlier passes in it) */
+    const int dl[CO_SB] = {WAVE_BCAST(leafD, 0), WAVE_BCAST(leafD, 16), WAVE_BCAST(leafD, 32), WAVE_BCAST(leafD, 48)};
+    FOR_LANES_HOT {
+      const int r = lane >> 4, c = lane & 15;
+      if (r < nsel && c < L(leafD)) {
+        const uint32_t sl = sb_slot[r * (CO_SB_DEPTH + 1) + c];
+        int last = 1;
+#pragma unroll
+        for (int r2 = 1; r2 < CO_SB; ++r2)
+          if (r2 > r && r2 < nsel && c < dl[r2] && sb_slot[r2 * (CO_SB_DEPTH + 1) + c] == sl) last = 0;
+        if (last) {
+          const uint4 v = sb_cs[r * CO_SB_DEPTH + c];
+          A[sl] = v;
+          const uint32_t idx = sl - rc.e0;
+          if (idx < rc.ne) rc.ev[idx] = v;
+        }
+      }
+    }
+    for (int j = 0; j < nsel; ++j) rc.cs = co_slot_pass(rc.cs);
+    CO_PH(9);
+    /* (2) the new nodes: blocks in simulation order (the bump pointer of the sequential search), header, edges in
+     * ascending move id */
+    LV(uint32_t, nblk);
+    LV(int, noff); /* generator outputs owed to the leaves queued before this one */
+    FOR_LANES_HOT {
+      const int r = lane >> 4, c = lane & 15;
+      const uint32_t before = (r > 0 ? 2u + (uint32_t)n0 : 0u) + (r > 1 ? 2u + (uint32_t)n1 : 0u) + (r > 2 ? 2u + (uint32_t)n2 : 0u);
+      L(nblk) = base0 + before;
+      L(noff) = noise0 + (r > 0 ? n0 : 0) + (r > 1 ? n1 : 0) + (r > 2 ? n2 : 0);
+      if (r < nsel) {
+        const uint32_t b = L(nblk);
+        const int depth = (int)CO_META_DEPTH(L(lmeta)) + 1;
+        if (c == 0) A[b] = make_uint4(L(nb0), L(nb1), co_meta_make(L(nmeta), depth, L(nl)), L(lpar));
+        if (c == 1) A[b + 1] = make_uint4(L(lslot), 0u, 0u, 0u);
+        const int c0 = co_popc32(L(l0)), c01 = c0 + co_popc32(L(l1));
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          const int id = 16 * q + c;
+          const uint32_t wd = q < 2 ? L(l0) : q < 4 ? L(l1) : L(l2);
+          const int bit = id & 31;
+          if ((wd >> bit) & 1u) {
+            const int rank = (q < 2 ? 0 : q < 4 ? c0 : c01) + co_popc32(wd & ((1u << bit) - 1u));
+            A[b + 2u + (uint32_t)rank] = make_uint4(CO_NONE, 0u, (uint32_t)id, 0u);
+          }
+        }
+        /* (3) the leaf's own slot, in its parent's block (and in the root copy when the parent is the root) */
+        if (c == 2) {
+          const uint4 v = make_uint4(b, co_f2u(1.0f), L(lz) | (1u << 16), (uint32_t)CO_RESULT_NONE | 0x100u);
+          A[L(lslot)] = v;
+          const uint32_t idx = L(lslot) - rc.e0;
+          if (idx < rc.ne) rc.ev[idx] = v;
+        }
+      }
+    }
+    {
+      const uint32_t units = 2u * (uint32_t)nsel + (uint32_t)(n0 + (nsel > 1 ? n1 : 0) + (nsel > 2 ? n2 : 0) + (nsel > 3 ? n3 : 0));
+      t.tc.units_used = base0 + units;
+      if (t.tc.units_used > t.tc.peak_units) t.tc.peak_units = t.tc.units_used;
+      w.gc.nodes += (uint32_t)nsel;
+      t.tc.searches_done += nsel;
+      w.gc.searches += (uint32_t)nsel;
+    }
+    CO_PH(15);
+    CO_PROF_ADD(w, 24, (unsigned long long)nsel);
+    if (w.analyse) {
+      /* Node::countNodes without a traversal (co_search): every node of a path counts the new node below it */
+      for (int j = 0; j < nsel; ++j) {
+        const int D = WAVE_BCAST(leafD, 16 * j);
+        FOR_LANES_HOT {
+          if (lane < D) A[sb_block[j * CO_SB_DEPTH + lane] + 1].z += 1u;
+        }
+        WAVE_SYNC();
+      }
+    }
+    /* (4) the requests (co_request): state rows, pending-leaf records, cache keys -- leaf k0 + r from row r */
+    {
+      float *req = w.req;
+      uint32_t *pend_leaf = w.pend_leaf, *pend_path = w.pend_path, *pend_n = w.pend_n;
+      int32_t *pend_depth = w.pend_depth;
+      uint4 *pend_key = w.pend_key;
+      FOR_LANES_HOT {
+        const int r = lane >> 4, c = lane & 15;
+        if (r < nsel) {
+          const int k = k0 + r;
+          const uint64_t b = (uint64_t)L(nb0) | ((uint64_t)L(nb1) << 32);
+          /* Game::writeGameState (game.cpp:45-58): a lane writes its cell's four floats, lanes 0..3 the reserves (the
+           * mover's first) and the padding */
+          uint4 *row = (uint4 *)(req + (size_t)k * CO_STATE_STRIDE);
+          const uint32_t nib = (uint32_t)(b >> (4 * c)) & 15u;
+          const uint32_t one = co_f2u(1.0f);
+          row[c] = make_uint4((nib & 1u) ? one : 0u, (nib & 2u) ? one : 0u, (nib & 4u) ? one : 0u, (nib & 8u) ? one : 0u);
+          const uint32_t pcs = L(nmeta) & 0x3FFFFu;
+          const uint32_t rot = CO_META_TO_PLAY(L(nmeta)) ? ((pcs >> 9) | (pcs << 9)) & 0x3FFFFu : pcs;
+          if (c < 4) {
+            uint32_t f[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int x = 4 * c + i;
+              f[i] = x < 6 ? co_f2u((float)((rot >> (3 * x)) & 7u) * 0.25f) : 0u;
+            }
+            row[16 + c] = make_uint4(f[0], f[1], f[2], f[3]);
+          }
+          if (c == 4) {
+            pend_leaf[k] = L(nblk);
+            pend_depth[k] = L(leafD);
+          }
+          if (c >= 5 && c < 9) pend_n[4 * k + (c - 5)] = c == 5 ? (((uint32_t)L(noff) << 8) | (uint32_t)L(nl)) : c == 6 ? L(l0) : c == 7 ? L(l1) : L(l2);
+          if (c == 9 && pend_key) pend_key[k] = make_uint4(L(nb0), L(nb1), rot | 0x80000000u, 0u);
+          if (c <= L(leafD)) pend_path[(size_t)k * CO_PATH_MAX + c] = sb_slot[r * (CO_SB_DEPTH + 1) + c];
+        }
+      }
+      w.gc.n_pending = k0 + nsel;
+      w.noise_words = noise0 + n0 + (nsel > 1 ? n1 : 0) + (nsel > 2 ? n2 : 0) + (nsel > 3 ? n3 : 0);
+    }
+    WAVE_SYNC();
+    CO_PH(17);
+  }
+  if (term >= 0) {
+    /* ---- the terminal leaf of simulation `term` (trainmc.cpp:663-682), on the tree the simulations before it have been
+     * committed to: its passes, the node, the result carried up (propagateTerminal), the default evaluations of its path
+     * replaced by the result.  The root copy is dropped: the caller loads it again and looks at the root's result. */
+    const int j = term;
+    const int D = WAVE_BCAST(leafD, 16 * j);
+    const uint64_t board = (uint64_t)WAVE_BCAST(nb0, 16 * j) | ((uint64_t)WAVE_BCAST(nb1, 16 * j) << 32);
+    const uint32_t meta = WAVE_BCAST(nmeta, 16 * j), z = WAVE_BCAST(lz, 16 * j), parent = WAVE_BCAST(lpar, 16 * j);
+    const uint32_t child_slot = WAVE_BCAST(lslot, 16 * j);
+    const int depth = (int)CO_META_DEPTH(WAVE_BCAST(lmeta, 16 * j)) + 1;
+    const int res = WAVE_BCAST(lin, 16 * j) ? CO_RESULT_LOSS : CO_RESULT_DRAW;
+    uint32_t *pslot = &sb_slot[j * (CO_SB_DEPTH + 1)];
+    uint32_t *pblock = &sb_block[j * CO_SB_DEPTH];
+    ++t.tc.searches_done;
+    w.gc.searches++;
+    FOR_LANES_HOT {
+      if (lane < D) {
+        const uint32_t sl = pslot[lane];
+        const uint4 v = sb_cs[j * CO_SB_DEPTH + lane];
+        A[sl] = v;
+        const uint32_t idx = sl - rc.e0;
+        if (idx < rc.ne) rc.ev[idx] = v;
+      }
+    }
+    WAVE_SYNC();
+    const uint32_t none[3] = {0u, 0u, 0u};
+    const uint32_t nb = co_emit_node(w, t, board, meta, depth, parent, child_slot, none, 0, res);
+    if (nb != CO_NONE) {
+      if (w.analyse) {
+        FOR_LANES_HOT {
+          if (lane < D) A[pblock[lane] + 1].z += 1u;
+        }
+        WAVE_SYNC();
+      }
+      const float cur_eval = res == CO_RESULT_DRAW ? 0.0f : -1.0f;
+      co_store_slot(A, child_slot, make_uint4(nb, co_f2u(cur_eval), z | (1u << 16), (uint32_t)res | 0x100u), rc);
+      co_propagate_terminal(t, pblock, pslot, D);
+      FOR_LANES_HOT {
+        if (lane < D) {
+          int kk = D - lane; /* kk-th ancestor receives eval*(-1)^(kk-1) - 1 */
+          float ce = ((kk - 1) & 1) ? (float)((double)cur_eval * -1.0) : cur_eval;
+          float add = (float)((double)ce - 1.0);
+          uint4 s = A[pslot[lane]];
+          s.y = co_f2u(co_u2f(s.y) + add);
+          A[pslot[lane]] = s;
+        }
+      }
+      WAVE_SYNC();
+      CO_PROF_ADD(w, 5, 1ull);
+    }
+    rc.valid = 0;
+    CO_PH(12);
+  }
+  CO_SBS(0, 1);
+  CO_SBS(1, m);
+  CO_SBS(2, done);
+  CO_SBP(w, 0, 1);
+  CO_SBP(w, 1, m);
+  CO_SBP(w, 2, done);
+  CO_SBP(w, 3, term >= 0);
+  CO_SBP(w, 4, term < 0 && done < m);
+  CO_SBS(12 + done, 1);
+  CO_PROF_ADD(w, 5, (unsigned long long)done);
+  /* simulations committed | 0x100: a terminal leaf behind them ended the group (done here) | 0x200: the group stopped at a
+   * simulation that is neither ordinary nor a terminal leaf -- the caller's next simulation takes co_search */
+  return done | (term >= 0 ? 0x100 : 0) | (term < 0 && done < m ? 0x200 : 0);
+}
+#endif
+
 /* the root asks for its own evaluation (trainmc.cpp:143-167, 198-202) */
 CO_DEV void co_request_root(CoWave &w, CoTree &t) {
   uint4 *A = t.A;
@@ -777,7 +1438,7 @@ CO_DEV void co_request_root(CoWave &w, CoTree &t) {
   WAVE_SYNC();
   uint64_t board = (uint64_t)h0.x | ((uint64_t)h0.y << 32);
   uint32_t lm[3];
-  co_legal_moves(board, h0.z, lm, w.K); /* (a root asks once per tree; its edges hold the same moves) */
+  co_legal_moves1(board, h0.z, lm); /* (a root asks once per tree; its edges hold the same moves) */
   co_request(w, board, h0.z, root, (int)CO_META_NEDGES(h0.z), lm, 0, one_path);
 }
 
@@ -808,6 +1469,9 @@ CO_DEV int co_mc_do_iteration(CoWave &w, CoTree &t, const float *eval, const flo
   rc.ev = root_ev;
   rc.e0 = 0u;
   rc.ne = 0u;
+#if CO_SB > 1
+  int cap = w.gc.sb_cap > 0 && w.gc.sb_cap < CO_SB ? w.gc.sb_cap : CO_SB;
+#endif
   for (;;) {
     if (!(w.gc.n_pending < w.spe && t.tc.searches_done < w.max_searches)) break;
     if (!rc.valid) co_root_load(t, rc);
@@ -815,9 +1479,35 @@ CO_DEV int co_mc_do_iteration(CoWave &w, CoTree &t, const float *eval, const flo
     if (co_res_known(co_slot_result(rc.cs)) || co_slot_all_visited(rc.cs)) break;
     if (w.gc.error) break;
     CO_PH_MEM(20);
+#if CO_SB > 1
+    {
+      /* How many to select together: everything behind a simulation that is not ordinary is selected in vain, so a
+       * position whose simulations keep ending in terminal leaves (endgames: a quarter of them and more) gets groups of
+       * the size that would just have fitted, and grows back by doubling. */
+      int m = w.spe - w.gc.n_pending;
+      if (w.max_searches - t.tc.searches_done < m) m = w.max_searches - t.tc.searches_done;
+      if (m > cap) m = cap;
+      if (m > 1 && (int)CO_META_NEDGES(rc.h0.z) <= CO_WAVE) {
+        const int r = co_search_rows(w, t, rc, m);
+        if (!(r & 0x300)) {
+          cap = 2 * cap < CO_SB ? 2 * cap : CO_SB;
+          continue;
+        }
+        cap = (r & 0xFF) + 1 < CO_SB ? (r & 0xFF) + 1 : CO_SB;
+        if (r & 0x100) continue;
+      } else if (cap < 2) {
+        cap = 2;
+      }
+    }
+#endif
+    CO_SBS(8, 1);
+    CO_SBP(w, 6, 1);
     co_search(w, t, rc);
     CO_PROF_ADD(w, 5, 1ull);
   }
+#if CO_SB > 1
+  w.gc.sb_cap = cap;
+#endif
   rs = co_load_unit(t.A, co_load_unit(t.A, t.tc.root + 1).x);
   return (t.tc.searches_done == w.max_searches || co_res_known(co_slot_result(rs))) && w.gc.n_pending == 0;
 }
@@ -840,7 +1530,7 @@ CO_DEV void co_reset_tree_to_child(CoWave &w, CoTree &t, int choice) {
   uint64_t board = (uint64_t)h0.x | ((uint64_t)h0.y << 32);
   uint32_t meta = h0.z;
   int depth = (int)CO_META_DEPTH(meta) + 1;
-  co_do_move(&board, &meta, choice, w.K);
+  co_do_move_lane(&board, &meta, choice);
   int res;
   uint32_t b = co_create_node(w, t, board, meta, depth, CO_NONE, CO_NONE, &res);
   if (b == CO_NONE) return;
@@ -948,7 +1638,7 @@ CO_DEV void co_log_ply(CoWave &w, CoTree &t, uint4 (&ch)[CO_NUM_MOVES]) {
 
 /* TrainMC::chooseMove and its four variants, trainmc.cpp:110-137, 298-473.
  * sample = this ply's (state[70], policy[96]) row, or null in testing mode. */
-CO_DEV int co_choose_move(CoWave &w, CoTree &t, float *sample) {
+CO_COLD int co_choose_move(CoWave &w, CoTree &t, float *sample) {
   uint4 *A = t.A;
   uint32_t root = t.tc.root;
   uint4 h0 = co_load_unit(A, root);
@@ -1053,7 +1743,7 @@ CO_DEV int co_choose_move(CoWave &w, CoTree &t, float *sample) {
         co_reset_tree_to_child(w, t, choice);
         return choice;
       }
-      int32_t target = (int32_t)(co_mt_next(w.mt, &w.gc.rng_idx) % (uint32_t)visits);
+      int32_t target = (int32_t)(co_wave_mt_next(w) % (uint32_t)visits);
       int32_t total = 0;
       for (int e = 0; e < n; ++e) {
         if (ch[e].x == CO_NONE || co_res_won(co_slot_result(ch[e]))) continue;
@@ -1120,7 +1810,7 @@ CO_DEV int co_choose_move(CoWave &w, CoTree &t, float *sample) {
 
 /* TrainMC::receiveOpponentMove, trainmc.cpp:180-204.  (board, meta) is the
  * opponent's new root position.  Returns "needs an evaluation". */
-CO_DEV int co_receive_opponent_move(CoWave &w, CoTree &t, int move_choice, uint64_t board, uint32_t meta_game,
+CO_COLD int co_receive_opponent_move(CoWave &w, CoTree &t, int move_choice, uint64_t board, uint32_t meta_game,
                                     int depth) {
   uint4 *A = t.A;
   uint32_t root = t.tc.root;
@@ -1168,12 +1858,12 @@ CO_DEV void co_use_player(CoWave &w, int p) {
  * (GCC >= 11) computes it on a 32-bit generator: Lemire's nearly divisionless method, one
  * 64-bit product per draw, a draw consumed even for n == 1 */
 CO_DEV uint32_t co_uniform_below(CoWave &w, uint32_t n) {
-  unsigned long long product = (unsigned long long)co_mt_next(w.mt, &w.gc.rng_idx) * (unsigned long long)n;
+  unsigned long long product = (unsigned long long)co_wave_mt_next(w) * (unsigned long long)n;
   uint32_t low = (uint32_t)product;
   if (low < n) {
     uint32_t threshold = (0u - n) % n;
     while (low < threshold) {
-      product = (unsigned long long)co_mt_next(w.mt, &w.gc.rng_idx) * (unsigned long long)n;
+      product = (unsigned long long)co_wave_mt_next(w) * (unsigned long long)n;
       low = (uint32_t)product;
     }
   }
@@ -1203,7 +1893,7 @@ CO_DEV void co_analyse_finish(CoWave &w, CoTree &t, int choice) {
   uint4 h1 = co_load_unit(t.A, t.tc.root + 1);
   uint4 rs = co_load_unit(t.A, h1.x);
   uint32_t lm[3];
-  co_legal_moves((uint64_t)h0.x | ((uint64_t)h0.y << 32), h0.z, lm, w.K);
+  co_legal_moves1((uint64_t)h0.x | ((uint64_t)h0.y << 32), h0.z, lm);
   uint32_t *out = (uint32_t *)w.req;
   FOR_LANES {
     if (lane == 0) {
@@ -1260,14 +1950,14 @@ CO_DEV int co_game_step(CoWave &w, const float *eval, const float *probs) {
       board = (uint64_t)w.gc.pos_lo | ((uint64_t)w.gc.pos_hi << 32);
       meta = w.gc.pos_meta;
       uint32_t lm[3];
-      co_legal_moves(board, meta, lm, w.K);
+      co_legal_moves1(board, meta, lm);
       int n = co_popc32(lm[0]) + co_popc32(lm[1]) + co_popc32(lm[2]);
       choice = co_nth_move(lm, (int)co_uniform_below(w, (uint32_t)n));
       co_trace_push(w, -2);
       co_trace_push(w, choice);
       w.gc.plies++;
-      co_do_move(&board, &meta, choice, w.K);
-      int lines = co_legal_moves(board, meta, lm, w.K);
+      co_do_move_lane(&board, &meta, choice);
+      int lines = co_legal_moves1(board, meta, lm);
       terminal = (lm[0] | lm[1] | lm[2]) == 0u;
       tres = lines ? CO_RESULT_LOSS : CO_RESULT_DRAW;
       depth = w.gc.plies; /* root_->depth() */
@@ -1414,7 +2104,7 @@ CO_DEV uint32_t co_cache_hash(uint32_t k0, uint32_t k1, uint32_t k2) {
   return h ^ (h >> 15);
 }
 
-/* rows [row0, row0 + n) of the pool's batch = the pending leaves 0 .. n - 1 of game g (keys in w.pend_key) */
+/* request rows [row0, row0 + n) of `req` = the pending leaves 0 .. n - 1 of game g (keys in w.pend_key) */
 CO_DEV void co_cache_resolve(const EngineParams &P, CoWave &w, int g, int n, int row0) {
   const EvalCache &C = P.cache;
   const int par = P.iteration & 1;
@@ -1526,7 +2216,6 @@ CO_DEV void co_pool_housekeeping(const EngineParams &P, int g) {
 CO_DEV void co_wave_init(const EngineParams &P, int g, const GameCtl &gc, const TreeCtl &tc0, const TreeCtl &tc1, CoWave &w) {
   w.g = g;
   w.gc = gc;
-  co_lanes_init(w.K);
   {
     const size_t stride = (size_t)P.cap_units + CO_ARENA_PAD;
     const int tm = 2 * g + gc.to_play, to = 2 * g + 1 - gc.to_play;
@@ -1572,7 +2261,7 @@ CO_DEV void co_wave_init(const EngineParams &P, int g, const GameCtl &gc, const 
 
 /* The slot's game is over: file it, and in a resident-slot pool hand the slot the next unstarted game.  Returns 1 when
  * a fresh game sits in the slot (its first step -- root + request for its evaluation -- is the caller's next pass). */
-CO_DEV int co_slot_next_game(const EngineParams &P, CoWave &w) {
+CO_COLD int co_slot_next_game(const EngineParams &P, CoWave &w) {
   w.gc.done = 1;
   if (!P.results) return 0;
   {
@@ -1599,6 +2288,7 @@ CO_DEV int co_slot_next_game(const EngineParams &P, CoWave &w) {
   fresh.plies = 0; fresh.searches = 0u; fresh.evals = 0u; fresh.nodes = 0u; fresh.trace_len = 0;
   fresh.row_off = 0; fresh.resume = 0; fresh.pos_lo = 0u; fresh.pos_hi = 0u; fresh.pos_meta = CO_META_START;
   fresh.gid = gid;
+  fresh.sb_cap = 0;
   w.gc = fresh;
   w.me.tc.root = CO_NONE; w.me.tc.searches_done = 0; w.me.tc.units_used = 0u;   /* peak_units: high-water of the slot */
   w.opp.tc.root = CO_NONE; w.opp.tc.searches_done = 0; w.opp.tc.units_used = 0u;
@@ -1607,6 +2297,7 @@ CO_DEV int co_slot_next_game(const EngineParams &P, CoWave &w) {
   w.trace = P.trace ? P.trace + (size_t)gid * CO_TRACE_CAP : (int32_t *)0;
   w.log = (int32_t *)0; /* logged games are the first ones: they start in their own slots */
   co_mt_seed(w.mt, P.seeds[gid]);
+  w.mt_staged = 0;
   return 1;
 }
 
@@ -1616,33 +2307,26 @@ CO_DEV int co_slot_next_game(const EngineParams &P, CoWave &w) {
 CO_DEV void co_step_tail(const EngineParams &P, CoWave &w, int g, int done) {
   const int packs = P.fused_pack && !w.gc.done && !w.gc.error;
   unsigned long long old = 0ull;
+  CO_PH_MEM(25);
   if (packs) old = co_atomic_add_u64(P.pack_counter + (P.iteration & 1), (1ull << 32) | (unsigned long long)w.gc.n_pending);
+  CO_PH_MEM(26);
   if (!done && !w.gc.error && w.gc.n_pending > 0) co_capture_noise(w);
+  CO_PH_MEM(27);
   if (packs) {
     const int n = w.gc.n_pending;
     const int base = P.pool_row_base + (int)(unsigned)(old & 0xFFFFFFFFull);
     w.gc.row_off = base;
-    if (w.pend_key) co_cache_resolve(P, w, g, n, base - P.pool_row_base);
-    /* rows are 80 floats = 20 16-byte units, contiguous on both sides; five units per lane and pass,
-     * loads first */
-    const uint4 *src = (const uint4 *)w.req;
-    uint4 *dst = (uint4 *)(P.nn_in + (size_t)base * CO_STATE_STRIDE);
-    const int total = n * (CO_STATE_STRIDE / 4);
-    for (int b0 = 0; b0 < total; b0 += 5 * CO_WAVE) {
-      LV(uint4, v[5]);
+    /* the rows stay in the game's request area; the network kernels read them through an index array (nn.h CoNetIO):
+     * with the evaluation cache the rows it has to evaluate (co_cache_resolve), else every row of the batch.  (Until
+     * round 5 the rows were copied into a compact batch here: 5 KB read back and written again at the end of every
+     * step, 35 k cycles of the wave's 190 k with two pools in flight.) */
+    const int first = g * P.searches_per_eval;
+    if (w.pend_key) {
+      co_cache_resolve(P, w, g, n, first);
+    } else {
+      int32_t *ri = P.row_idx + base;
       FOR_LANES {
-#pragma unroll
-        for (int j = 0; j < 5; ++j) {
-          const int i = b0 + j * CO_WAVE + lane;
-          L(v[j]) = src[i < total ? i : 0];
-        }
-      }
-      FOR_LANES {
-#pragma unroll
-        for (int j = 0; j < 5; ++j) {
-          const int i = b0 + j * CO_WAVE + lane;
-          if (i < total) dst[i] = L(v[j]);
-        }
+        if (lane < n) ri[lane] = first + lane;
       }
     }
   }
@@ -1671,12 +2355,19 @@ CO_DEV void co_mcts_step_wave(const EngineParams &P, int g) {
     return;
   }
   CoWave w;
+  WAVE_SHARED(uint32_t, mt_stage, CO_MT_STAGE);
+  w.mt_stage = mt_stage;
+  WG_SHARED(uint32_t, lb, CO_LB_WORDS);
+  co_line_breakers_to_lds(lb);
+  w.lb = lb;
 #if defined(CO_PROF) && !defined(CO_EMU)
   const unsigned long long t_wave0 = CO_CLK(), t_real0 = __builtin_amdgcn_s_memrealtime();
   for (int i = 0; i < CO_NPROF; ++i) w.pacc[i] = 0ull;
   w.tph = t_wave0;
 #endif
   co_wave_init(P, g, gc, tc0, tc1, w);
+  co_mt_stage_load(w.mt, w.mt_stage);
+  w.mt_staged = 1;
   CO_PROF_ADD(w, 4, 1ull);
   CO_PH_MEM(22);
   int off = co_step_row(P, g, gc);
@@ -1702,6 +2393,12 @@ CO_DEV void co_mcts_step_wave(const EngineParams &P, int g) {
       glob[1] += __builtin_amdgcn_s_memrealtime() - t_real0;
     }
     atomicMax(glob + 2, dt);
+#ifndef CO_PROF_SLOW_FROM
+#define CO_PROF_SLOW_FROM 0
+#endif
+    if (dt > 280000ull && P.iteration >= CO_PROF_SLOW_FROM) { /* the waves a launch waits for: their phases apart (slot 4 counts them) */
+      for (int i = 0; i < CO_NPROF; ++i) atomicAdd(glob + 24 + i, w.pacc[i]);
+    }
     int bucket = (int)(dt / 50000ull);
     if (bucket > 15) bucket = 15;
     atomicAdd(glob + 4 + bucket, 1ull);

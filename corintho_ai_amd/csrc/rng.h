@@ -57,6 +57,69 @@ CO_DEV void co_mt_twist(uint32_t *mt) {
   }
 }
 
+/* The same through a staging copy in the wavefront's LDS (st: CO_MT_STAGE words).  The twist above is ten dependent
+ * trips to memory (a chunk reads what the chunk before it stored), 25-40 k cycles at the end of three steps out of four
+ * (round 5 stamps: a fifth of the search kernel's wave time); here the old state is fetched in one trip, the ten dependent
+ * passes run in LDS, and the new words are stored behind them -- and stay in st for the caller. */
+#define CO_MT_STAGE 640
+/* the state -> st */
+CO_DEV void co_mt_stage_load(const uint32_t *mt, uint32_t *st) {
+  LV(uint32_t, x[10]);
+  FOR_LANES {
+#pragma unroll
+    for (int c = 0; c < 10; ++c) {
+      const int i = c * CO_WAVE + lane;
+      L(x[c]) = mt[i < CO_MT_N ? i : 0];
+    }
+  }
+  FOR_LANES {
+#pragma unroll
+    for (int c = 0; c < 10; ++c) {
+      const int i = c * CO_WAVE + lane;
+      if (i < CO_MT_N) st[i] = L(x[c]);
+    }
+  }
+  WAVE_SYNC();
+}
+/* st holds the state: twist it there, then store the new state to mt.  (The stores come BEHIND the ten passes, in one
+ * run: issued inside the passes, between the LDS reads each pass waits for, every one of them held the wave for
+ * 1.6 k cycles -- 8 k in a wave that was slow anyway; round 5, tools/prof_phases.py: 20 k cycles per twist against 5 k.) */
+CO_DEV void co_mt_twist_staged(uint32_t *mt, uint32_t *st) {
+  for (int c = 0; c < (CO_MT_N + CO_WAVE - 1) / CO_WAVE; ++c) {
+    LV(uint32_t, nv);
+    FOR_LANES {
+      int i = c * CO_WAVE + lane;
+      if (i < CO_MT_N) {
+        int i1 = i + 1 == CO_MT_N ? 0 : i + 1;
+        int im = i + 397 >= CO_MT_N ? i + 397 - CO_MT_N : i + 397;
+        uint32_t y = (st[i] & 0x80000000u) | (st[i1] & 0x7fffffffu);
+        L(nv) = st[im] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+      }
+    }
+    WAVE_SYNC();
+    FOR_LANES {
+      int i = c * CO_WAVE + lane;
+      if (i < CO_MT_N) st[i] = L(nv);
+    }
+    WAVE_SYNC();
+  }
+  LV(uint32_t, x[10]);
+  FOR_LANES {
+#pragma unroll
+    for (int c = 0; c < 10; ++c) {
+      const int i = c * CO_WAVE + lane;
+      L(x[c]) = st[i < CO_MT_N ? i : 0];
+    }
+  }
+  FOR_LANES {
+#pragma unroll
+    for (int c = 0; c < 10; ++c) {
+      const int i = c * CO_WAVE + lane;
+      if (i < CO_MT_N) mt[i] = L(x[c]);
+    }
+  }
+}
+
 /* Draw `n` (<= 64) consecutive outputs: lane j < n receives output number j.
  * `idx` is the game's position in the state (uniform, updated). */
 #define CO_MT_DRAW(mt, idx, n, outvar)                          \

@@ -225,6 +225,213 @@ CO_DEV void co_do_move(uint64_t *board, uint32_t *meta, int id, const CoLanes &K
   *meta = m ^ (1u << 18);
 }
 
+/* ---- the rule layer for FOUR positions at a time, one per row of 16 lanes (round 5; mcts.h co_search_rows): position,
+ * legal-move mask and everything in between are row-uniform values in vector registers; a lane's column is a cell.
+ * Same rules, same citations as above; checked against co_legal_moves on the rules corpus and by every parity test. */
+
+/* candidate line j (the reference's scan order, co_lanes_init): cells | first line_breakers index << 16 */
+CO_CONST uint32_t CO_LINE_CAND[48] = {
+    0x18000Fu, 0x7u, 0xC000Eu, 0x1B00F0u, 0x30070u, 0xF00E0u, 0x1E0F00u, 0x60700u, 0x120E00u, 0x21F000u, 0x97000u, 0x15E000u,
+    0x3C1111u, 0x240111u, 0x301110u, 0x3F2222u, 0x270222u, 0x332220u, 0x424444u, 0x2A0444u, 0x364440u, 0x458888u, 0x2D0888u,
+    0x398880u, 0x4E8421u, 0x480421u, 0x4B8420u, 0x571248u, 0x510248u, 0x541240u, 0x5A0124u, 0x5D0842u, 0x602480u, 0x634210u,
+    0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+
+/* game.cpp:60-96 on per-lane values (no cross-lane traffic) */
+CO_DEV void co_do_move_lane(uint64_t *board, uint32_t *meta, int id) {
+  uint64_t b = *board & ~0x8888888888888888ull;
+  uint32_t m = *meta;
+  if (id >= 48) {
+    const uint32_t piece = (uint32_t)(id - 48) >> 4, to4 = 4u * ((uint32_t)id & 15u);
+    m -= 1u << (3u * (CO_META_TO_PLAY(m) * 3u + piece));
+    b |= (uint64_t)((1u << piece) | 8u) << to4;
+  } else {
+    int is_place, piece, from, to;
+    co_decode_move(id, &is_place, &piece, &from, &to);
+    const uint32_t from4 = 4u * (uint32_t)from, to4 = 4u * (uint32_t)to;
+    const uint64_t src = (b >> from4) & 7ull;
+    b &= ~(15ull << from4);
+    b |= (src | 8ull) << to4;
+  }
+  *board = b;
+  *meta = m ^ (1u << 18);
+}
+
+/* bits {4 i + sh .. 4 i + sh + 2}, i = 0..3, of a 16-cell mask as 12 consecutive bits */
+CO_DEV uint32_t co_pack3(uint32_t m, int sh) {
+  return ((m >> sh) & 7u) | (((m >> (4 + sh)) & 7u) << 3) | (((m >> (8 + sh)) & 7u) << 6) | (((m >> (12 + sh)) & 7u) << 9);
+}
+
+/* line_breakers (util.h:85-637) in the workgroup's LDS: the four categories' masks are four DEPENDENT fetches otherwise.
+ * Every wavefront writes the same words before it reads any (no workgroup barrier is needed, nor wanted). */
+#define CO_LB_WORDS (CO_NUM_LINES * 3)
+CO_DEV void co_line_breakers_to_lds(uint32_t *lb) {
+  FOR_LANES {
+    const uint32_t *flat = &CO_LINE_BREAKERS[0][0];
+#pragma unroll
+    for (int k = 0; k < (CO_LB_WORDS + CO_WAVE - 1) / CO_WAVE; ++k) {
+      const int i = k * CO_WAVE + lane;
+      if (i < CO_LB_WORDS) lb[i] = flat[i];
+    }
+  }
+  WAVE_SYNC();
+}
+
+/* game.cpp:28-43 for the four rows' positions; o0..o2 = the rows' 96-bit legal masks.  `on` = rows that hold a position;
+ * lb = co_line_breakers_to_lds's copy. */
+CO_DEV void co_legal_moves_rows(LVP(uint32_t, blo), LVP(uint32_t, bhi), LVP(uint32_t, meta), LVP(int, on), LVP(uint32_t, o0),
+                                LVP(uint32_t, o1), LVP(uint32_t, o2), LVP(int, lines), const uint32_t *lb) {
+  LV(int, pb);
+  LV(int, pc);
+  LV(int, pa);
+  LV(int, pf);
+  LV(uint32_t, cd0);
+  LV(uint32_t, cd1);
+  LV(uint32_t, cd2);
+  FOR_LANES_HOT {
+    const int c = lane & 15;
+    const uint32_t nib = ((c < 8 ? L(blo) : L(bhi)) >> (4 * (c & 7))) & 15u;
+    L(pb) = (int)(nib & 1u);
+    L(pc) = (int)((nib >> 1) & 1u);
+    L(pa) = (int)((nib >> 2) & 1u);
+    L(pf) = (int)((nib >> 3) & 1u);
+    L(cd0) = CO_LINE_CAND[c]; /* this lane's three candidate lines: c, c + 16, c + 32 */
+    L(cd1) = CO_LINE_CAND[c + 16];
+    L(cd2) = CO_LINE_CAND[c + 32];
+  }
+  LV(uint32_t, B);
+  LV(uint32_t, C);
+  LV(uint32_t, A);
+  LV(uint32_t, F);
+  ROW_BALLOT(B, pb);
+  ROW_BALLOT(C, pc);
+  ROW_BALLOT(A, pa);
+  ROW_BALLOT(F, pf);
+  /* ---- lines: a candidate is a line iff all its cells lie in one top-piece plane (game.cpp:249-405) */
+  LV(int, mt0);
+  LV(int, mt1);
+  LV(int, mt2);
+  LV(uint32_t, pk); /* tops of this lane's candidates (2 bits each) | their line_breakers bases (7 bits each) */
+  FOR_LANES_HOT {
+    const uint32_t T2 = L(A), T1 = L(C) & ~L(A), T0 = L(B) & ~L(C) & ~L(A);
+    uint32_t p = 0u;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const uint32_t cd = k == 0 ? L(cd0) : k == 1 ? L(cd1) : L(cd2);
+      const uint32_t M = cd & 0xFFFFu;
+      const uint32_t tt = (T0 & M) == M ? 0u : (T1 & M) == M ? 1u : (T2 & M) == M ? 2u : 3u;
+      const int hit = M != 0u && tt < 3u && L(on);
+      if (k == 0) L(mt0) = hit;
+      else if (k == 1) L(mt1) = hit;
+      else L(mt2) = hit;
+      p |= (tt & 3u) << (2 * k);
+      p |= (cd >> 16) << (6 + 7 * k);
+    }
+    L(pk) = p;
+  }
+  LV(uint32_t, cb0);
+  LV(uint32_t, cb1);
+  LV(uint32_t, cb2);
+  ROW_BALLOT(cb0, mt0);
+  ROW_BALLOT(cb1, mt1);
+  ROW_BALLOT(cb2, mt2);
+  LV(uint32_t, m0);
+  LV(uint32_t, m1);
+  LV(uint32_t, m2);
+  LV(int, anyl);
+  FOR_LANES_HOT {
+    L(m0) = L(m1) = L(m2) = 0xFFFFFFFFu;
+    L(anyl) = (L(cb0) | L(cb1) | L(cb2)) != 0u;
+    L(lines) = L(anyl); /* is_lines (game.cpp:28-43): the mover of a position without legal moves has lost iff there is a line */
+  }
+  if (WAVE_BALLOT(anyl)) {
+    /* one line per category, first match in scan order (game.cpp:265,310,330-356,368-388) */
+#pragma unroll
+    for (int cat = 0; cat < 4; ++cat) {
+      LV(int, jj); /* the category's first matching candidate, or -1 */
+      LV(int, col);
+      FOR_LANES_HOT {
+        const uint32_t lo = L(cb0) | (L(cb1) << 16);
+        const uint32_t cm = cat == 0 ? (lo & 0xFFFu) : cat == 1 ? (lo & 0xFFF000u) : cat == 2 ? (lo & 0x3F000000u) : 0u;
+        int j = -1;
+        if (cat < 3) {
+          if (cm) j = co_ffs64((uint64_t)cm) - 1;
+        } else {
+          const uint32_t c3 = (lo >> 30) | ((L(cb2) & 3u) << 2);
+          if (c3) j = 30 + co_ffs64((uint64_t)c3) - 1;
+        }
+        L(jj) = j;
+        L(col) = j & 15;
+      }
+      LV(int, has);
+      FOR_LANES_HOT { L(has) = L(jj) >= 0; }
+      if (!WAVE_BALLOT(has)) continue;
+      LV(uint32_t, sp);
+      ROW_SHFL_U32(sp, pk, col);
+      FOR_LANES_HOT {
+        if (L(jj) >= 0) {
+          const int j = L(jj), k = j >> 4;
+          const int tt = (int)((L(sp) >> (2 * k)) & 3u);
+          const int line = (int)((L(sp) >> (6 + 7 * k)) & 127u) + tt;
+          L(m0) &= lb[3 * line];
+          L(m1) &= lb[3 * line + 1];
+          L(m2) &= lb[3 * line + 2];
+          if (cat < 2 && tt == 2) {
+            const int kq = (cat == 0 ? j : j - 12) % 3;
+            if (kq != 0) {
+              /* capital triple in a row/column: game.cpp:280-309 */
+              const int is_col = cat == 1;
+              const int ec = kq == 1 ? 3 : 0;
+              for (int kk = 0; kk < 4; ++kk) {
+                const int cell = is_col ? (ec * 4 + kk) : (kk * 4 + ec);
+                if ((L(A) >> cell) & 1u) continue;
+                if (kk > 0) {
+                  const int id = is_col ? (24 + ec * 3 + (kk - 1)) : (36 + (kk - 1) * 4 + ec);
+                  if (id < 32) L(m0) &= ~(1u << id);
+                  else L(m1) &= ~(1u << (id - 32));
+                }
+                if (kk < 3) {
+                  const int id = is_col ? (ec * 3 + kk) : (12 + kk * 4 + ec);
+                  if (id < 32) L(m0) &= ~(1u << id);
+                  else L(m1) &= ~(1u << (id - 32));
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  /* ---- stack moves (canMove, game.cpp:222-232) on the planes: a column-bottomed stack without a base onto a bare base,
+   * a bare capital onto a column-topped stack, neither frozen; then placements (canPlace, game.cpp:193-220) */
+  FOR_LANES_HOT {
+    const uint32_t b = L(B), c = L(C), a = L(A), f = L(F);
+    const uint32_t T1 = c & ~a, T0 = b & ~c & ~a;
+    const uint32_t s1 = c & ~b & ~f, d1 = b & ~c & ~a & ~f, s2 = a & ~b & ~c & ~f, d2 = c & ~a & ~f;
+    const uint32_t Rm = ((s1 & (d1 >> 1)) | (s2 & (d2 >> 1))) & 0x7777u;
+    const uint32_t Dm = ((s1 & (d1 >> 4)) | (s2 & (d2 >> 4))) & 0x0FFFu;
+    const uint32_t Lm = ((s1 & (d1 << 1)) | (s2 & (d2 << 1))) & 0xEEEEu;
+    const uint32_t Um = ((s1 & (d1 << 4)) | (s2 & (d2 << 4))) & 0xFFF0u;
+    const uint32_t mv_lo = co_pack3(Rm, 0) | (Dm << 12) | (co_pack3(Lm, 1) << 24); /* ids 0 .. 31 (left moves 24 .. 35 straddle) */
+    const uint32_t mv_hi = (co_pack3(Lm, 1) >> 8) | ((Um >> 4) << 4);             /* ids 32 .. 47 */
+    const uint32_t E = ~(b | c | a) & 0xFFFFu;
+    const uint32_t mine = CO_META_TO_PLAY(L(meta)) ? L(meta) >> 9 : L(meta);
+    const uint32_t qb = (mine & 7u) ? E : 0u;
+    const uint32_t qc = (mine & 0x38u) ? (E | (T0 & ~f)) : 0u;
+    const uint32_t qa = (mine & 0x1C0u) ? (E | (T1 & ~f)) : 0u;
+    L(o0) = L(m0) & mv_lo;
+    L(o1) = L(m1) & (mv_hi | (qb << 16));
+    L(o2) = L(m2) & (qc | (qa << 16));
+  }
+}
+
+/* co_legal_moves with its per-lane constants made on the spot: for callers off the hot path (roots, the sequential
+ * simulation), so that the constants do not live in registers across the whole step */
+CO_DEV int co_legal_moves1(uint64_t board, uint32_t meta, uint32_t out[3]) {
+  CoLanes K;
+  co_lanes_init(K);
+  return co_legal_moves(board, meta, out, K);
+}
+
 /* game.cpp:45-58: lanes 0..63 write the board bits, lanes 0..5 the reserves (the mover's first).
  * `row` has room for CO_STATE_STRIDE floats; the padding is zeroed. */
 CO_DEV void co_write_state(uint64_t board, uint32_t meta, float *row) {

@@ -27,6 +27,12 @@
 
 #define CO_WAVE 64
 
+/* Simulations of a step selected together by the search kernel (mcts.h co_search_rows): 4 = one per row of the
+ * wavefront, 1 = one after another (rounds 1-4). */
+#ifndef CO_SB
+#define CO_SB 4
+#endif
+
 #ifdef CO_EMU
 // ------------------------------------------------------------------ emulation
 #include <math.h>
@@ -39,13 +45,19 @@ static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
   return v;
 }
 #define CO_DEV static inline
+#define CO_COLD static /* the product build keeps these out of line (see below) */
+#define CO_COLD2 static
 #define CO_KERNEL static void
 #define CO_CONST static const
 #define LV(T, x) T x[CO_WAVE]
+#define LVP(T, x) T *x /* an LV variable as a function parameter */
+#define CO_OPAQUE_V(x) ((void)0)
 #define L(x) x[lane]
 #define LAT(x, i) x[(i)]
 #define FOR_LANES for (int lane = 0; lane < CO_WAVE; ++lane)
+#define FOR_LANES_HOT FOR_LANES
 #define WAVE_SHARED(T, x, n) T x[n]
+#define WG_SHARED(T, x, n) T x[n] /* one copy for the workgroup's wavefronts (here: the one wavefront) */
 #define WAVE_SYNC() ((void)0)
 #define UNI_I(x) (x)
 #define UNI_U(x) (x)
@@ -97,6 +109,45 @@ static inline uint32_t co_lane_cas_u32(uint32_t *p, uint32_t expected, uint32_t 
   __atomic_compare_exchange_n(p, &expected, desired, 0, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE);
   return expected;
 }
+/* ---- rows: a wavefront as four groups of 16 lanes (the rows of the DPP unit).  Inside a row every lane may hold
+ * the same value ("row-uniform"); the ROW_* statements below move data inside each row, all four rows at once.
+ * They are statements used OUTSIDE FOR_LANES (dst and src are LV variables). */
+#define CO_ROW_LANES 16
+static inline void emu_row_max_f32(float *d, const float *s) {
+  float t[CO_WAVE];
+  for (int r = 0; r < CO_WAVE; r += CO_ROW_LANES) {
+    float m = s[r];
+    for (int i = 1; i < CO_ROW_LANES; ++i) m = s[r + i] > m ? s[r + i] : m;
+    for (int i = 0; i < CO_ROW_LANES; ++i) t[r + i] = m;
+  }
+  memcpy(d, t, sizeof t);
+}
+static inline void emu_row_min_u32(uint32_t *d, const uint32_t *s) {
+  uint32_t t[CO_WAVE];
+  for (int r = 0; r < CO_WAVE; r += CO_ROW_LANES) {
+    uint32_t m = s[r];
+    for (int i = 1; i < CO_ROW_LANES; ++i) m = s[r + i] < m ? s[r + i] : m;
+    for (int i = 0; i < CO_ROW_LANES; ++i) t[r + i] = m;
+  }
+  memcpy(d, t, sizeof t);
+}
+static inline void emu_row_ballot(uint32_t *d, const int *p) {
+  for (int r = 0; r < CO_WAVE; r += CO_ROW_LANES) {
+    uint32_t m = 0;
+    for (int i = 0; i < CO_ROW_LANES; ++i)
+      if (p[r + i]) m |= 1u << i;
+    for (int i = 0; i < CO_ROW_LANES; ++i) d[r + i] = m;
+  }
+}
+static inline void emu_row_shfl_u32(uint32_t *d, const uint32_t *s, const int *col) {
+  uint32_t t[CO_WAVE];
+  for (int l = 0; l < CO_WAVE; ++l) t[l] = s[(l & ~(CO_ROW_LANES - 1)) + (col[l] & (CO_ROW_LANES - 1))];
+  memcpy(d, t, sizeof t);
+}
+#define ROW_MAX_F32(d, s) emu_row_max_f32(d, s)
+#define ROW_MIN_U32(d, s) emu_row_min_u32(d, s)
+#define ROW_BALLOT(d, p) emu_row_ballot(d, p)           /* d = the 16 predicate bits of the lane's row */
+#define ROW_SHFL_U32(d, s, col) emu_row_shfl_u32(d, s, col) /* d = s of lane `col` (an LV int, 0..15) of the same row */
 extern thread_local int co_emu_block_idx;
 #define CO_BLOCK_IDX co_emu_block_idx
 /* kernels whose wavefronts are independent may pack several per workgroup on the GPU (fewer, fatter
@@ -108,12 +159,40 @@ extern thread_local int co_emu_block_idx;
 // ------------------------------------------------------------------- gfx950
 #include <hip/hip_runtime.h>
 #define CO_DEV __device__ __forceinline__
+/* once-per-ply and rare paths (move choice, the sequential simulation, slot recycling).  Round 5 measured them as real calls
+ * (-DCO_COLD_NOINLINE: the search kernel's spills go from 328 scalar + 36 vector registers to 54 + 58, its scratch from
+ * 240 to 1208 bytes per lane): a generation of 4096 games with the reference's network takes 262 ms instead of 181 --
+ * every call saves and restores through scratch memory.  Inlined, as before. */
+#ifdef CO_COLD_NOINLINE
+#define CO_COLD __device__ __attribute__((noinline))
+#define CO_COLD2 __device__ __attribute__((noinline))
+#else
+#define CO_COLD __device__ __forceinline__
+#define CO_COLD2 __device__ __forceinline__
+#endif
 #define CO_KERNEL __global__ void
 #define CO_CONST __device__ const
 #define LV(T, x) T x
+#define LVP(T, x) T &x
+/* the compiler may not look through x from here on.  For values derived from the lane index in hot sections: left
+ * transparent, every such expression (1 << column, row * stride, ...) is hoisted to the kernel's entry, lives across the
+ * whole step and is spilled -- and a reload from scratch behind a store waits for the store (round 5: six of them in the
+ * node-store loop of the grouped search cost more than the loop) */
+#define CO_OPAQUE_V(x) asm volatile("" : "+v"(x))
 #define L(x) x
 #define LAT(x, i) x
+/* the same with a lane index the compiler cannot see through (CO_OPAQUE_V): nothing derived from it leaves the section */
+__device__ __forceinline__ int co_lane_opaque() {
+  int l = (int)(threadIdx.x & 63);
+  CO_OPAQUE_V(l);
+  return l;
+}
+#define FOR_LANES_HOT for (int lane = co_lane_opaque(), _co_once = 1; _co_once; _co_once = 0)
+#ifdef CO_LANES_TRANSPARENT
 #define FOR_LANES for (int lane = (int)(threadIdx.x & 63), _co_once = 1; _co_once; _co_once = 0)
+#else
+#define FOR_LANES FOR_LANES_HOT
+#endif
 /* Wavefronts of the search kernel per workgroup.  A game is one wavefront whatever this is; what it changes is where
  * the dispatcher puts them: single-wave workgroups spread a launch of 2048 games over all 1024 SIMDs at two waves
  * each, CO_K3_WPB = 16 packs them onto half of the CUs at four waves per SIMD and leaves the other CUs to the
@@ -128,6 +207,7 @@ extern thread_local int co_emu_block_idx;
   __shared__ T name_##_blk[CO_K3_WPB][n];     \
   T(&name_)[n] = name_##_blk[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))]
 #endif
+#define WG_SHARED(T, name_, n) __shared__ T name_[n]
 // a wave barrier orders LDS traffic of the wave (its LDS slices are its own)
 #define WAVE_SYNC() __builtin_amdgcn_wave_barrier()
 #define UNI_I(x) __builtin_amdgcn_readfirstlane((int)(x))
@@ -256,6 +336,48 @@ __device__ __forceinline__ void co_lane_store_coherent_u32(uint32_t *p, uint32_t
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ uint32_t co_lane_cas_u32(uint32_t *p, uint32_t expected, uint32_t desired) { return atomicCAS(p, expected, desired); }
+/* ---- rows: a wavefront as four groups of 16 lanes (the rows of the DPP unit).  Inside a row every lane may hold
+ * the same value ("row-uniform"); the ROW_* statements move data inside each row, all four rows at once. */
+#define CO_ROW_LANES 16
+__device__ __forceinline__ float co_row_max_f32(float v) {
+  float r;
+  asm("s_nop 1\n\t"
+      "v_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf"
+      : "=&v"(r)
+      : "v"(v));
+  return r;
+}
+__device__ __forceinline__ uint32_t co_row_min_u32(uint32_t v) {
+  uint32_t r;
+  asm("s_nop 1\n\t"
+      "v_min_u32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_min_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf"
+      : "=&v"(r)
+      : "v"(v));
+  return r;
+}
+__device__ __forceinline__ uint32_t co_row_ballot(int p) {
+  const unsigned long long m = __ballot(p);
+  return (uint32_t)(m >> (threadIdx.x & 48u)) & 0xFFFFu;
+}
+__device__ __forceinline__ uint32_t co_row_shfl_u32(uint32_t v, int col) {
+  return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((threadIdx.x & 48u) | ((unsigned)col & 15u)) << 2), (int)v);
+}
+#define ROW_MAX_F32(d, s) ((d) = co_row_max_f32(s))
+#define ROW_MIN_U32(d, s) ((d) = co_row_min_u32(s))
+#define ROW_BALLOT(d, p) ((d) = co_row_ballot(p))
+#define ROW_SHFL_U32(d, s, col) ((d) = co_row_shfl_u32((s), (col)))
 #define CO_BLOCK_IDX ((int)blockIdx.x)
 #define CO_WAVES_PER_BLOCK 4
 #define CO_WAVE_IN_BLOCK ((int)(threadIdx.x >> 6))

@@ -227,7 +227,7 @@ int ca_trainer_game_info(ca_trainer *t, int game, int32_t out[8]);
 int ca_trainer_trace(ca_trainer *t, int game, int32_t *out, int32_t cap, int32_t *n);
 /* diagnostic builds of the library (-DCO_PROF) only: summed in-kernel cycle stamps of the search kernel
  * (slots documented in csrc/mcts.h); the shipped build returns CA_ERR_STATE */
-int ca_trainer_prof(ca_trainer *t, unsigned long long out[52]);
+int ca_trainer_prof(ca_trainer *t, unsigned long long out[88]);
 
 /* ---- Tourney: replaces `class Tourney` of corintho_ai/cpp/include/tourney.h:13-46
  * consumed by corintho_ai/rating/tourney.pyx:15-31.  One match = one slot of a device pool
@@ -286,6 +286,9 @@ int ca_rules_legal_moves(int device, const uint64_t *boards, const uint32_t *met
 /* apply moves[i] (or -1 for none) and expand the 70-float state */
 int ca_rules_do_move(int device, uint64_t *boards, uint32_t *metas, const int32_t *moves, int32_t n,
                      float *states /* [n][70] */);
+/* the same two through the search's four-positions-per-wavefront rule layer (csrc/rules.h co_do_move_lane,
+ * co_legal_moves_rows): apply moves[i] (or -1 for none), then the legal-move mask of the new position */
+int ca_rules_rows(int device, uint64_t *boards, uint32_t *metas, const int32_t *moves, int32_t n, uint32_t *masks /* [n][3] */);
 /* std::mt19937 through the device draw path: n outputs for `seed`, drawn `chunk` at a time */
 int ca_rng_draw(int device, uint32_t seed, int32_t n, int32_t chunk, uint32_t *out);
 /* floating-point contract probe, see kernels.h co_k_fp_probe: in [n][8] -> out [n][8] */

@@ -126,6 +126,13 @@ def test_legal_masks_random_corpus(engine):
     _lib.check(L, L.ca_rules_do_move(0, b2.ctypes.data_as(_lib.u64p), m2.ctypes.data_as(_lib.u32p),
                                      mv.ctypes.data_as(_lib.i32p), n, st.ctypes.data_as(_lib.f32p)))
     assert np.array_equal(st, np.array(want_state))
+    # the four-positions-per-wavefront rule layer of the search (rules.h co_legal_moves_rows), ragged tail included
+    for cut in (n, n - 1, n - 2, n - 3):
+        b3, m3 = b[:cut].copy(), m[:cut].copy()
+        out3 = np.zeros((cut, 3), np.uint32)
+        _lib.check(L, L.ca_rules_rows(0, b3.ctypes.data_as(_lib.u64p), m3.ctypes.data_as(_lib.u32p),
+                                      mv[:cut].copy().ctypes.data_as(_lib.i32p), cut, out3.ctypes.data_as(_lib.u32p)))
+        assert np.array_equal(out3, out[:cut]) and np.array_equal(b3, b[:cut]) and np.array_equal(m3, m[:cut])
 
 
 @pytest.mark.parametrize("engine", ENGINES)

@@ -55,6 +55,22 @@ def test_rules_corpus(engine):
                                      mv.ctypes.data_as(_lib.i32p), n, st.ctypes.data_as(_lib.f32p)))
     assert np.array_equal(b, z["boards_after"])
     assert np.array_equal(m, z["metas_after"])
+    # the search's four-positions-per-wavefront rule layer (round 5): the same masks, the same moves
+    for mv, wb, wm, wmask in ((np.full(n, -1, np.int32), z["boards"], z["metas"], z["masks"]),
+                              (z["moves"].copy(), z["boards_after"], z["metas_after"], None)):
+        b, m = z["boards"].copy(), z["metas"].copy()
+        out = np.zeros((n, 3), np.uint32)
+        _lib.check(L, L.ca_rules_rows(0, b.ctypes.data_as(_lib.u64p), m.ctypes.data_as(_lib.u32p),
+                                      mv.ctypes.data_as(_lib.i32p), n, out.ctypes.data_as(_lib.u32p)))
+        assert np.array_equal(b, wb) and np.array_equal(m, wm)
+        if wmask is not None:
+            assert np.array_equal(out, wmask)
+        else:  # the masks of the positions behind the moves: against the one-position-per-wavefront layer
+            ref = np.zeros((n, 3), np.uint32)
+            ln2 = np.zeros(n, np.int32)
+            _lib.check(L, L.ca_rules_legal_moves(0, wb.copy().ctypes.data_as(_lib.u64p), wm.copy().ctypes.data_as(_lib.u32p), n,
+                                                 ref.ctypes.data_as(_lib.u32p), ln2.ctypes.data_as(_lib.i32p)))
+            assert np.array_equal(out, ref)
 
 
 def _factory(engine):

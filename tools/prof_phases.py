@@ -12,7 +12,9 @@ from corintho_ai_amd import Trainer, _lib, build, nets  # noqa: E402
 
 out = os.path.join(ROOT, "gpurun_out", "libcorintho_hip_prof.so")
 os.makedirs(os.path.dirname(out), exist_ok=True)
-cmd = [build.hipcc()] + build.FLAGS + ["-DCO_PROF", "-o", out] + [os.path.join(build.CSRC, s) for s in build.SOURCES]
+extra = [a for a in sys.argv[1:] if a.startswith("-D")]
+sys.argv = [a for a in sys.argv if not a.startswith("-D")]
+cmd = [build.hipcc()] + build.FLAGS + ["-DCO_PROF"] + extra + ["-o", out] + [os.path.join(build.CSRC, s) for s in build.SOURCES]
 subprocess.check_call(cmd)
 L = _lib.declare(C.CDLL(out))
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
@@ -23,7 +25,7 @@ t.set_net(9, nets.init_mlp12x100(0))
 t.run()
 st = t.stats()
 NP = 32
-p = (C.c_ulonglong * (NP + 20))()
+p = (C.c_ulonglong * (2 * NP + 24))()
 L.ca_trainer_prof.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
 _lib.check(L, L.ca_trainer_prof(t._t, p))
 v = [int(x) for x in p]
@@ -38,8 +40,18 @@ print("histogram of wave-step cycles (50k buckets):", v[NP + 4:NP + 20])
 names = {22: "wave set-up", 0: "backup: indices", 1: "backup: slot fetch", 3: "backup: sums + stores", 20: "loop control + root load",
          19: "simulation start (root copy, path)", 8: "PUCT scan", 9: "virtual-loss store + path", 11: "descent: block fetch (waited for)",
          16: "expansion: doMove", 14: "expansion: legal moves", 15: "expansion: node stores", 10: "expansion: slot + path update",
+         28: "grouped search: root scans", 25: "tail: stores of the step waited for", 26: "tail: batch-row atomic", 27: "tail: noise capture (copy)", 30: "tail: noise capture (before a twist)", 31: "tail: twist", 29: "tail: request rows read back",
          12: "terminal leaf", 17: "request: state row", 18: "request: pending-leaf records", 2: "move choice / hand-over", 21: "step tail"}
 tot = sum(v[i] for i in names)
 print("stamped %.0f cycles per wave-step (%.1f %% of the whole step); per SIMULATION:" % (tot / steps, 100.0 * tot / max(v[7], 1)))
 for i, nm in names.items():
     print("  %-40s %8.0f cycles  %5.1f %%" % (nm, v[i] / nsearch, 100.0 * v[i] / tot))
+
+sv = v[NP + 24:NP + 24 + NP]
+ssteps = max(sv[4], 1)
+if sv[4]:
+    stot = sum(sv[i] for i in names)
+    print("SLOW wave-steps (> 280 k cycles): %d (%.2f %% of all), %.0f cycles avg, %.1f simulations, %.1f evaluations received; per wave-STEP:"
+          % (sv[4], 100.0 * sv[4] / steps, sv[7] / ssteps, sv[5] / ssteps, sv[6] / ssteps))
+    for i, nm in names.items():
+        print("  %-40s %8.0f cycles  %5.1f %%   (all steps: %8.0f)" % (nm, sv[i] / ssteps, 100.0 * sv[i] / stot, v[i] / steps))
