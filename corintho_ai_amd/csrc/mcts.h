@@ -452,6 +452,8 @@ CO_DEV void co_backup_batch(CoWave &w, CoTree &t, int k0, int nb, const float *e
   LV(uint32_t, at[CO_RB]);
   LV(uint32_t, ny[CO_RB]);
   LV(uint32_t, nw[CO_RB]);
+  LV(uint32_t, nx[CO_RB]); /* (the slot's other two words, so that a slot goes back as ONE 16-byte store) */
+  LV(uint32_t, nz[CO_RB]);
   LV(int, on[CO_RB]);
 #pragma unroll
   for (int k = 0; k < CO_RB; ++k) {
@@ -468,7 +470,9 @@ CO_DEV void co_backup_batch(CoWave &w, CoTree &t, int k0, int nb, const float *e
     FOR_LANES {
       if (!L(on[k])) L(at[k]) = 0u;
       uint4 sl = A[L(at[k])]; /* unconditional: inactive lanes read unit 0 */
+      L(nx[k]) = sl.x;
       L(ny[k]) = sl.y;
+      L(nz[k]) = sl.z;
       L(nw[k]) = sl.w & ~0x100u; /* all_visited := false */
     }
   }
@@ -494,10 +498,7 @@ CO_DEV void co_backup_batch(CoWave &w, CoTree &t, int k0, int nb, const float *e
 #pragma unroll
   for (int k = 0; k < CO_RB; ++k) {
     FOR_LANES {
-      if (L(on[k])) {
-        A[L(at[k])].y = L(ny[k]);
-        A[L(at[k])].w = L(nw[k]);
-      }
+      if (L(on[k])) A[L(at[k])] = make_uint4(L(nx[k]), L(ny[k]), L(nz[k]), L(nw[k]));
     }
   }
   WAVE_SYNC();
@@ -564,7 +565,7 @@ CO_DEV void co_propagate_terminal(CoTree &t, const uint32_t *path_block, const u
  * itself or at least ulp/(2 d) >= 2^-17 ulp away from every rounding boundary, so q = RN(x/d).
  * (A zero quotient may differ in sign; pv >= +0 makes the PUCT sum the same.)  The seed only has
  * to be good to ~20 bits, so the emulation build's 1.0f / d and v_rcp_f32 give the same q. */
-CO_DEV double co_div_small(double x, float df) {
+CO_DEV double co_recip_small(float df) {
 #ifdef CO_EMU
   float rf = 1.0f / df;
 #else
@@ -576,10 +577,16 @@ CO_DEV double co_div_small(double x, float df) {
   r = __builtin_fma(r, e, r);
   e = __builtin_fma(-d, r, 1.0);
   r = __builtin_fma(r, e, r);
+  return r;
+}
+/* x / df given r = co_recip_small(df) */
+CO_DEV double co_div_with(double x, float df, double r) {
+  double d = (double)df;
   double q0 = x * r;
   double rem = __builtin_fma(-d, q0, x);
   return __builtin_fma(rem, r, q0);
 }
+CO_DEV double co_div_small(double x, float df) { return co_div_with(x, df, co_recip_small(df)); }
 
 /* Copy of the root kept across the simulations of one step, so that a simulation starts without any
  * dependent load: header and stat slot in registers, the first 64 edge slots (the whole PUCT scan of
@@ -891,17 +898,50 @@ CO_DEV int co_search_rows(CoWave &w, CoTree &t, CoRoot &rc, int m) {
     LV(uint4, ev);
     FOR_LANES_HOT { L(ev) = rc.ev[lane]; }
     uint4 rcs = rc.cs;
+    /* What a scan of this node needs of each edge, kept across the group's scans (co_puct_u in two halves): the
+     * exploitation term a = -E / V, the reciprocal of V + 1 for the exploration term, the prior, and which form u takes
+     * (0 unvisited, 1 visited, 2 drawn, 3 not to be searched).  Only the chosen edge changes between two scans -- one
+     * more visit, +1.0: its a is the old reciprocal's quotient, its reciprocal is made anew.  And the exploration factors
+     * of the group's scans (visits, visits + 1, ...: one double-precision square root each) come from ONE pass, a lane each. */
+    LV(double, ea);
+    LV(double, er);
+    LV(float, ecv1);
+    LV(float, eprob);
+    LV(int, emode);
+    LV(float, vsl);
     for (;;) {
       const int msel = bad < m ? bad : m;
       uint32_t same_slot = CO_NONE; /* the child every simulation so far has taken, 0 = not one child (or a new one) */
       uint4 first_bs = make_uint4(0u, 0u, 0u, 0u);
+      {
+        const int v0 = co_slot_visits(rcs);
+        FOR_LANES_HOT {
+          const uint4 s = L(ev);
+          const int r = (int)(s.w & 0xFFu);
+          const int has_child = s.x != CO_NONE;
+          const int drawn = (r == CO_RESULT_DRAW) | (r == CO_DEDUCED_DRAW);
+          const int searchable = ((r == CO_RESULT_NONE) | drawn) & !((s.w >> 8) & 1u);
+          const int vis = co_slot_visits(s);
+          const float cv = (float)(vis > 0 ? vis : 1);
+          L(eprob) = (float)((s.z >> 7) & 511u) * denom0;
+          L(ea) = co_div_small(-(double)co_u2f(s.y), cv);
+          L(ecv1) = cv + 1.0f;
+          L(er) = co_recip_small(L(ecv1));
+          L(emode) = !has_child ? 0 : !searchable ? 3 : drawn ? 2 : 1;
+          L(vsl) = co_vsqrt(w.c_puct, v0 + (lane < CO_SB ? lane : 0));
+        }
+      }
       for (int j = 0; j < msel; ++j) {
         CO_SBS(10, 1);
         CO_PROF_ADD(w, 23, 1ull);
-        const float v_sqrt = co_vsqrt(w.c_puct, co_slot_visits(rcs));
+        const float v_sqrt = WAVE_BCAST(vsl, j);
         LV(float, u);
         FOR_LANES_HOT {
-          const float uu = co_puct_u(L(ev), denom0, v_sqrt);
+          const float pv = L(eprob) * v_sqrt;
+          const double bq = co_div_with((double)pv, L(ecv1), L(er));
+          const float uv = (float)(L(ea) + bq);
+          const int md = L(emode);
+          const float uu = md == 1 ? uv : md == 3 ? CO_NEG_INF : pv;
           L(u) = lane < n0 ? uu : CO_NEG_INF;
         }
         const float mx = WAVE_MAX_F32(u);
@@ -931,7 +971,16 @@ CO_DEV int co_search_rows(CoWave &w, CoTree &t, CoRoot &rc, int m) {
         const uint32_t xb = shX, xo = shown;
         const int lv = lev0;
         FOR_LANES_HOT {
-          if (lane == le) L(ev) = nv;
+          if (lane == le) {
+            L(ev) = nv;
+            if (L(emode) == 0) {
+              L(emode) = 3; /* a new child: all_visited until its evaluation arrives */
+            } else {
+              L(ea) = co_div_with(-(double)co_u2f(nv.y), L(ecv1), L(er));
+              L(ecv1) = L(ecv1) + 1.0f;
+              L(er) = co_recip_small(L(ecv1));
+            }
+          }
           if (lane == 0) {
             sb_block[j * CO_SB_DEPTH + lv] = xb;
             sb_slot[j * (CO_SB_DEPTH + 1) + lv] = xo;
