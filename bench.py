@@ -245,6 +245,7 @@ def cpu_leg(args, G, threads, net_name, weights, cap_s, evals_per_game):
     leg still running then stops and reports its rate scaled by the evaluations a game needs
     (finished = false)."""
     from corintho_ai_amd import nets
+    from tests import ref_nets
     from oracle import oracle as O
     from tests import harness as H
 
@@ -258,9 +259,9 @@ def cpu_leg(args, G, threads, net_name, weights, cap_s, evals_per_game):
         import torch
 
         torch.set_num_threads(threads)
-        fwd = lambda s: nets.rescnn4_forward_ref(weights, s)  # noqa: E731
+        fwd = lambda s: ref_nets.rescnn4_forward_ref(weights, s)  # noqa: E731
     elif net_name == "mlp12x100":
-        fwd = lambda s: nets.mlp12x100_forward_np(weights, s)  # noqa: E731
+        fwd = lambda s: ref_nets.mlp12x100_forward_np(weights, s)  # noqa: E731
     else:
         fwd = H.uniform_net  # zero-cost stand-in: the search alone
     t = O.Trainer(G, seed=12345, max_searches=args.sims, searches_per_eval=args.spe, c_puct=args.c_puct,
@@ -630,6 +631,14 @@ def main():
                                                   "roofline": roofline_of(args.net, t3, int(t3.get("pools", 1)), wall_s=d3),
                                                   "nn_rows_evaluated_over_requested": t3["nn_rows_evaluated"] / max(t3["nn_rows"], 1)}
                 del tr3
+        if world == 1 and not args.no_variants and npools != 2:
+            # rounds 1-4 ran two pools per GPU; the same workload that way, for continuity of the per-launch figures
+            trp = make_trainer(2)
+            n2 = min(5, args.steps)
+            dp, tp = run_generations(trp, args.net, n2, 1, 13000, False)
+            out["detail"]["two_pools"] = {"games_per_s": G * n2 / dp, "ms_per_step": dp * 1e3 / n2, "steps": n2, "warmup": 1,
+                                          "roofline": roofline_of(args.net, tp, int(tp.get("pools", 1)), wall_s=dp)}
+            del trp
         if world == 1 and args.recycle_games > G:
             # one generation of `recycle_games` games on G resident slots: a slot whose game ends takes the next game
             # (ca_config.resident), so the launches stay full until the games run out instead of thinning with the
@@ -653,6 +662,7 @@ def main():
             "fp32_mfma_games_per_s": d.get("variants", {}).get("rescnn4", {}).get("games_per_s"),
             "reference_network_mlp12x100h3_games_per_s": d.get("variants", {}).get("mlp12x100h3", {}).get("games_per_s"),
             "recycled_games_per_s": d.get("recycled", {}).get("games_per_s"),
+            "two_pools_games_per_s": d.get("two_pools", {}).get("games_per_s"),
         }
         if world == 1 and args.cpu_games > 0:
             out["cpu_baseline"] = cpu_baseline(args, arch, weights_by_arch, out["detail"]["evals_per_game"])

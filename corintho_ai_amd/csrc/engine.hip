@@ -1267,7 +1267,10 @@ struct ca_trainer {
     if (!nets[0]) throw EngineError(CA_ERR_STATE, "ca_trainer_run: no network set (ca_trainer_set_net)");
     if (cfg.testing && !cfg.analyse && !nets[1]) throw EngineError(CA_ERR_STATE, "arena mode needs both networks");
     if (!cfg.testing || cfg.analyse) { /* one network, every slot active: self-play training, or N position searches */
-      int npools = cfg.pools > 0 ? cfg.pools : (R >= 2048 ? 2 : 1);
+      /* automatic: three pools from 3072 resident games on (round 5, one box, same library, 4096 games x 400: rescnn4 f16x3
+       * 417.9 -> 407.6 ms per generation, mlp12x100 f16x3 145.4 -> 138.3 -- with the grouped search a pool's search launch is
+       * short enough for a third pool to fit under the other two's network launches), two from 2048, else one */
+      int npools = cfg.pools > 0 ? cfg.pools : (R >= 3072 ? 3 : R >= 2048 ? 2 : 1);
       if (npools > CO_MAX_POOLS) npools = CO_MAX_POOLS;
       if (npools > R) npools = R;
       return run_pools(max_iterations, npools);

@@ -304,7 +304,10 @@ __device__ __forceinline__ void rc_dense_value(const RcParams &P, const float *w
   if (q == 0 && pos < rows && c < ncols) P.eval[rc_out_row(P, pos) * (size_t)P.io.eval_stride] = tanhf(v2[0] + P.bv2[0]);
 }
 
-__global__ __launch_bounds__(256, 2) void co_k_rescnn_forward(RcParams P) {
+#ifndef CO_RC_F32_BLOCKS
+#define CO_RC_F32_BLOCKS 2
+#endif
+__global__ __launch_bounds__(256, CO_RC_F32_BLOCKS) void co_k_rescnn_forward(RcParams P) {
   __shared__ __attribute__((aligned(16))) float lds_w[2 * RC_CONV_CHUNK];
   __shared__ float lds_feat[4][RC_NB][96];
   const int rows = *P.d_rows;
@@ -438,7 +441,11 @@ struct Rc3Params {
  * latency are scarce, the pixel-major kernel's 32 rows per 160 us of a CU beat the small kernel's 16 per 110: a
  * two-pool generation 438.7 ms split against 434.0 unsplit.) */
 __device__ __forceinline__ int rcp_small_begin(const Rc3Params &Q, int rows) {
-  if (Q.pass_rows <= 0) return rows <= RC3_SMALL_ROWS ? 0 : rows;
+  /* (a batch the host queues no throughput kernel for -- rows_cap <= RC3_SMALL_ROWS -- is the small kernel's whole,
+   * whatever a pass is: on a device or partition of <= 128 CUs a pass is <= RC3_SMALL_ROWS rows, and `full` below would
+   * hand rows to a kernel that was never launched) */
+  if (rows <= RC3_SMALL_ROWS) return 0;
+  if (Q.pass_rows <= 0) return rows;
   const int full = rows / Q.pass_rows * Q.pass_rows;
   return rows - full > RC3_SMALL_ROWS ? rows : full;
 }
@@ -887,7 +894,12 @@ __global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_x6(Rc3Params Q) {
 /* The f16x3 kernels (see above rcs_forward): throughput kernel, 32 positions per workgroup; _small: batches up to
  * RC3_SMALL_ROWS rows, 16 positions per workgroup, and up to RC6_THIN_ROWS rows on the four-wave thin path (one wave per
  * SIMD, 8 positions per workgroup, waves 4..7 leave at once; see co_k_rescnn_forward_x6). */
+#ifndef CO_RESCNN_PIXMAJOR_DEFAULT
+#define CO_RESCNN_PIXMAJOR_DEFAULT 1 /* 0: a diagnostic build whose batches beyond RC3_SMALL_ROWS take the (position, pixel)-column kernel (tools/exp/pixmajor_ab.py) */
+#endif
+#if !CO_RESCNN_PIXMAJOR_DEFAULT
 __global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_h3(Rc3Params Q) { rcs_forward<2, 2, 8, true>(Q); }
+#endif
 __global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_h3_small(Rc3Params Q) {
   const int rows = *Q.base.d_rows, rbase = rcp_small_begin(Q, rows);
   if (rows - rbase <= 0) return; /* the whole batch is the throughput kernel's */
@@ -1472,15 +1484,13 @@ struct ResCnnSplitNet : ResCnnNet {
                                    RCS_LDS_WORDS(2, 2) * 4));
       RT_CHECK(hipFuncSetAttribute((const void *)co_k_rescnn_forward_x3_small, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    RCS_LDS_WORDS(2, 1) * 4));
+#if !CO_RESCNN_PIXMAJOR_DEFAULT
       RT_CHECK(hipFuncSetAttribute((const void *)co_k_rescnn_forward_h3, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    RCH_LDS_WORDS(2) * 4));
-      RT_CHECK(hipFuncSetAttribute((const void *)co_k_rescnn_forward_h3p, hipFuncAttributeMaxDynamicSharedMemorySize, RCP_LDS_WORDS * 4));
-#ifndef CO_RESCNN_PIXMAJOR_DEFAULT
-#define CO_RESCNN_PIXMAJOR_DEFAULT 1
 #endif
+      RT_CHECK(hipFuncSetAttribute((const void *)co_k_rescnn_forward_h3p, hipFuncAttributeMaxDynamicSharedMemorySize, RCP_LDS_WORDS * 4));
       {
-        const char *e = getenv("CORINTHO_RESCNN_PIXMAJOR"); /* diagnostic: 0 = the (position, pixel)-column kernel for every batch size */
-        pixmajor = f16 && (e ? e[0] != '0' : CO_RESCNN_PIXMAJOR_DEFAULT != 0);
+        pixmajor = f16 && CO_RESCNN_PIXMAJOR_DEFAULT != 0;
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
@@ -1536,9 +1546,12 @@ struct ResCnnSplitNet : ResCnnNet {
       if (rows_cap > RC3_SMALL_ROWS) {
         if (pixmajor)
           hipLaunchKernelGGL(co_k_rescnn_forward_h3p, dim3((rows_cap + 31) / 32), dim3(512), RCP_LDS_WORDS * 4, s, q);
+#if !CO_RESCNN_PIXMAJOR_DEFAULT
+        else if (f16)
+          hipLaunchKernelGGL(co_k_rescnn_forward_h3, dim3((rows_cap + 31) / 32), dim3(RCH_THREADS), RCH_LDS_WORDS(2) * 4, s, q);
+#endif
         else
-          hipLaunchKernelGGL(f16 ? co_k_rescnn_forward_h3 : co_k_rescnn_forward_x3, dim3((rows_cap + 31) / 32), dim3(f16 ? RCH_THREADS : 512),
-                             (f16 ? RCH_LDS_WORDS(2) : RCS_LDS_WORDS(2, 2)) * 4, s, q);
+          hipLaunchKernelGGL(co_k_rescnn_forward_x3, dim3((rows_cap + 31) / 32), dim3(512), RCS_LDS_WORDS(2, 2) * 4, s, q);
       }
     } else {
       /* enough workgroups for either path: 16 positions each in the throughput path, 8 in the thin one (<= 2048 rows) */

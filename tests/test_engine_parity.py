@@ -9,6 +9,8 @@ import numpy as np
 import pytest
 
 from corintho_ai_amd import _lib, nets
+
+from tests import ref_nets
 from oracle import oracle as O
 from tests import harness as H
 from tests import ref_scenarios as S
@@ -415,7 +417,7 @@ def test_mlp_matches_float32_restatement(engine):
         w = nets.init_mlp12x100(seed=seed, bn_noise=noise)
         t.set_net(1, w)
         ev, pr = t.net_forward(states)
-        ev0, pr0 = nets.mlp12x100_forward_np(w, states)
+        ev0, pr0 = ref_nets.mlp12x100_forward_np(w, states)
         assert np.max(np.abs(ev - ev0)) < 1e-4
         assert np.max(np.abs(pr - pr0)) < 1e-4
         assert np.all(np.abs(pr.sum(axis=1) - 1) < 1e-5)
@@ -441,7 +443,7 @@ def test_mlp_bf16x3_within_tolerance_of_float32():
         w = nets.init_mlp12x100(seed=seed, bn_noise=noise)
         t.set_net(NET_MLP12X100_X3, w)
         ev, pr = t.net_forward(states)
-        ev0, pr0 = nets.mlp12x100_forward_np(w, states)
+        ev0, pr0 = ref_nets.mlp12x100_forward_np(w, states)
         assert np.max(np.abs(ev - ev0)) < 1e-4, np.max(np.abs(ev - ev0))
         assert np.max(np.abs(pr - pr0)) < 1e-4, np.max(np.abs(pr - pr0))
         assert np.all(np.abs(pr.sum(axis=1) - 1) < 1e-5)
@@ -474,7 +476,7 @@ def test_rescnn4_matches_float32_restatement():
         w = nets.init_rescnn4(seed=seed, bn_noise=noise)
         t.set_net(NET_RESCNN4, w)
         ev, pr = t.net_forward(states)
-        ev0, pr0 = nets.rescnn4_forward_ref(w, states)
+        ev0, pr0 = ref_nets.rescnn4_forward_ref(w, states)
         assert np.max(np.abs(ev - ev0)) < 1e-4, np.max(np.abs(ev - ev0))
         assert np.max(np.abs(pr - pr0)) < 1e-4, np.max(np.abs(pr - pr0))
         assert np.all(np.abs(pr.sum(axis=1) - 1) < 1e-5)
@@ -515,7 +517,7 @@ def test_rescnn4_bf16x3_within_tolerance_of_float32():
         w = nets.init_rescnn4(seed=seed, bn_noise=noise)
         t.set_net(NET_RESCNN4_X3, w)
         ev, pr = t.net_forward(states)
-        ev0, pr0 = nets.rescnn4_forward_ref(w, states)
+        ev0, pr0 = ref_nets.rescnn4_forward_ref(w, states)
         assert np.max(np.abs(ev - ev0)) < 1e-4, np.max(np.abs(ev - ev0))
         assert np.max(np.abs(pr - pr0)) < 1e-4, np.max(np.abs(pr - pr0))
         ev1, pr1 = t.net_forward(states[9:10])

@@ -23,6 +23,7 @@ from corintho_ai_amd import (NET_MLP12X100, NET_MLP12X100_H3, NET_MLP12X100_X3, 
                              NET_RESCNN4_X3, NET_RESCNN4_X6, nets)
 from oracle import oracle as O
 from tests import harness as H
+from tests import ref_nets
 from tests.engines import make_trainer
 
 pytestmark = pytest.mark.gpu
@@ -76,11 +77,11 @@ def _check(kinds, sets, f64, label, floor):
 
 
 def test_rescnn4_bf16x6_is_float32_equivalent():
-    _check((NET_RESCNN4, NET_RESCNN4_X6, NET_RESCNN4_X3, NET_RESCNN4_H3), CNN_SETS, nets.rescnn4_forward_f64, "rescnn4", 2.4e-7)
+    _check((NET_RESCNN4, NET_RESCNN4_X6, NET_RESCNN4_X3, NET_RESCNN4_H3), CNN_SETS, ref_nets.rescnn4_forward_f64, "rescnn4", 2.4e-7)
 
 
 def test_mlp12x100_bf16x6_is_float32_equivalent():
-    _check((NET_MLP12X100, NET_MLP12X100_X6, NET_MLP12X100_X3, NET_MLP12X100_H3), MLP_SETS, nets.mlp12x100_forward_f64, "mlp12x100", 2.4e-7)
+    _check((NET_MLP12X100, NET_MLP12X100_X6, NET_MLP12X100_X3, NET_MLP12X100_H3), MLP_SETS, ref_nets.mlp12x100_forward_f64, "mlp12x100", 2.4e-7)
 
 
 @pytest.mark.parametrize("kind,make", [(NET_RESCNN4_X6, lambda: nets.trained_like_rescnn4(2)),

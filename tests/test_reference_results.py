@@ -34,6 +34,8 @@ import numpy as np
 import pytest
 
 from corintho_ai_amd import NET_MLP12X100, Tourney, nets
+
+from tests import ref_nets
 from oracle import oracle as O
 from tests import harness as H
 from tests.conftest import REFERENCE
@@ -96,7 +98,7 @@ def test_one_search_pairing_at_the_reference_seed_positions():
     for _ in range(pairs):
         t.addMatch(0, 1, False)
         t.addMatch(1, 0, False)
-    H.play_tourney(t, [-1, 0], {0: lambda s: nets.mlp12x100_forward_np(w, s)}, rows=2 * pairs)
+    H.play_tourney(t, [-1, 0], {0: lambda s: ref_nets.mlp12x100_forward_np(w, s)}, rows=2 * pairs)
     sc = np.array([t.match_score(i) for i in range(2 * pairs)])
     p_first = float(np.mean(sc[0::2] == 1.0))
     p_second = float(np.mean(sc[1::2] == 0.0))
@@ -110,7 +112,7 @@ def test_oracle_reproduces_the_reference_rates():
     w = np.load(os.path.join(GOLDEN, "trained_last.npz"))["weights"]
     n_each = 1500
     t = _play(lambda: O.Tourney(8, ""), n_each)
-    H.play_tourney(t, [-1, 0], {0: lambda s: nets.mlp12x100_forward_np(w, s)}, rows=2 * n_each)
+    H.play_tourney(t, [-1, 0], {0: lambda s: ref_nets.mlp12x100_forward_np(w, s)}, rows=2 * n_each)
     scores = [t.match_score(i) for i in range(2 * n_each)]
     p1, p2, pd = _rates(scores, n_each)
     print("oracle: model_93 @ 1 search wins %.3f moving first (reference %.3f), %.3f moving second (reference %.3f), draws %.3f"
@@ -226,7 +228,7 @@ def test_exact_offsets_switch_equals_oracle(engine):
         for i in range(n):
             t.addMatch(*((a, b) if i % 3 else (b, a)), False)
         t.set_exact_offsets(True)
-    nets_by_model = {m: (lambda s, m=m: nets.mlp12x100_forward_np(W[m], s)) for m in (PLAYER_MODEL[a], PLAYER_MODEL[b])}
+    nets_by_model = {m: (lambda s, m=m: ref_nets.mlp12x100_forward_np(W[m], s)) for m in (PLAYER_MODEL[a], PLAYER_MODEL[b])}
     ids = sorted(nets_by_model)
     H.play_tourney(o, ids, nets_by_model, rows=n * 8)
     H.play_tourney(e, ids, nets_by_model, rows=n * 8)

@@ -9,6 +9,8 @@ import numpy as np
 import pytest
 
 from corintho_ai_amd import nets
+
+from tests import ref_nets
 from corintho_ai_amd import tflite_import as TI
 from tests import tflite_writer as TW
 from tests.engines import ENGINES, make_trainer
@@ -36,9 +38,9 @@ def test_import_of_a_synthetic_checkpoint(with_bias):
     assert imported.size == nets.MLP_NUM_WEIGHTS
     s = _states(300)
     # the imported flat weights, the stored graph and the un-folded Keras weights are one function
-    ev_i, pr_i = nets.mlp12x100_forward_np(imported, s)
+    ev_i, pr_i = ref_nets.mlp12x100_forward_np(imported, s)
     g = TI.tflite_forward_np(m, s)
-    ev_k, pr_k = nets.mlp12x100_forward_np(w, s)
+    ev_k, pr_k = ref_nets.mlp12x100_forward_np(w, s)
     assert np.max(np.abs(ev_i - g[roles["value"]][:, 0])) < 1e-6
     assert np.max(np.abs(pr_i - g[roles["policy"]])) < 1e-6
     assert np.max(np.abs(ev_i - ev_k)) < 1e-4 and np.max(np.abs(pr_i - pr_k)) < 1e-4
@@ -76,7 +78,7 @@ def test_reference_checkpoints_import():
         m = TI.read_tflite(path)
         roles = TI.output_roles(m)
         w = TI.mlp12x100_from_tflite(path)
-        ev, pr = nets.mlp12x100_forward_np(w, s)
+        ev, pr = ref_nets.mlp12x100_forward_np(w, s)
         g = TI.tflite_forward_np(m, s)
         assert np.max(np.abs(ev - g[roles["value"]][:, 0])) < 1e-4, path  # BLAS summation order differs
         assert np.max(np.abs(pr - g[roles["policy"]])) < 1e-4, path

@@ -13,6 +13,8 @@ import numpy as np
 import pytest
 
 from corintho_ai_amd import NET_MLP12X100, NET_MLP12X100_H3, NET_MLP12X100_X3, NET_MLP12X100_X6, nets
+
+from tests import ref_nets
 from oracle import oracle as O
 from tests import harness as H
 from tests.engines import ENGINES, make_trainer
@@ -31,9 +33,9 @@ def test_float64_restatement_reproduces_the_stored_graph(tag):
     """CPU: the engine's weight layout evaluated in float64 is the checkpoint's graph in float64, and the
     float32 restatement is within float32 rounding of it"""
     z = load(tag)
-    v, p = nets.mlp12x100_forward_f64(z["weights"], z["states"])
+    v, p = ref_nets.mlp12x100_forward_f64(z["weights"], z["states"])
     assert np.max(np.abs(v - z["value_f64"])) < 2e-6 and np.max(np.abs(p - z["policy_f64"])) < 2e-6
-    v32, p32 = nets.mlp12x100_forward_np(z["weights"], z["states"])
+    v32, p32 = ref_nets.mlp12x100_forward_np(z["weights"], z["states"])
     assert np.max(np.abs(v32 - z["value_f64"])) < 2e-5 and np.max(np.abs(p32 - z["policy_f64"])) < 2e-5
 
 

@@ -9,6 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from corintho_ai_amd import Trainer, nets  # noqa: E402
+from tests import ref_nets
 import _wino_lib  # noqa: E402
 
 L = _wino_lib.load()
@@ -27,7 +28,7 @@ t = Trainer(8192, "", 1, 50, 16, 1.0, 0.25, 0, 1, False, _cdll=L)
 st = states(777)
 for name, w in (("init", nets.init_rescnn4(0)), ("bn-noise", nets.init_rescnn4(3, bn_noise=True)),
                 ("trained-like-0", nets.trained_like_rescnn4(0)), ("trained-like-1", nets.trained_like_rescnn4(1))):
-    want = nets.rescnn4_forward_f64(w, st)
+    want = ref_nets.rescnn4_forward_f64(w, st)
     line = name
     for kind in (2, 5, 7):
         t.set_net(kind, w)

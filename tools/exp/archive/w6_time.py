@@ -9,6 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from corintho_ai_amd import Trainer, nets  # noqa: E402
+from tests import ref_nets
 import _wino_lib  # noqa: E402
 
 L = _wino_lib.load()
@@ -27,7 +28,7 @@ def states(n):
 t = Trainer(8192, "", 1, 50, 16, 1.0, 0.25, 0, 1, False, _cdll=L)
 st = states(777)
 w = nets.trained_like_rescnn4(1)
-want = nets.rescnn4_forward_f64(w, st)
+want = ref_nets.rescnn4_forward_f64(w, st)
 out = []
 for kind in kinds:
     t.set_net(kind, w)

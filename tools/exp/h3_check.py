@@ -9,6 +9,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import corintho_ai_amd as CA  # noqa: E402
+from tests import ref_nets
 from corintho_ai_amd import Trainer, nets  # noqa: E402
 
 
@@ -33,8 +34,8 @@ for tag in ("early", "middle", "last"):
 d = np.load(os.path.join(G, "ref_models.npz"))
 for k in d.files:
     mlp.append((k, d[k]))
-for label, sets, f64, kinds in (("rescnn4", cnn, nets.rescnn4_forward_f64, ("NET_RESCNN4", "NET_RESCNN4_X6", "NET_RESCNN4_H3", "NET_RESCNN4_X3")),
-                                ("mlp12x100", mlp, nets.mlp12x100_forward_f64, ("NET_MLP12X100", "NET_MLP12X100_X6", "NET_MLP12X100_H3", "NET_MLP12X100_X3"))):
+for label, sets, f64, kinds in (("rescnn4", cnn, ref_nets.rescnn4_forward_f64, ("NET_RESCNN4", "NET_RESCNN4_X6", "NET_RESCNN4_H3", "NET_RESCNN4_X3")),
+                                ("mlp12x100", mlp, ref_nets.mlp12x100_forward_f64, ("NET_MLP12X100", "NET_MLP12X100_X6", "NET_MLP12X100_H3", "NET_MLP12X100_X3"))):
     for name, w in sets:
         for st_name, st in (("synthetic", S), ("self-play", real)):
             want = f64(w, st)

@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Experiment: the pixel-major f16x3 throughput kernel (K6p, nn_rescnn.hip co_k_rescnn_forward_h3p) against the
-(position, pixel)-column kernel it replaces -- same library, CORINTHO_RESCNN_PIXMAJOR=0/1 picks the kernel when the
-network is set.  Prints kernel-only ms per evaluation for several batch sizes and checks that the two kernels give
-the same bits.  usage (GPU box): python tools/exp/pixmajor_ab.py [lib.so]"""
+(position, pixel)-column kernel it replaces.  The product library holds the pixel-major kernel only (round 5: no
+environment switch, no dead kernel in the shipped library); the other one comes from a diagnostic build,
+    tools/build_variant.sh colmajor -DCO_RESCNN_PIXMAJOR_DEFAULT=0
+Prints kernel-only ms per evaluation for several batch sizes and checks that the two kernels give the same bits.
+usage (GPU box): python tools/exp/pixmajor_ab.py build_ab/colmajor.so [product.so]"""
 import ctypes as C
 import os
 import sys
@@ -13,7 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 from corintho_ai_amd import NET_RESCNN4_H3, Trainer, _lib, nets  # noqa: E402
 
-L = _lib.declare(C.CDLL(os.path.abspath(sys.argv[1]))) if len(sys.argv) > 1 else None
+LIBS = {"0": _lib.declare(C.CDLL(os.path.abspath(sys.argv[1]))),
+        "1": _lib.declare(C.CDLL(os.path.abspath(sys.argv[2]))) if len(sys.argv) > 2 else None}
 
 rng = np.random.default_rng(0)
 R = 65536
@@ -23,8 +26,7 @@ st[:, 64:] = rng.integers(0, 5, (R, 6)) * 0.25
 w = nets.init_rescnn4(0, bn_noise=True)
 out = {}
 for pm in ("0", "1"):
-    os.environ["CORINTHO_RESCNN_PIXMAJOR"] = pm
-    t = Trainer(R // 16, "", 1, 50, 16, 1.0, 0.25, 0, 1, False, stagger=False, _cdll=L)
+    t = Trainer(R // 16, "", 1, 50, 16, 1.0, 0.25, 0, 1, False, stagger=False, _cdll=LIBS[pm])
     t.set_net(NET_RESCNN4_H3, w)
     ev, pr = t.net_forward(st[:20000])
     out[pm] = (ev, pr)

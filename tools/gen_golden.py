@@ -19,6 +19,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from corintho_ai_amd import nets  # noqa: E402
+from tests import ref_nets
 from oracle import oracle as O  # noqa: E402
 from tests import harness as H  # noqa: E402
 
@@ -122,10 +123,10 @@ def net_vectors():
     r = H.play_generation(t, 4, 8, H.hash_net, record=True)
     states = np.concatenate([a[1] for a in r["log"]])[:256]
     out = {"states": states}
-    for name, w, f in (("mlp_seed0", nets.init_mlp12x100(0), nets.mlp12x100_forward_np),
-                       ("mlp_seed1_noise", nets.init_mlp12x100(1, bn_noise=True), nets.mlp12x100_forward_np),
-                       ("rescnn4_seed0", nets.init_rescnn4(0), nets.rescnn4_forward_ref),
-                       ("rescnn4_seed3_noise", nets.init_rescnn4(3, bn_noise=True), nets.rescnn4_forward_ref)):
+    for name, w, f in (("mlp_seed0", nets.init_mlp12x100(0), ref_nets.mlp12x100_forward_np),
+                       ("mlp_seed1_noise", nets.init_mlp12x100(1, bn_noise=True), ref_nets.mlp12x100_forward_np),
+                       ("rescnn4_seed0", nets.init_rescnn4(0), ref_nets.rescnn4_forward_ref),
+                       ("rescnn4_seed3_noise", nets.init_rescnn4(3, bn_noise=True), ref_nets.rescnn4_forward_ref)):
         ev, pr = f(w, states)
         out[name + "_value"] = ev.astype(np.float32)
         out[name + "_policy"] = pr.astype(np.float32)

@@ -22,6 +22,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from corintho_ai_amd import nets  # noqa: E402
+from tests import ref_nets
 from corintho_ai_amd import tflite_import as TI  # noqa: E402
 
 REF = "/root/reference/corintho_ai/rating/tflite_models"
@@ -40,7 +41,7 @@ def main():
         g = TI.tflite_forward_np(m, states, dtype=np.float64)
         v64, p64 = g[roles["value"]][:, 0], g[roles["policy"]]
         # the import is faithful: the engine's layout evaluated in float64 is the stored graph in float64
-        v2, p2 = nets.mlp12x100_forward_f64(w, states)
+        v2, p2 = ref_nets.mlp12x100_forward_f64(w, states)
         assert np.max(np.abs(v2 - v64)) < 2e-6 and np.max(np.abs(p2 - p64)) < 2e-6, (np.max(np.abs(v2 - v64)), np.max(np.abs(p2 - p64)))
         name = os.path.basename(path)
         np.savez_compressed(os.path.join(OUT, "trained_%s.npz" % tag), weights=w, states=states, value_f64=v64, policy_f64=p64,
@@ -61,7 +62,7 @@ def extra_models(ids=(92, 4)):
         roles = TI.output_roles(m)
         states = np.load(os.path.join(OUT, "net_vectors.npz"))["states"][:64]
         g = TI.tflite_forward_np(m, states, dtype=np.float64)
-        v2, p2 = nets.mlp12x100_forward_f64(w, states)
+        v2, p2 = ref_nets.mlp12x100_forward_f64(w, states)
         assert np.max(np.abs(v2 - g[roles["value"]][:, 0])) < 2e-6 and np.max(np.abs(p2 - g[roles["policy"]])) < 2e-6
         out["model_%d" % i] = w
     np.savez_compressed(os.path.join(OUT, "ref_models.npz"), **out)
@@ -92,7 +93,7 @@ def population_models():
         m = TI.read_tflite(path)
         roles = TI.output_roles(m)
         g = TI.tflite_forward_np(m, states, dtype=np.float64)
-        v2, p2 = nets.mlp12x100_forward_f64(w, states)
+        v2, p2 = ref_nets.mlp12x100_forward_f64(w, states)
         assert np.max(np.abs(v2 - g[roles["value"]][:, 0])) < 2e-6 and np.max(np.abs(p2 - g[roles["policy"]])) < 2e-6
         out["model_%d" % i] = w
     np.savez_compressed(os.path.join(OUT, "ref_models_pop.npz"), **out)
