@@ -38,9 +38,13 @@ class SampleGather:
         self.games = games_per_rank
         self.cap = games_per_rank * MAX_PLIES  # upper bound of a rank's rows; the gather moves max(count) of them
         dev = "cuda" if on_device else "cpu"
+        self.dev = dev
         self.on_device = on_device
-        self.buf = torch.zeros((self.cap * ROW_FLOATS,), dtype=torch.float32, device=dev)
-        self.all = torch.zeros((self.world * self.cap * ROW_FLOATS,), dtype=torch.float32, device=dev)
+        # The payload buffers are sized AFTER the counts are known (round 5): world x max(count) rows, not
+        # world x games x 44 plies -- 963 MB per rank at 8 x 4096 games before, ~400 MB for the ~17 plies games have.
+        # They are kept and only grow (a generation's counts vary by a few per cent).
+        self.buf = None
+        self.all = None
         self.cnt = torch.zeros((1,), dtype=torch.int32, device=dev)
         self.all_cnt = torch.zeros((self.world,), dtype=torch.int32, device=dev)
         self.pair = torch.zeros((2,), dtype=torch.float64, device=dev)
@@ -55,7 +59,12 @@ class SampleGather:
         counts = self.all_cnt.cpu().numpy().astype(np.int64)
         max_n = int(counts.max())
         if max_n == 0:
-            return counts, 0, self.all[:0]
+            return counts, 0, self.torch.zeros((0,), dtype=self.torch.float32, device=self.dev)
+        assert max_n <= self.cap, (max_n, self.cap)
+        if self.buf is None or self.buf.numel() < max_n * ROW_FLOATS:
+            rows = min(self.cap, max_n + max_n // 8 + 64)  # some headroom, so that the next generations reuse it
+            self.buf = self.torch.zeros((rows * ROW_FLOATS,), dtype=self.torch.float32, device=self.dev)
+            self.all = self.torch.zeros((self.world * rows * ROW_FLOATS,), dtype=self.torch.float32, device=self.dev)
         sp = self.buf[:max_n * SAMPLE_FLOATS]
         oc = self.buf[max_n * SAMPLE_FLOATS:max_n * ROW_FLOATS]
         if self.on_device:

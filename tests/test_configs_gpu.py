@@ -6,7 +6,8 @@ device network: samples, score, mate length bit for bit; the reference's counter
 which runs the one code path there is), and so is the bench's `recycled` variant (16 384 games on the 4 096 slots).
 tests/test_engine_parity.py::test_full_size_generation_properties adds the size-independent properties, determinism and
 sharding for the same configuration.  Configs 3-5 are checked through size-independent properties plus an oracle replay
-of a slice (cfg3: 32 games of the shard; cfg4: a 512-game generation whole; cfg5: all 1024 games), bit for bit.
+of a slice (cfg3: 32 games of the shard; cfg4: a 512-game generation whole and 512 games of the full-size one; cfg5:
+all 1024 games), bit for bit -- at the bench's arithmetic (f16x3) and at bf16x6.
 
   cfg3  32 768 games sharded over 8 GPUs: ONE shard of it on this GPU -- rank 7 of 8, games
         [28 672, 32 768), seeds / parity / colours on the global index (trainer.cpp:243-255)
@@ -60,16 +61,16 @@ def _replay_whole_generation(t, G, sims, spe, seed, c_puct=1.0, eps=0.25):
     return o
 
 
-@pytest.mark.parametrize("games,slots", [(4096, -1), (16384, 4096)], ids=["default", "recycled"])
-def test_cfg2_the_bench_default_whole_on_the_oracle(games, slots):
-    """what `python bench.py` times (and its `recycled` variant): NET_RESCNN4_H3, evaluation cache on, two pools,
-    400 sims/move, seed 12345 -- every game replayed on the oracle"""
+@pytest.mark.parametrize("games,slots,pools", [(4096, -1, 0), (4096, -1, 2), (16384, 4096, 0)], ids=["default", "two_pools", "recycled"])
+def test_cfg2_the_bench_default_whole_on_the_oracle(games, slots, pools):
+    """what `python bench.py` times (its `two_pools` record of rounds 1-4, its `recycled` variant): NET_RESCNN4_H3,
+    evaluation cache on, the engine's default of three pools, 400 sims/move, seed 12345 -- every game replayed on the oracle"""
     S_, spe, seed = 400, 16, 12345
-    t = make_trainer("hip", games, "", seed, S_, spe, 1.0, 0.25, 0, 1, False, stagger=False, resident=slots, pools=2)
+    t = make_trainer("hip", games, "", seed, S_, spe, 1.0, 0.25, 0, 1, False, stagger=False, resident=slots, pools=pools)
     t.set_net(NET_RESCNN4_H3, nets.init_rescnn4(0))
     assert t.run()
     st = t.stats()
-    assert st["resident_slots"] == 4096 and st["pools"] == 2
+    assert st["resident_slots"] == 4096 and st["pools"] == (pools or 3)
     assert st["nn_rows"] == st["evals"] > 0
     assert 0 < st["nn_rows_evaluated"] < 0.9 * st["nn_rows"]  # the evaluation cache is on and serves rows
     _replay_whole_generation(t, games, S_, spe, seed)
@@ -97,11 +98,15 @@ def _check_training_generation(t, G):
     return gs, ev, pr
 
 
-def test_cfg3_one_shard_of_the_32768_game_generation():
+KINDS = [pytest.param(NET_RESCNN4_H3, id="f16x3"), pytest.param(NET_RESCNN4_X6, id="bf16x6")]  # the bench's arithmetic first
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_cfg3_one_shard_of_the_32768_game_generation(kind):
     G, TOTAL, BASE, S_, spe, seed = 4096, 32768, 28672, 400, 16, 12345
     w = nets.init_rescnn4(0)
     t = make_trainer("hip", G, "", seed, S_, spe, 1.0, 0.25, 0, 1, False, stagger=False, game_base=BASE, total_games=TOTAL)
-    t.set_net(NET_RESCNN4_X6, w)
+    t.set_net(kind, w)
     assert t.run()
     _check_training_generation(t, G)
     sp_all, oc_all = t.export_samples()
@@ -117,16 +122,18 @@ def test_cfg3_one_shard_of_the_32768_game_generation():
         assert t.game_info(g)["result"] == o.game_result(g)
     # the shard's seeds are those of the global indices: the same 32 local games of shard 0 differ
     t0 = make_trainer("hip", NREPLAY, "", seed, S_, spe, 1.0, 0.25, 0, 1, False, stagger=False, game_base=0, total_games=TOTAL)
-    t0.set_net(NET_RESCNN4_X6, w)
+    t0.set_net(kind, w)
     assert t0.run()
     assert t0.export_samples()[0].tobytes() != sp_all[:m].tobytes()
 
 
 def test_cfg4_1600_simulations_with_dirichlet_noise():
+    """full size at the bench's arithmetic; the first 512 games replayed on the oracle (round 4: 32 at bf16x6)"""
     G, S_, spe, seed = 4096, 1600, 16, 12345
+    N4 = 512
     w = nets.init_rescnn4(0)
     t = make_trainer("hip", G, "", seed, S_, spe, 1.0, 0.25, 0, 1, False, stagger=False)
-    t.set_net(NET_RESCNN4_X6, w)
+    t.set_net(NET_RESCNN4_H3, w)
     assert t.run()
     _check_training_generation(t, G)
     st = t.stats()
@@ -136,8 +143,8 @@ def test_cfg4_1600_simulations_with_dirichlet_noise():
     assert 0 < st["peak_arena_units"] < cap, st["peak_arena_units"]
     assert st["searches"] > G * S_ * 8  # ~18 plies per game; tree reuse and solved roots make a ply cheaper than 1600 new simulations
     sp_all, oc_all = t.export_samples()
-    m = sum(t.game_info(g)["n_samples"] for g in range(NREPLAY))
-    o = _replay_first_games(t, G, 0, S_, spe, seed)
+    m = sum(t.game_info(g)["n_samples"] for g in range(N4))
+    o = _replay_first_games(t, G, 0, S_, spe, seed, n=N4)
     ogs, oev, opr = H.get_samples(o)
     assert ogs.shape[0] == m * 8
     assert ogs[0::8].tobytes() == sp_all[:m, :70].tobytes()
@@ -147,12 +154,13 @@ def test_cfg4_1600_simulations_with_dirichlet_noise():
           % (st["peak_arena_units"], cap, st["plies"] / G, st["evals"] / G))
 
 
-def test_cfg5_arena_1024_two_model_games():
+@pytest.mark.parametrize("kind", KINDS)
+def test_cfg5_arena_1024_two_model_games(kind):
     G, S_, spe, seed = 1024, 400, 16, 77
     wa, wb = nets.init_rescnn4(0), nets.init_rescnn4(1)
     t = make_trainer("hip", G, "", seed, S_, spe, 1.0, 0.25, 0, 1, True, trace=True)
-    t.set_net(NET_RESCNN4_X6, wa, slot=0)  # best model
-    t.set_net(NET_RESCNN4_X6, wb, slot=1)  # new model
+    t.set_net(kind, wa, slot=0)  # best model
+    t.set_net(kind, wb, slot=1)  # new model
     assert t.run()
     infos = [t.game_info(g) for g in range(G)]
     assert all(i["done"] == 1 and i["error"] == 0 for i in infos)

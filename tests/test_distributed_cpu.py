@@ -1,12 +1,13 @@
-"""World-size-2 test of the sharded path on CPU: two processes (gloo, 127.0.0.1), each
-running its shard of one generation on the emulation build of the engine, then the
-per-generation sample all-gather; the gathered, x8-expanded samples must equal what ONE
-trainer over all games writes (Trainer::writeSamples order, trainer.cpp:103-113)."""
+"""Tests of the sharded path on CPU at world sizes 2 and 8 (the size BASELINE configs[2] asks for): one process per rank
+(gloo, 127.0.0.1), each running its shard of one generation on the emulation build of the engine, then the
+per-generation sample all-gather; the gathered, x8-expanded samples must equal what ONE trainer over all games writes
+(Trainer::writeSamples order, trainer.cpp:103-113; seeds and colours on the global index, :243-255)."""
 import os
 import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -22,7 +23,7 @@ from tests import harness as H
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
 L = emulib.load()
-G, S, spe = 6, 24, 8
+G, S, spe = %(games)d, 24, 8
 base, total = shard(rank, world, G)
 t = Trainer(G, "", 4242, S, spe, 1.0, 0.25, 0, 1, False, stagger=False, game_base=base, total_games=total, _cdll=L)
 t.set_net(1, nets.init_mlp12x100(0, bn_noise=True))
@@ -38,12 +39,13 @@ dist.destroy_process_group()
 """
 
 
-def test_two_rank_sharded_generation_matches_single_trainer(tmp_path):
+@pytest.mark.parametrize("world,games,port", [(2, 6, "29533"), (8, 3, "29541")], ids=["2_ranks", "8_ranks"])
+def test_sharded_generation_matches_single_trainer(tmp_path, world, games, port):
     out = str(tmp_path / "gathered.npz")
     script = tmp_path / "worker.py"
-    script.write_text(WORKER % {"root": ROOT, "out": out})
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2", OMP_NUM_THREADS="2")
-    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r))) for r in range(2)]
+    script.write_text(WORKER % {"root": ROOT, "out": out, "games": games})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, WORLD_SIZE=str(world), OMP_NUM_THREADS="1" if world > 2 else "2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r))) for r in range(world)]
     for p in procs:
         assert p.wait(timeout=600) == 0
     got = np.load(out)
@@ -52,7 +54,7 @@ def test_two_rank_sharded_generation_matches_single_trainer(tmp_path):
     from tests import harness as H
     from tests.emu import emulib
 
-    t = Trainer(12, "", 4242, 24, 8, 1.0, 0.25, 0, 1, False, stagger=False, _cdll=emulib.load())
+    t = Trainer(world * games, "", 4242, 24, 8, 1.0, 0.25, 0, 1, False, stagger=False, _cdll=emulib.load())
     t.set_net(1, nets.init_mlp12x100(0, bn_noise=True))
     assert t.run()
     gs, ev, pr = H.get_samples(t)
@@ -61,7 +63,7 @@ def test_two_rank_sharded_generation_matches_single_trainer(tmp_path):
     assert got["pr"].tobytes() == pr.tobytes()
     assert abs(float(got["score"]) - t.score()) < 1e-6
     # the payload all-gather is sized by the largest shard, not by the 44-ply upper bound
-    assert int(got["moved"]) < 2 * int(got["rows"]) * 167 * 4 * 1.5
+    assert int(got["moved"]) < world * (int(got["rows"]) / world) * 167 * 4 * (1.5 if world == 2 else 2.5)
 
 
 def _bench(args, env_extra=None, timeout=900):
@@ -99,6 +101,25 @@ def test_bench_gpus_2_launches_two_ranks_itself():
     assert r1.returncode == 0, r1.stderr[-2000:]
     o1 = json.loads(r1.stdout.strip().splitlines()[-1])
     assert o1["n_gpus"] == 1 and o1["detail"]["ranks_seen"] == 1 and "collectives_per_step" not in o1["detail"]
+
+
+def test_bench_gpus_8_rehearsal():
+    """the eight ranks of BASELINE configs[2], tiny, on the emulation build over gloo: every rank seen, the gathered
+    samples = the sum of the eight shards, value = all games over the slowest rank's time"""
+    import json
+
+    tiny8 = [a if a != "6" else "2" for a in TINY]  # 2 games per rank
+    r = _bench(["--gpus", "8"] + tiny8, env_extra={"OMP_NUM_THREADS": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["scaling"] == "weak"
+    d = out["detail"]
+    assert d["world_size"] == 8 and d["ranks_seen"] == 8 and len(d["per_rank_games_per_s"]) == 8
+    c = d["collectives_per_step"]
+    assert c["samples_gathered"] == c["samples_of_all_shards"] > 0 and c["unfinished_games"] == 0
+    assert abs(out["value"] - 16 / (out["ms_per_step"] * 1e-3)) < 1e-6 * out["value"]
 
 
 def test_bench_ends_every_rank_when_one_dies_during_set_up():
