@@ -1119,6 +1119,7 @@ struct ca_trainer {
     };
     /* the table was emptied in mid-generation (a new network, set_net): pending leaves point into its old contents */
     bool emptied_before_resuming = cache_clean_now && iterations > 0;
+    long long guard_from = -1; /* the no-claim iteration behind the last emptying in mid-generation (EvalCache::guard_from) */
     while (!all_finished && (max_iterations <= 0 || it < max_iterations)) {
       const int parity = window & 1;
       bool emptied = emptied_before_resuming; /* (EvalCache::no_claim) */
@@ -1160,6 +1161,14 @@ struct ca_trainer {
         pp.pack_counter = pack_counter.p + 2 * p;
         pp.cache = q.cache; /* (hdr null: no cache) */
         pp.cache.no_claim = emptied ? 1u : 0u;
+        if (emptied) guard_from = trainer_iteration;
+        pp.cache.guard_pools = 0u;
+        if (guard_from >= 0 && trainer_iteration <= guard_from + 2 * poll + 1) {
+          /* (the streams are within two windows of each other: the host waits for window w - 1 before it queues w + 1) */
+          pp.cache.guard_from = (uint32_t)guard_from;
+          for (int p2 = 0; p2 < npools; ++p2)
+            if (!pools[p2].finished) pp.cache.guard_pools |= 1u << p2;
+        }
         const bool timed = in_window == poll - 1 || (max_iterations > 0 && it + 1 == max_iterations);
         /* The network launch is sized by what the batch can hold: the games still running at the pool's last poll (they
          * only become fewer) times the searches per evaluation.  In a generation's thin tail the throughput kernel is

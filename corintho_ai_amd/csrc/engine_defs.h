@@ -127,6 +127,14 @@ struct EvalCache {
                           * pending leaves of EVERY pool still point at elements of the old contents, which a pool reads
                           * during this iteration -- an entry claimed now could be another pool's network launch writing
                           * into an element a third party has yet to read.  One iteration later nothing points there. */
+  /* The pools' streams are only level at the emptying itself; behind it each runs on by itself.  So for a few windows
+   * behind an emptying (the host cannot know more than that the streams are within two windows of each other) a claim
+   * also needs every pool in guard_pools to be past the no-claim iteration: done[p] > guard_from, i.e. p's search launch
+   * of the iteration behind it has started and its priors and search launches of the no-claim iteration -- the last
+   * ones that read through pend_src into the OLD contents -- are over.  (a pool with short launches
+   * could claim a slot and have it written while a slower pool was still reading the element.)  guard_pools == 0: no guard. */
+  uint32_t guard_from;
+  uint32_t guard_pools;
   uint32_t *done;      /* [CO_MAX_POOLS] shared: the network launches of pool p's iterations < done[p] have completed
                         * (stored by the first wave of p's next search launch, which stream order puts behind them) */
   int32_t *in_idx;     /* [pool rows] request rows the network evaluates this iteration, compact ... */

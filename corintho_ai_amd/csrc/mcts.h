@@ -2157,6 +2157,11 @@ CO_DEV uint32_t co_cache_hash(uint32_t k0, uint32_t k1, uint32_t k2) {
 CO_DEV void co_cache_resolve(const EngineParams &P, CoWave &w, int g, int n, int row0) {
   const EvalCache &C = P.cache;
   const int par = P.iteration & 1;
+  int may_claim = !C.no_claim;
+  if (may_claim && C.guard_pools) { /* an emptying not long ago: see EvalCache::guard_from */
+    for (uint32_t p = 0; p < 4u; ++p)
+      if (((C.guard_pools >> p) & 1u) && co_atomic_load_u32(C.done + p) <= C.guard_from) may_claim = 0;
+  }
   LV(int, slot);
   LV(int, need);
   FOR_LANES {
@@ -2178,7 +2183,7 @@ CO_DEV void co_cache_resolve(const EngineParams &P, CoWave &w, int g, int n, int
         uint32_t *H = C.hdr + (size_t)s * 4;
         uint32_t e0 = co_lane_load_coherent_u32(H + 0), e1 = co_lane_load_coherent_u32(H + 1), e2 = co_lane_load_coherent_u32(H + 2);
         if (e2 == 0u) {
-          if (C.no_claim) break; /* (EvalCache::no_claim: the row is evaluated into its scratch element) */
+          if (!may_claim) break; /* (EvalCache::no_claim, guard_from: the row is evaluated into its scratch element) */
           e2 = co_lane_cas_u32(H + 2, 0u, mine);
           if (e2 == 0u) {
             co_lane_store_coherent_u32(H + 0, x0);

@@ -186,3 +186,19 @@ def test_cfg5_arena_1024_two_model_games(kind):
         assert np.array_equal(t.trace(g), o.trace(g)), "game %d" % g
         assert infos[g]["result"] == o.game_result(g)
     assert t.score() == o.score()
+
+
+@pytest.mark.parametrize("pools,bits,seed", [(2, 14, 1), (3, 14, 2), (3, 17, 3)], ids=["2_pools_2^14", "3_pools_2^14", "3_pools_2^17"])
+def test_shared_cache_table_under_real_concurrency(pools, bits, seed):
+    """The pools share one evaluation-cache table through relaxed atomics, per-pool progress words and an emptying protocol
+    (DESIGN section 4; mcts.h co_cache_resolve, EvalCache::guard_from).  The emulation build runs the pools of an iteration
+    one after the other and cannot see a race; here the streams really run side by side, with tables so small that they
+    are emptied hundreds of times per generation -- and every game must still replay on the oracle bit for bit.
+    (tools/exp/cache_stress.py as a test)"""
+    G = 1024
+    t = make_trainer("hip", G, "", seed, 400, 16, 1.0, 0.25, 0, 1, False, stagger=False, pools=pools, eval_cache=bits)
+    t.set_net(NET_RESCNN4_H3, nets.init_rescnn4(0))
+    assert t.run()
+    st = t.stats()
+    assert st["pools"] == pools and 0 < st["nn_rows_evaluated"] < st["nn_rows"]
+    _replay_whole_generation(t, G, 400, 16, seed)

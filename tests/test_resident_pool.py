@@ -153,10 +153,10 @@ def test_reference_production_setting_25000_games_1600_simulations():
 # ---------------------------------------------------------------------------------------------------------------
 def test_the_pools_share_one_cache_table():
     """round 4: ONE table for all pools -- a position another pool evaluated in an earlier iteration is not evaluated
-    again (what both reach in the same iteration still is).  On the emulation build the pools of an iteration run one after
-    the other, so the counts are reproducible to a few rows (two waves that claim for the same position in the same
-    instant may both evaluate it): 30 831 / 31 185 / 31 277 rows with one / two / three pools, where a table per pool
-    evaluated 31 443 and 31 729."""
+    again (what both reach in the same iteration still is).  The counts themselves depend on how the waves interleave (two
+    that claim for one position in the same instant both evaluate it), on the thread count and on the pools' order within an
+    iteration, so only what must hold is asserted: the cache serves rows, more pools lose a little to the
+    one iteration of lag, and even three pools on one table beat what a table per pool evaluated (31 443 with two pools)."""
     w = nets.init_mlp12x100(seed=3, bn_noise=True)
     got = {}
     for pools in (1, 2, 3):
@@ -167,7 +167,8 @@ def test_the_pools_share_one_cache_table():
         got[pools] = st["nn_rows_evaluated"]
         assert st["nn_rows"] == 35584
         t.close()
-    assert abs(got[1] - 30831) <= 10 and got[1] < got[2] <= 31185 + 20 and got[2] < got[3] <= 31277 + 20, got
+    assert got[1] < got[2] < got[3] < 31443, got
+    assert got[1] < 0.88 * 35584, got
 
 
 # Evaluation cache (ca_config.eval_cache): a request row whose position was evaluated earlier in the generation gets the
