@@ -635,7 +635,6 @@ struct ca_trainer {
     }
     P.to_play = to_play;
     P.iteration = trainer_iteration;
-    RT_LAUNCH(co_k_priors, ((R) * P.searches_per_eval + CO_WAVES_PER_BLOCK - 1) / CO_WAVES_PER_BLOCK, CO_WAVE * CO_WAVES_PER_BLOCK, stream, P);
     RT_LAUNCH(co_k_mcts_step, ((R) + CO_K3_WAVES - 1) / CO_K3_WAVES, CO_WAVE * CO_K3_WAVES, stream, P);
     if (to_play == -1) ++trainer_iteration;
     ++iterations;
@@ -685,7 +684,6 @@ struct ca_trainer {
       rt_h2d(nn_probs.p, probs, (size_t)rows * CO_NUM_MOVES * 4, stream);
     }
     P.iteration = trainer_iteration;
-    RT_LAUNCH(co_k_priors, ((R) * P.searches_per_eval + CO_WAVES_PER_BLOCK - 1) / CO_WAVES_PER_BLOCK, CO_WAVE * CO_WAVES_PER_BLOCK, stream, P);
     RT_LAUNCH(co_k_mcts_step, ((R) + CO_K3_WAVES - 1) / CO_K3_WAVES, CO_WAVE * CO_K3_WAVES, stream, P);
     ++iterations;
     ++mcts_launches;
@@ -1177,7 +1175,6 @@ struct ca_trainer {
         const int cap_rows = (q.running < q.n ? (q.running > 0 ? q.running : 1) : q.n) * spe;
         rt_event_t *e = q.ev[parity];
         if (timed) rt_event_record(e[0], q.st);
-        RT_LAUNCH(co_k_priors, ((q.n) * pp.searches_per_eval + CO_WAVES_PER_BLOCK - 1) / CO_WAVES_PER_BLOCK, CO_WAVE * CO_WAVES_PER_BLOCK, q.st, pp);
         RT_LAUNCH(co_k_mcts_step, ((q.n) + CO_K3_WAVES - 1) / CO_K3_WAVES, CO_WAVE * CO_K3_WAVES, q.st, pp);
         if (timed) rt_event_record(e[1], q.st);
         if (q.cache.hdr) {
@@ -1306,7 +1303,6 @@ struct ca_trainer {
       P.scan_phase = 0;
       RT_LAUNCH(co_k_scan, 1, CO_WAVE, stream, P); /* offsets at entry (trainer.cpp:208-215) */
       if (timed) rt_event_record(ev[0], stream);
-      RT_LAUNCH(co_k_priors, ((R) * P.searches_per_eval + CO_WAVES_PER_BLOCK - 1) / CO_WAVES_PER_BLOCK, CO_WAVE * CO_WAVES_PER_BLOCK, stream, P);
       RT_LAUNCH(co_k_mcts_step, ((R) + CO_K3_WAVES - 1) / CO_K3_WAVES, CO_WAVE * CO_K3_WAVES, stream, P);
       if (timed) rt_event_record(ev[1], stream);
       P.scan_phase = 1;
@@ -1500,7 +1496,6 @@ struct ca_tourney {
           nets[id]->forward(p.nn_in.p, p.G * p.spe, p.req_offset.p + p.G, p.nn_eval.p, p.nn_probs.p, p.stream);
           ++p.nn_launches;
         }
-        RT_LAUNCH(co_k_priors, ((p.G) * p.P.searches_per_eval + CO_WAVES_PER_BLOCK - 1) / CO_WAVES_PER_BLOCK, CO_WAVE * CO_WAVES_PER_BLOCK, p.stream, p.P);
         RT_LAUNCH(co_k_mcts_step, ((p.G) + CO_K3_WAVES - 1) / CO_K3_WAVES, CO_WAVE * CO_K3_WAVES, p.stream, p.P);
         ++p.mcts_launches;
         ++p.iterations;

@@ -29,30 +29,6 @@ CO_K3_BOUNDS CO_KERNEL co_k_mcts_step(EngineParams P) {
   if (i < P.pool_n && g < P.num_games) co_mcts_step_wave(P, g);
 }
 
-/* K2b: the priors of every pending leaf whose evaluation this launch consumes -- one wavefront per
- * (game, pending leaf), before the search kernel (mcts.h "receiveEval, split in two").
- * getFilteredProbs + generateDirichlet + setProbs, trainmc.cpp:212-267. */
-CO_KERNEL co_k_priors(EngineParams P) {
-  const int spe = P.searches_per_eval;
-  const int unit = CO_BLOCK_IDX * CO_WAVES_PER_BLOCK + CO_WAVE_IN_BLOCK; /* (game of the pool, pending leaf) */
-  const int g = P.pool_lo + unit / spe, k = unit % spe;
-  if (unit / spe >= P.pool_n || g >= P.num_games) return;
-  /* the three fetches the rest depends on are independent of each other: issued together */
-  GameCtl gc = P.games[g];
-  const uint32_t leaf = P.pend_leaf[(size_t)g * spe + k];
-  const uint4 pn = ((const uint4 *)P.pend_n)[(size_t)g * spe + k];
-  const int32_t src = P.cache.hdr ? P.pend_src[(size_t)g * spe + k] : 0;
-  if (co_step_gate(P, g, gc) != 1 || k >= gc.n_pending) return;
-  const size_t stride = (size_t)P.cap_units + CO_ARENA_PAD;
-  uint4 *A = P.arena + (size_t)(2 * g + gc.to_play) * stride; /* the mover's tree holds the pending leaves */
-  const int row = co_step_row(P, g, gc) + k;
-  const float eps = P.pcfg ? P.pcfg[2 * g + gc.to_play].epsilon : P.epsilon; /* match.h:13-31: per-side settings */
-  /* the network's priors of the leaf's row: in place, or where the evaluation cache resolved the row to */
-  const float *row_probs = P.cache.hdr ? P.cache.val + (size_t)src * CO_CACHE_VAL_FLOATS + 4 : P.nn_probs + (size_t)row * CO_NUM_MOVES;
-  co_prior_leaf(A, leaf, (int)(pn.x & 255u), pn.y, pn.z, pn.w, row_probs,
-                P.noise_raw + (size_t)g * spe * CO_NUM_MOVES + (pn.x >> 8), eps);
-}
-
 /* is game g part of the batch of model `tp` (trainer.cpp:42-46, 84-98)? */
 CO_DEV int co_game_active(const EngineParams &P, int g, const GameCtl &gc, int tp) {
   if (gc.done) return 0;

@@ -74,6 +74,7 @@ struct CoWave {
    * no register-resident state is indexed dynamically (that would spill to scratch) */
   CoTree me, opp;
   uint32_t *mt;
+  const uint32_t *gamma; /* LDS: gamma_samples (util.h), CO_NUM_GAMMA words */
   const uint32_t *lb; /* LDS: line_breakers (rules.h co_line_breakers_to_lds) */
   int mt_staged;      /* mt_stage holds the generator's current state */
   uint32_t *mt_stage; /* LDS, CO_MT_STAGE words: staging copy of the generator state for a twist (rng.h co_mt_twist_lds) */
@@ -318,123 +319,119 @@ CO_DEV uint32_t co_wave_mt_next(CoWave &w) {
   return co_mt_next(w.mt, &w.gc.rng_idx);
 }
 
-/* the id of the r-th legal move (r-th set bit of the 96-bit mask), r < number of set bits */
-CO_DEV uint32_t co_nth_set(uint32_t m0, uint32_t m1, uint32_t m2, uint32_t r) {
-  const uint32_t c0 = (uint32_t)co_popc32(m0), c1 = (uint32_t)co_popc32(m1);
-  uint32_t word = m0, base = 0u;
-  if (r >= c0 + c1) {
-    word = m2;
-    base = 64u;
-    r -= c0 + c1;
-  } else if (r >= c0) {
-    word = m1;
-    base = 32u;
-    r -= c0;
-  }
-  uint32_t pos = 0u;
+/* Part (1) for FOUR leaves at a time, one per row of the wavefront (round 5): the same arithmetic as co_prior_leaf --
+ * which the separate priors kernel of rounds 2-4 ran, one wavefront per leaf, as a launch of its own in front of every
+ * search launch: 19-50 us on each pool's chain, most of it waiting for CUs beside the network kernels.  In row form it is
+ * ~550 instructions per four leaves inside the game's own step.
+ *   A lane looks at move ids column + 16 q (q < 6): legal?  its rank among the legal moves = its edge; the network's prior
+ *   of the move (coalesced: 16 consecutive floats of the row), the generator output of the edge -> its gamma sample
+ *   (table in LDS).  Illegal moves carry +0.0: the two SEQUENTIAL float sums of the reference's loops over edges
+ *   (trainmc.cpp:219-229, 238-241) then run over all 96 move ids in order -- x + 0.0 == x -- as 96 v_add_f32 with a
+ *   row_newbcast source each (ROW_SEQ_SUM16), the two chains interleaved.  Weights, row maximum, 9-bit quantisation, the
+ *   integer sum and the denominator as in co_prior_leaf. */
+CO_DEV void co_prior_rows(CoWave &w, CoTree &t, int k0, int nk, const float *probs) {
+  uint4 *A = t.A;
+  LV(int, on);
+  LV(uint32_t, leaf);
+  LV(uint32_t, l0);
+  LV(uint32_t, l1);
+  LV(uint32_t, l2);
+  LV(float, pq[6]);
+  LV(float, gq[6]);
+  LV(int, rk[6]); /* the edge of move id column + 16 q, or -1 */
+  {
+    const uint32_t *pend_leaf = w.pend_leaf;
+    const uint4 *pend_n = (const uint4 *)w.pend_n;
+    const uint32_t *noise_raw = w.noise_raw;
+    const uint32_t *gam = w.gamma;
+    const float *cval = w.cval;
+    const int32_t *csrc = w.csrc;
+    FOR_LANES_HOT {
+      const int r = lane >> 4, c = lane & 15, k = k0 + r;
+      L(on) = r < nk;
+      const int kk = L(on) ? k : k0;
+      L(leaf) = pend_leaf[kk];
+      const uint4 pn = pend_n[kk];
+      L(l0) = pn.y;
+      L(l1) = pn.z;
+      L(l2) = pn.w;
+      const float *row = cval ? cval + (size_t)csrc[kk] * CO_CACHE_VAL_FLOATS + 4 : probs + (size_t)kk * CO_NUM_MOVES;
+      const uint32_t *raw = noise_raw + (pn.x >> 8);
+      const int c0 = co_popc32(pn.y), c01 = c0 + co_popc32(pn.z);
+      uint32_t rw[6];
 #pragma unroll
-  for (uint32_t s = 16u; s >= 1u; s >>= 1) {
-    const uint32_t cnt = (uint32_t)co_popc32((word >> pos) & ((1u << s) - 1u));
-    if (r >= cnt) {
-      r -= cnt;
-      pos += s;
+      for (int q = 0; q < 6; ++q) {
+        const int id = 16 * q + c, bit = id & 31;
+        const uint32_t wd = q < 2 ? pn.y : q < 4 ? pn.z : pn.w;
+        const int legal = L(on) && ((wd >> bit) & 1u);
+        const int rank = (q < 2 ? 0 : q < 4 ? c0 : c01) + co_popc32(wd & ((1u << bit) - 1u));
+        L(rk[q]) = legal ? rank : -1;
+        L(pq[q]) = row[id]; /* (all loads first: their latencies overlap) */
+        rw[q] = raw[legal ? rank : 0];
+      }
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        const int legal = L(rk[q]) >= 0;
+        const float g = co_u2f(gam[co_mt_temper(rw[q]) % CO_NUM_GAMMA]);
+        L(gq[q]) = legal ? g : 0.0f;
+        L(pq[q]) = legal ? L(pq[q]) : 0.0f;
+      }
     }
   }
-  return base + pos;
-}
-
-/* Part (1) for ONE leaf, one wavefront: lanes = edges (two per lane beyond 64).  A = the leaf's tree,
- * n / lm = the leaf's legal moves (count and mask, recorded when the leaf was queued, so that the
- * gathers below depend on nothing in the tree), probs = the network's 96 priors of the leaf's row,
- * raw = the leaf's generator outputs.  The two sums are sequential float additions in edge order, as
- * the reference's loops. */
-CO_DEV void co_prior_leaf(uint4 *A, uint32_t leaf, int n, uint32_t lm0, uint32_t lm1, uint32_t lm2, const float *probs,
-                          const uint32_t *raw, float epsilon) {
-  LV(uint32_t, z0);
-  LV(uint32_t, z1);
-  LV(float, fp0); /* filtered priors: edge `lane` and edge `lane + 64` */
-  LV(float, fp1);
-  LV(float, dn0); /* dirichlet */
-  LV(float, dn1);
-  FOR_LANES {
-    L(z0) = 0u;
-    L(z1) = 0u;
-    L(fp0) = L(fp1) = L(dn0) = L(dn1) = 0.0f;
-    /* unconditional loads (lanes beyond n read move 0 / word 0): every lane's fetches are in flight together */
-    const uint32_t m0 = lane < n ? co_nth_set(lm0, lm1, lm2, (uint32_t)lane) : 0u; /* edges are the legal moves in ascending id */
-    const uint32_t r0 = raw[lane < n ? lane : 0];
-    const float p0 = probs[m0];
-    const float g0 = co_u2f(CO_GAMMA_BITS[co_mt_temper(r0) % CO_NUM_GAMMA]);
-    if (lane < n) {
-      L(z0) = m0;
-      L(fp0) = p0;
-      L(dn0) = g0;
-    }
-    if (lane + CO_WAVE < n) {
-      L(z1) = co_nth_set(lm0, lm1, lm2, (uint32_t)(lane + CO_WAVE));
-      L(fp1) = probs[L(z1)];
-      L(dn1) = co_u2f(CO_GAMMA_BITS[co_mt_temper(raw[lane + CO_WAVE]) % CO_NUM_GAMMA]);
-    }
+  LV(float, sum);
+  LV(float, dsum);
+  FOR_LANES_HOT { L(sum) = L(dsum) = 0.0f; }
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    ROW_SEQ_SUM16(sum, pq[q]);
+    ROW_SEQ_SUM16(dsum, gq[q]);
   }
-  /* sequential float additions in edge order (trainmc.cpp:219-229, 238-241): lane broadcasts, no memory */
-  float sum = 0.0f, dsum = 0.0f;
-  const int n0 = n < CO_WAVE ? n : CO_WAVE;
-  for (int e = 0; e < n0; ++e) {
-    sum += WAVE_BCAST(fp0, e);
-    dsum += WAVE_BCAST(dn0, e);
-  }
-  for (int e = CO_WAVE; e < n; ++e) {
-    sum += WAVE_BCAST(fp1, e - CO_WAVE);
-    dsum += WAVE_BCAST(dn1, e - CO_WAVE);
-  }
-  float one_minus = (float)1 - epsilon;
-  float scalar = (float)(1.0 / (double)sum * (double)one_minus);
-  float dscalar = (float)(1.0 / (double)dsum * (double)epsilon);
-  LV(float, wt0);
-  LV(float, wt1);
+  LV(float, wt[6]);
   LV(float, mxl);
-  FOR_LANES {
-    float m = 0.0f;
-    L(wt0) = 0.0f;
-    L(wt1) = 0.0f;
-    if (lane < n) {
-      float a = L(fp0) * scalar;
-      float d = L(dn0) * dscalar;
-      L(wt0) = a + d;
-      m = L(wt0) > m ? L(wt0) : m;
+  const float eps = w.epsilon;
+  FOR_LANES_HOT {
+    const float one_minus = (float)1 - eps;
+    const float scalar = (float)(1.0 / (double)L(sum) * (double)one_minus);
+    const float dscalar = (float)(1.0 / (double)L(dsum) * (double)eps);
+    float mx = 0.0f; /* weights are >= 0, as the reference's max_prob start value */
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const float a = L(pq[q]) * scalar;
+      const float d = L(gq[q]) * dscalar;
+      const float x = a + d;
+      L(wt[q]) = x;
+      if (L(rk[q]) >= 0) mx = x > mx ? x : mx;
     }
-    if (lane + CO_WAVE < n) {
-      float a = L(fp1) * scalar;
-      float d = L(dn1) * dscalar;
-      L(wt1) = a + d;
-      m = L(wt1) > m ? L(wt1) : m;
-    }
-    L(mxl) = m;
+    L(mxl) = mx;
   }
-  float max_prob = WAVE_MAX_F32(mxl); /* weights are >= 0, as the reference's max_prob start value */
-  float denom = 511.0f / max_prob;
+  LV(float, mxr);
+  ROW_MAX_F32(mxr, mxl);
   LV(int, qs);
-  FOR_LANES {
+  FOR_LANES_HOT {
+    const float denom = 511.0f / L(mxr);
     int s = 0;
-    for (int h = 0; h < 2; ++h) {
-      int e = lane + h * CO_WAVE;
-      if (e < n) {
-        float x = (h ? L(wt1) : L(wt0)) * denom;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      if (L(rk[q]) >= 0) {
+        const float x = L(wt[q]) * denom;
         /* lround: half away from zero (x >= 0 here; NaN/neg handled like max(1, .)) */
-        float fl = __builtin_truncf(x);
-        int q = (int)fl;
-        if (x - fl >= 0.5f) q += 1;
-        if (!(q >= 1)) q = 1;
-        s += q;
-        A[leaf + 2 + e].z = (h ? L(z1) : L(z0)) | ((uint32_t)(q & 511) << 7);
+        const float fl = __builtin_truncf(x);
+        int qq = (int)fl;
+        if (x - fl >= 0.5f) qq += 1;
+        if (!(qq >= 1)) qq = 1;
+        s += qq;
+        A[L(leaf) + 2u + (uint32_t)L(rk[q])].z = (uint32_t)(16 * q + (lane & 15)) | ((uint32_t)(qq & 511) << 7);
       }
     }
     L(qs) = s;
   }
-  int final_sum = WAVE_SUM_I32(qs);
-  float denominator = (float)(1.0 / (double)(float)final_sum);
-  FOR_LANES {
-    if (lane == 0) A[leaf + 1].y = co_f2u(denominator);
+  LV(int, fs);
+  ROW_SUM_I32(fs, qs);
+  FOR_LANES_HOT {
+    if (L(on) && (lane & 15) == 0) {
+      const float denominator = (float)(1.0 / (double)(float)L(fs));
+      A[L(leaf) + 1u].y = co_f2u(denominator);
+    }
   }
 }
 
@@ -445,6 +442,7 @@ CO_DEV void co_prior_leaf(uint4 *A, uint32_t leaf, int n, uint32_t lm0, uint32_t
  * the value left by the latest earlier leaf of the batch that touched the same slot (register
  * forwarding) instead of re-reading memory. */
 #define CO_RB 8
+#define CO_SB_ROWS 4 /* rows of a wavefront */
 CO_DEV void co_backup_batch(CoWave &w, CoTree &t, int k0, int nb, const float *eval) {
   uint4 *A = t.A;
   LV(int, dv);
@@ -508,8 +506,11 @@ CO_DEV void co_backup_batch(CoWave &w, CoTree &t, int k0, int nb, const float *e
 
 /* trainmc.cpp:269-296, the game's share: the priors of the pending leaves are in the tree already
  * (co_k_priors ran on this launch's rows) */
-CO_DEV void co_receive_eval(CoWave &w, CoTree &t, const float *eval) {
+CO_DEV void co_receive_eval(CoWave &w, CoTree &t, const float *eval, const float *probs) {
   int n = w.gc.n_pending;
+  for (int k0 = 0; k0 < n; k0 += CO_SB_ROWS) co_prior_rows(w, t, k0, n - k0 < CO_SB_ROWS ? n - k0 : CO_SB_ROWS, probs);
+  WAVE_SYNC();
+  CO_PH_MEM(13);
   for (int k0 = 0; k0 < n; k0 += CO_RB) {
     int nb = n - k0 < CO_RB ? n - k0 : CO_RB;
     co_backup_batch(w, t, k0, nb, eval);
@@ -1511,7 +1512,7 @@ CO_DEV int co_mc_do_iteration(CoWave &w, CoTree &t, const float *eval, const flo
     co_request_root(w, t);
     return 0;
   }
-  if (w.gc.n_pending > 0) co_receive_eval(w, t, eval);
+  if (w.gc.n_pending > 0) co_receive_eval(w, t, eval, probs);
   WAVE_SHARED(uint4, root_ev, CO_WAVE);
   CoRoot rc;
   rc.valid = 0;
@@ -2414,6 +2415,15 @@ CO_DEV void co_mcts_step_wave(const EngineParams &P, int g) {
   WG_SHARED(uint32_t, lb, CO_LB_WORDS);
   co_line_breakers_to_lds(lb);
   w.lb = lb;
+  WG_SHARED(uint32_t, gam, CO_NUM_GAMMA);
+  { /* (the same way: every wavefront writes the same words before it reads any) */
+    FOR_LANES {
+#pragma unroll
+      for (int i = 0; i < CO_NUM_GAMMA / CO_WAVE; ++i) gam[i * CO_WAVE + lane] = CO_GAMMA_BITS[i * CO_WAVE + lane];
+    }
+    WAVE_SYNC();
+  }
+  w.gamma = gam;
 #if defined(CO_PROF) && !defined(CO_EMU)
   const unsigned long long t_wave0 = CO_CLK(), t_real0 = __builtin_amdgcn_s_memrealtime();
   for (int i = 0; i < CO_NPROF; ++i) w.pacc[i] = 0ull;

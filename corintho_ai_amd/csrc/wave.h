@@ -144,6 +144,26 @@ static inline void emu_row_shfl_u32(uint32_t *d, const uint32_t *s, const int *c
   for (int l = 0; l < CO_WAVE; ++l) t[l] = s[(l & ~(CO_ROW_LANES - 1)) + (col[l] & (CO_ROW_LANES - 1))];
   memcpy(d, t, sizeof t);
 }
+static inline void emu_row_sum_i32(int *d, const int *s) {
+  int t[CO_WAVE];
+  for (int r = 0; r < CO_WAVE; r += CO_ROW_LANES) {
+    int m = 0;
+    for (int i = 0; i < CO_ROW_LANES; ++i) m += s[r + i];
+    for (int i = 0; i < CO_ROW_LANES; ++i) t[r + i] = m;
+  }
+  memcpy(d, t, sizeof t);
+}
+/* acc += v of column 0, then of column 1, ... column 15 of the lane's row: sixteen SEQUENTIAL float additions (the
+ * reference's loops over edges add in edge order) */
+static inline void emu_row_seq_sum16(float *acc, const float *v) {
+  for (int r = 0; r < CO_WAVE; r += CO_ROW_LANES) {
+    float a = acc[r];
+    for (int i = 0; i < CO_ROW_LANES; ++i) a += v[r + i];
+    for (int i = 0; i < CO_ROW_LANES; ++i) acc[r + i] = a;
+  }
+}
+#define ROW_SUM_I32(d, s) emu_row_sum_i32(d, s)
+#define ROW_SEQ_SUM16(acc, v) emu_row_seq_sum16(acc, v)
 #define ROW_MAX_F32(d, s) emu_row_max_f32(d, s)
 #define ROW_MIN_U32(d, s) emu_row_min_u32(d, s)
 #define ROW_BALLOT(d, p) emu_row_ballot(d, p)           /* d = the 16 predicate bits of the lane's row */
@@ -374,6 +394,39 @@ __device__ __forceinline__ uint32_t co_row_ballot(int p) {
 __device__ __forceinline__ uint32_t co_row_shfl_u32(uint32_t v, int col) {
   return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((threadIdx.x & 48u) | ((unsigned)col & 15u)) << 2), (int)v);
 }
+__device__ __forceinline__ int co_row_sum_i32(int v) {
+  v += CO_DPP_I(v, CO_DPP_XOR1);
+  v += CO_DPP_I(v, CO_DPP_XOR2);
+  v += CO_DPP_I(v, CO_DPP_HALF_MIRROR);
+  v += CO_DPP_I(v, CO_DPP_MIRROR);
+  return v;
+}
+/* sixteen v_add_f32 with a DPP source (row_newbcast:c = column c of the lane's own row), one after the other */
+template <int C>
+__device__ __forceinline__ float co_row_col(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + C, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float co_row_seq_sum16(float a, float v) {
+  a += co_row_col<0>(v);
+  a += co_row_col<1>(v);
+  a += co_row_col<2>(v);
+  a += co_row_col<3>(v);
+  a += co_row_col<4>(v);
+  a += co_row_col<5>(v);
+  a += co_row_col<6>(v);
+  a += co_row_col<7>(v);
+  a += co_row_col<8>(v);
+  a += co_row_col<9>(v);
+  a += co_row_col<10>(v);
+  a += co_row_col<11>(v);
+  a += co_row_col<12>(v);
+  a += co_row_col<13>(v);
+  a += co_row_col<14>(v);
+  a += co_row_col<15>(v);
+  return a;
+}
+#define ROW_SUM_I32(d, s) ((d) = co_row_sum_i32(s))
+#define ROW_SEQ_SUM16(acc, v) ((acc) = co_row_seq_sum16((acc), (v)))
 #define ROW_MAX_F32(d, s) ((d) = co_row_max_f32(s))
 #define ROW_MIN_U32(d, s) ((d) = co_row_min_u32(s))
 #define ROW_BALLOT(d, p) ((d) = co_row_ballot(p))

@@ -83,6 +83,24 @@ if sq:
         for c in sorted(d):
             lines.append("| `%s` | %s | %.0f |" % (k, c, d[c][0]))
         pmc["kernels"].setdefault(k, {})["sq"] = {c: d[c][0] for c in d}
+    # the ratios DESIGN.md quotes, so that they follow from this file alone: of a kernel's wave cycles, the
+    # share spent at s_waitcnt, the share with a vector instruction issuing, and the matrix pipe's busy share.
+    # SQ_VALU_MFMA_BUSY_CYCLES counts per SIMD cycles with the pipe busy; SQ_BUSY_CYCLES per SE x4 -> the same normalisation
+    # as the microarchitecture guide's: MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES x CUs-per-SE share); given the
+    # guide's caveat about that counter on gfx950 the per-wave form is printed as well (busy cycles / wave cycles x waves per SIMD).
+    lines += ["", "Derived (same pass): share of the wave cycles waiting (SQ_WAIT_ANY), issuing any instruction (SQ_ACTIVE_INST_ANY), "
+              "issuing vector instructions (SQ_ACTIVE_INST_VALU); matrix-pipe cycles per wave cycle (SQ_VALU_MFMA_BUSY_CYCLES / SQ_WAVE_CYCLES: x waves "
+              "per SIMD = the pipe's busy share while the kernel's waves are resident):", "",
+              "| kernel | wait % | any instruction % | VALU % | MFMA busy cycles / wave cycles |", "|---|---:|---:|---:|---:|"]
+    for k, d in counters(sq).items():
+        if not k.startswith("co_k_") or k in ("co_k_scan", "co_k_compact") or "SQ_WAVE_CYCLES" not in d:
+            continue
+        wc = max(d["SQ_WAVE_CYCLES"][0], 1.0)
+        g = lambda c: d[c][0] if c in d else float("nan")  # noqa: E731
+        lines.append("| `%s` | %.1f | %.1f | %.1f | %.3f |" % (k, 100 * g("SQ_WAIT_ANY") / wc, 100 * g("SQ_ACTIVE_INST_ANY") / wc,
+                                                              100 * g("SQ_ACTIVE_INST_VALU") / wc, g("SQ_VALU_MFMA_BUSY_CYCLES") / wc))
+        pmc["kernels"][k]["derived"] = {"wait_share": g("SQ_WAIT_ANY") / wc, "any_inst_share": g("SQ_ACTIVE_INST_ANY") / wc,
+                                        "valu_share": g("SQ_ACTIVE_INST_VALU") / wc, "mfma_busy_per_wave_cycle": g("SQ_VALU_MFMA_BUSY_CYCLES") / wc}
 os.makedirs(DST, exist_ok=True)
 with open(os.path.join(DST, "%s_kernel_stats.md" % tag), "w") as fh:
     fh.write("\n".join(lines) + "\n")
