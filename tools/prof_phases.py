@@ -40,7 +40,7 @@ print("histogram of wave-step cycles (50k buckets):", v[NP + 4:NP + 20])
 names = {22: "wave set-up", 0: "backup: indices", 1: "backup: slot fetch", 3: "backup: sums + stores", 20: "loop control + root load",
          19: "simulation start (root copy, path)", 8: "PUCT scan", 9: "virtual-loss store + path", 11: "descent: block fetch (waited for)",
          16: "expansion: doMove", 14: "expansion: legal moves", 15: "expansion: node stores", 10: "expansion: slot + path update",
-         28: "grouped search: root scans", 25: "tail: stores of the step waited for", 26: "tail: batch-row atomic", 27: "tail: noise capture (copy)", 30: "tail: noise capture (before a twist)", 31: "tail: twist", 29: "tail: request rows read back",
+         28: "grouped search: root scans", 13: "priors of the pending leaves (rows)", 25: "tail: stores of the step waited for", 26: "tail: batch-row atomic", 27: "tail: noise capture (copy)", 30: "tail: noise capture (before a twist)", 31: "tail: twist", 29: "tail: request rows read back",
          12: "terminal leaf", 17: "request: state row", 18: "request: pending-leaf records", 2: "move choice / hand-over", 21: "step tail"}
 tot = sum(v[i] for i in names)
 print("stamped %.0f cycles per wave-step (%.1f %% of the whole step); per SIMULATION:" % (tot / steps, 100.0 * tot / max(v[7], 1)))
