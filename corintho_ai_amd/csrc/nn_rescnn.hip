@@ -387,7 +387,9 @@ __global__ __launch_bounds__(256, CO_RC_F32_BLOCKS) void co_k_rescnn_forward(RcP
  * runs hundreds of such iterations, each as long as its slowest kernel).  NT = 3: 1 (three packed
  * operand sets + three weight fragment sets leave no registers for a second pair at two waves per
  * SIMD; the MFMA work per weight byte is that of NT = 2, NP = 2 again). */
+#ifndef RC3_SMALL_ROWS
 #define RC3_SMALL_ROWS 4096 /* NT = 2: batches up to this size take the small-batch kernel: <= 256 workgroups */
+#endif
 #define RC6_THIN_ROWS 2048  /* NT = 3: batches up to this size take the four-wave kernel: <= 256 workgroups of 8 positions */
 #define RCS_STEM_CHUNK(NT) (512 * (NT))  /* u32: 1 k-step x 2 out tiles x NT terms x 64 lanes x 4 */
 #define RCS_CONV_CHUNK(NT) (2048 * (NT)) /* u32: 4 k-steps ... = 8 KB per term */
