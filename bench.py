@@ -185,12 +185,12 @@ def launch_ranks(args):
 
 def measured_traffic(kernel, args, net, npools):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
-    (profiles/r03_<net>_pmc.json, else round 2's; PMC counters cannot be collected from inside an un-profiled run).
+    (profiles/r05_<net>_pmc.json, else an earlier round's; PMC counters cannot be collected from inside an un-profiled run).
     Only valid for the workload those passes were taken on (the default one); otherwise null."""
     if (args.games, args.sims, args.spe) != (4096, 400, 16):
         return None
     try:
-        for rnd in ("r04", "r03", "r02"):
+        for rnd in ("r05", "r04", "r03", "r02"):
             path = os.path.join(ROOT, "profiles", "%s_%s_pmc.json" % (rnd, net))
             if os.path.exists(path):
                 break
@@ -489,7 +489,7 @@ def main():
         sims_per_launch = totals["searches"] / max(totals["mcts_launches"], 1)
         s_launch_ms = (totals["mcts_timed_ms"] / tl) if tl else totals["mcts_ms"] / max(totals["mcts_launches"], 1)
         achieved_s = sims_per_launch * BYTES_PER_SIM / max(s_launch_ms * 1e-3, 1e-12) / 1e9
-        rs = {"kernel": "co_k_mcts_step (+ co_k_priors)", "bound": "hbm", "achieved": achieved_s, "peak": HBM_PEAK_GBS,
+        rs = {"kernel": "co_k_mcts_step", "bound": "hbm", "achieved": achieved_s, "peak": HBM_PEAK_GBS,
               "unit": "GB/s", "frac": achieved_s / HBM_PEAK_GBS,
               "traffic": measured_traffic("co_k_mcts_step", args, net, npools),
               "algorithmic": "%.0f B/simulation x %.0f simulations per launch (%d simulations in %d launches)"
