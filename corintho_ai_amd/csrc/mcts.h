@@ -378,11 +378,21 @@ CO_DEV void co_prior_rows(CoWave &w, CoTree &t, int k0, int nk, const float *pro
       }
     }
   }
+  /* a block of sixteen move ids none of the four leaves has a legal move in (the stack moves of an early position: three
+   * of the six blocks) adds sixteen zeros: skipped, here and below */
+  int live[6];
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    LV(int, lq);
+    FOR_LANES_HOT { L(lq) = L(rk[q]) >= 0; }
+    live[q] = WAVE_BALLOT(lq) != 0ull;
+  }
   LV(float, sum);
   LV(float, dsum);
   FOR_LANES_HOT { L(sum) = L(dsum) = 0.0f; }
 #pragma unroll
   for (int q = 0; q < 6; ++q) {
+    if (!live[q]) continue;
     ROW_SEQ_SUM16(sum, pq[q]);
     ROW_SEQ_SUM16(dsum, gq[q]);
   }
