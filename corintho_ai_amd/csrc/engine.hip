@@ -945,7 +945,10 @@ struct ca_trainer {
   }
 
   /* nn.h range_exceeded: an f16x3 network met an operand beyond fp16's range -- its outputs since are NaN or wrong */
+  bool net_used = false; /* a network launch has been queued since the range flags were last read */
   void check_net_range() {
+    if (!net_used) return; /* (no copy and stream wait per slot when nothing ran) */
+    net_used = false;
     for (int slot = 0; slot < 2; ++slot)
       if (nets[slot] && nets[slot]->range_exceeded(stream))
         throw EngineError(CA_ERR_ENGINE, std::string("network slot ") + std::to_string(slot) +
@@ -969,6 +972,7 @@ struct ca_trainer {
     rt_h2d(fw_rows.p, &n, 4, stream);
     const int nb = n * CO_STATE_STRIDE / CO_WAVE + 1 < 1024 ? n * CO_STATE_STRIDE / CO_WAVE + 1 : 1024;
     RT_LAUNCH(co_k_expand_rows, nb, CO_WAVE, stream, (const float *)fw_in70.p, fw_in.p, (int)n, nb);
+    net_used = true;
     net->forward(fw_in.p, n, fw_rows.p, fw_ev.p, fw_pr.p, stream);
     rt_d2h(evals, fw_ev.p, (size_t)n * 4, stream);
     rt_d2h(probs, fw_pr.p, (size_t)n * CO_NUM_MOVES * 4, stream);
@@ -978,6 +982,7 @@ struct ca_trainer {
 
   void net_forward_rows(int slot, const float *d_in, int32_t rows_cap, const int32_t *d_rows, float *d_eval,
                         float *d_probs) {
+    net_used = true;
     nets[slot]->forward(d_in, rows_cap, d_rows, d_eval, d_probs, stream);
   }
 
@@ -1188,6 +1193,7 @@ struct ca_trainer {
           io.eval_stride = CO_CACHE_VAL_FLOATS;
           io.probs_stride = CO_CACHE_VAL_FLOATS;
           io.alone = npools == 1;
+          net_used = true;
           nets[0]->forward(req.p, cap_rows, (const int32_t *)(q.c_count + 4 * (trainer_iteration & 1)), q.c_val, q.c_val + 4, q.st, io);
           if (timed) rt_event_record(e[3], q.st);
         } else {
@@ -1196,6 +1202,7 @@ struct ca_trainer {
           CoNetIO io;
           io.alone = npools == 1;
           io.in_idx = row_idx.p + q.row_base; /* the rows stay where the games wrote them (co_step_tail) */
+          net_used = true;
           nets[0]->forward(req.p, cap_rows, d_rows, nn_eval.p + q.row_base, nn_probs.p + (size_t)q.row_base * CO_NUM_MOVES, q.st, io);
           if (timed) rt_event_record(e[3], q.st);
         }
@@ -1309,6 +1316,7 @@ struct ca_trainer {
       RT_LAUNCH(co_k_scan, 1, CO_WAVE, stream, P);
       RT_LAUNCH(co_k_compact, R, CO_WAVE, stream, P);
       if (timed) rt_event_record(ev[2], stream);
+      net_used = true;
       for (int slot = 0; slot < 2; ++slot) /* get_predictions, main.pyx:74-81 */
         nets[slot]->forward(nn_in.p, R * spe, arena_state.p + 3 + slot, nn_eval.p, nn_probs.p, stream);
       if (timed) rt_event_record(ev[3], stream);
@@ -1750,6 +1758,7 @@ extern "C" int ca_trainer_net_bench(ca_trainer *t, int slot, const float *states
     d_n.alloc(1, t->stream);
     rt_h2d(t->nn_in.p, pad.data(), pad.size() * 4, t->stream);
     rt_h2d(d_n.p, &rows, 4, t->stream);
+    t->net_used = true;
     t->nets[slot]->forward(t->nn_in.p, rows, d_n.p, t->nn_eval.p, t->nn_probs.p, t->stream); /* warm */
     rt_event_t e0, e1;
     rt_event_create(&e0);

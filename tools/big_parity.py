@@ -2,7 +2,8 @@
 """One-off parity run at the bench's full size: a fused generation on the GPU, then EVERY game
 replayed on the CPU oracle (fed by the same device network through ca_trainer_net_forward) and
 compared bit for bit: sample tensors (state, policy, outcome), score, mate length.
-usage: big_parity.py [games] [sims] [net: mlp12x100|mlp12x100x3|mlp12x100x6|mlp12x100h3|rescnn4|rescnn4x3|rescnn4x6|rescnn4h3] [seed] [resident slots]"""
+usage: big_parity.py [games] [sims] [net: mlp12x100|mlp12x100x3|mlp12x100x6|mlp12x100h3|rescnn4|rescnn4x3|rescnn4x6|rescnn4h3] [seed] [resident slots] [trained]
+(trained: the mlp12x100 kinds with the reference's last checkpoint, tests/golden/trained_last.npz -- narrow, deep trees)"""
 import os
 import sys
 import time
@@ -26,6 +27,9 @@ KINDS = {"mlp12x100": "NET_MLP12X100", "mlp12x100x3": "NET_MLP12X100_X3", "mlp12
          "mlp12x100h3": "NET_MLP12X100_H3"}
 kind = getattr(CA, KINDS[net])
 w = nets.init_mlp12x100(0) if net.startswith("mlp12x100") else nets.init_rescnn4(0)
+trained = len(sys.argv) > 6 and sys.argv[6] == "trained"
+if trained:
+    w = np.load(os.path.join(ROOT, "tests", "golden", "trained_last.npz"))["weights"]
 spe = 16
 t = Trainer(G, "", seed, S, spe, 1.0, 0.25, 0, 1, False, stagger=False, resident=resident)
 t.set_net(kind, w)
@@ -51,8 +55,8 @@ n = t.num_samples()
 ok = (ogs.shape[0] == n * 8 and ogs[0::8].tobytes() == sp[:, :70].tobytes() and opr[0::8].tobytes() == sp[:, 70:].tobytes()
       and oev[0::8].tobytes() == oc.tobytes() and o.score() == t.score() and o.avg_mate_length() == t.avg_mate_length())
 st = t.stats()
-print("%d games x %d sims/move on %d slots, %s, seed %d: GPU generation %.2f s (%d of %d request rows evaluated); oracle replay of all "
-      "games %.1f s (%d host iterations)" % (G, S, st["resident_slots"], net, seed, t_gpu, st["nn_rows_evaluated"], st["nn_rows"], t_cpu,
+print("%d games x %d sims/move on %d slots, %s%s, seed %d: GPU generation %.2f s (%d of %d request rows evaluated); oracle replay of all "
+      "games %.1f s (%d host iterations)" % (G, S, st["resident_slots"], net, " (the reference's last checkpoint)" if trained else "", seed, t_gpu, st["nn_rows_evaluated"], st["nn_rows"], t_cpu,
                                              r["iterations"]))
 print("plies %d, simulations %d, leaf evaluations %d, samples %d, score %.6f" % (st["plies"], st["searches"], st["evals"], n, t.score()))
 print("BIT-EXACT: every (state[70], policy[96], outcome) row, score and mate length agree" if ok else "MISMATCH")
