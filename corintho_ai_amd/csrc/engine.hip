@@ -1062,8 +1062,10 @@ struct ca_trainer {
           rt_memset(q.c_hdr, 0, q.c_entries * 16, q.st);
           rt_memset(q.c_done, 0, 4 * CO_MAX_POOLS, q.st); /* (the iteration count starts again with the generation) */
         }
-        rt_memset(q.c_count, 0, 32, q.st);
-        rt_memset(q.c_totals, 0, 16, q.st);
+        if (iterations == 0) { /* (in mid-generation -- a new network, set_net -- the rows evaluated so far stay counted: ADVICE round 4) */
+          rt_memset(q.c_count, 0, 32, q.st);
+          rt_memset(q.c_totals, 0, 16, q.st);
+        }
         rt_sync(q.st);
       }
       cache_clean = true;

@@ -84,8 +84,8 @@ struct GameCtl {
   /* the game this slot plays (index within this trainer's games; = the slot index unless the pool recycles
    * slots, see EngineParams::results) */
   int32_t gid;
-  /* the search's hint to itself: simulations it selects together in this position (mcts.h co_search_rows; 0 = CO_SB).
-   * Positions whose simulations keep ending in terminal leaves get smaller groups; results do not depend on it. */
+  /* the search's hint to itself (mcts.h co_mc_do_iteration): running share, in 1/256, of this game's recent simulations that
+   * ended in a terminal leaf or a dead end; decides how many simulations are selected together.  Results do not depend on it. */
   int32_t sb_cap;
 };
 

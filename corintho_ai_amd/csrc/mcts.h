@@ -858,6 +858,12 @@ CO_COLD2 void co_search(CoWave &w, CoTree &t, CoRoot &rc) {
  * leaf, a node wider than the wavefront, a path beyond CO_SB_DEPTH, a full arena) ends the group in front of it: the
  * simulations before it are committed, it is run by co_search on the committed tree, the ones behind it are selected
  * again in the next group (their selection is discarded -- nothing was written). */
+#ifndef CO_SB_PE_ONE
+#define CO_SB_PE_ONE 96
+#endif
+#ifndef CO_SB_PE_TWO
+#define CO_SB_PE_TWO 40
+#endif
 #define CO_SB_DEPTH 12 /* levels a grouped simulation may pass (a level = a lane of its row when it commits: at most 16) */
 #if CO_SB != 1 && CO_SB != 4
 #error "CO_SB: 1 (one simulation after another) or 4 (one per row of the wavefront)"
@@ -866,7 +872,8 @@ CO_COLD2 void co_search(CoWave &w, CoTree &t, CoRoot &rc) {
 #if defined(CO_SB_STATS) && defined(CO_EMU)
 /* emulation-build counters of the grouped search (tools/sb_stats.py): 0 groups, 1 simulations asked for, 2 committed,
  * 3 nothing searchable, 4 terminal child, 5 wide node, 6 too deep, 7 terminal leaf / full arena, 8 sequential simulations,
- * 9 levels of the groups, 10 scans, 11 patches applied (same node, same level), 12 + k: groups that committed k */
+ * 9 levels of the groups, 10 scans, 11 patches applied (same node, same level), 12 + k: groups that committed k,
+ * 20 shared levels below the root, 21 / 22 levels scanned wave-wide for one / two rows, 23 levels in row form, 24 turns taken there */
 extern unsigned long long co_sb_stats[32];
 extern unsigned long long co_sb_ply[8][8]; /* by game progress (plies / 4): groups, asked, committed, terminal leaves, nothing searchable, levels, sequential, - */
 #define CO_SBS(i, v) __atomic_fetch_add(&co_sb_stats[i], (unsigned long long)(v), __ATOMIC_RELAXED)
@@ -895,6 +902,11 @@ CO_DEV int co_search_rows(CoWave &w, CoTree &t, CoRoot &rc, int m) {
   WAVE_SHARED(uint4, sb_cs, CO_SB * CO_SB_DEPTH);             /* [sim][level] that slot after the pass */
   WAVE_SHARED(uint4, sb_hand, CO_SB * 2);                     /* root -> row j: {child block, child slot, z of the chosen slot, -}, the chosen slot */
   WAVE_SHARED(uint4, sb_leaf, CO_SB * 2);                     /* row j's leaf: {its parent's board lo, hi, meta, block}, {the chosen slot's move | prior, the leaf's slot, -, -} */
+  WAVE_SHARED(int, sb_kn, CO_SB);                             /* sim j found nothing searchable below the node of this level (else -1) */
+  FOR_LANES_HOT {
+    if (lane < CO_SB) sb_kn[lane] = -1;
+  }
+  WAVE_SYNC();
   int bad = m; /* the first simulation that is not ordinary */
   /* ---- the root, simulation after simulation; and on down for as long as ALL of them take the same child (a forced
    * line, a trained network's favourite: rows that share a node would take turns anyway -- one wave-wide scan per
@@ -960,6 +972,15 @@ CO_DEV int co_search_rows(CoWave &w, CoTree &t, CoRoot &rc, int m) {
         if (!(mx > CO_NEG_INF)) {
           CO_SBS(3, 1);
           bad = j;
+          const uint32_t xo = shown;
+          const int lv = lev0;
+          FOR_LANES_HOT {
+            if (lane == 0) { /* (for the tail below: this node's slot and its value after the pass) */
+              sb_slot[j * (CO_SB_DEPTH + 1) + lv] = xo;
+              sb_cs[j * CO_SB_DEPTH + lv] = rcs;
+              sb_kn[j] = lv;
+            }
+          }
           break;
         }
         LV(int, hit);
@@ -1006,6 +1027,7 @@ CO_DEV int co_search_rows(CoWave &w, CoTree &t, CoRoot &rc, int m) {
       const int left = bad < m ? bad : m;
       if (left < 2 || same_slot == 0u || same_slot == CO_NONE || lev0 + 3 >= CO_SB_DEPTH) break;
       /* every simulation left went to the same visited child: that node is shared as well */
+      CO_SBS(20, 1);
       shX = first_bs.x;
       shown = same_slot;
       rcs = first_bs;
@@ -1061,6 +1083,135 @@ CO_DEV int co_search_rows(CoWave &w, CoTree &t, CoRoot &rc, int m) {
       if (fr < bad) bad = fr;
       break;
     }
+    {
+      /* One or two rows left descending (the deep, narrow trees of a trained network: most levels): the row form costs
+       * ~300 instructions a level however few rows are busy, a wave-wide scan ~110 -- so these rows are scanned wave-wide,
+       * one after the other, their blocks fetched together.  (With the reference's last checkpoint the grouped search was
+       * 8 % SLOWER than round 4's sequential one before this path existed) */
+      const uint64_t am = WAVE_BALLOT(act);
+      const int a0 = (int)(am & 1ull), a1 = (int)((am >> 16) & 1ull), a2 = (int)((am >> 32) & 1ull), a3 = (int)((am >> 48) & 1ull);
+      if (a0 + a1 + a2 + a3 <= 2) {
+        CO_SBS(20 + (a0 + a1 + a2 + a3), 1);
+        const int r0 = a0 ? 0 : a1 ? 1 : a2 ? 2 : 3;
+        const int r1 = a0 + a1 + a2 + a3 < 2 ? -1 : (a3 ? 3 : a2 ? 2 : 1); /* (the last active row: with two, the other one) */
+        uint32_t wx[2], ws[2];
+        uint4 wc[2], wh[2];
+        uint32_t wd[2];
+        LV(uint4, we[2]);
+        int wr[2] = {r0, r1};
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int r = wr[i] < 0 ? r0 : wr[i];
+          wx[i] = WAVE_BCAST(X, 16 * r);
+          ws[i] = WAVE_BCAST(slot, 16 * r);
+          wc[i] = WAVE_BCAST(cs, 16 * r);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          wh[i] = co_load_unit(A, wx[i]);
+          wd[i] = co_load_unit(A, wx[i] + 1u).y;
+          const uint32_t e0 = wx[i] + 2u;
+          FOR_LANES_HOT { L(we[i]) = A[e0 + lane]; }
+        }
+        CO_PH_MEM(11);
+        uint32_t pX = CO_NONE;
+        int pe = -1;
+        uint4 pv = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int r = wr[i];
+          if (r < 0 || r >= bad) continue;
+          CO_SBS(10, 1);
+          CO_PROF_ADD(w, 23, 1ull);
+          const int n = (int)CO_META_NEDGES(wh[i].z);
+          int gone = 0; /* the row's simulation is not ordinary */
+          int le = 0;
+          uint4 bs = make_uint4(0u, 0u, 0u, 0u);
+          if (n > CO_WAVE) {
+            CO_SBS(5, 1);
+            gone = 1;
+          } else {
+            const float denom = co_u2f(wd[i]);
+            const float v_sqrt = co_vsqrt(w.c_puct, co_slot_visits(wc[i]));
+            LV(float, u);
+            FOR_LANES_HOT {
+              uint4 sl = L(we[i]);
+              if (pe >= 0 && pX == wx[i] && lane == pe) { /* the row before scanned this very node */
+                sl = pv;
+                CO_SBS(11, 1);
+              }
+              L(we[i]) = sl;
+              const float uu = co_puct_u(sl, denom, v_sqrt);
+              L(u) = lane < n ? uu : CO_NEG_INF;
+            }
+            const float mx = WAVE_MAX_F32(u);
+            wc[i] = co_slot_pass(wc[i]);
+            if (!(mx > CO_NEG_INF)) {
+              CO_SBS(3, 1);
+              gone = 1;
+              const uint32_t xs = ws[i];
+              const uint4 xc = wc[i];
+              FOR_LANES_HOT {
+                if (lane == 0) {
+                  sb_slot[r * (CO_SB_DEPTH + 1) + lev] = xs;
+                  sb_cs[r * CO_SB_DEPTH + lev] = xc;
+                  sb_kn[r] = lev;
+                }
+              }
+            } else {
+              LV(int, hit);
+              FOR_LANES_HOT { L(hit) = (L(u) == mx); }
+              le = co_ffs64(WAVE_BALLOT(hit)) - 1;
+              bs = WAVE_BCAST(we[i], le);
+              if (bs.x != CO_NONE && co_res_terminal(co_slot_result(bs))) {
+                CO_SBS(4, 1);
+                gone = 1;
+              }
+            }
+          }
+          if (gone) {
+            if (r < bad) bad = r;
+            FOR_LANES_HOT {
+              if ((lane >> 4) >= r) L(act) = 0;
+            }
+            continue;
+          }
+          const uint32_t child_slot = wx[i] + 2u + (uint32_t)le;
+          const int isnew = bs.x == CO_NONE;
+          pX = wx[i];
+          pe = le;
+          pv = isnew ? make_uint4(0u, co_f2u(1.0f), (bs.z & 0xFFFFu) | (1u << 16), 0x100u) : co_slot_pass(bs);
+          const uint32_t xb = wx[i], xs = ws[i];
+          const uint4 xc = wc[i], xh = wh[i];
+          FOR_LANES_HOT {
+            if (lane == 0) {
+              sb_block[r * CO_SB_DEPTH + lev] = xb;
+              sb_slot[r * (CO_SB_DEPTH + 1) + lev] = xs;
+              sb_slot[r * (CO_SB_DEPTH + 1) + lev + 1] = child_slot;
+              sb_cs[r * CO_SB_DEPTH + lev] = xc;
+              if (isnew) {
+                sb_leaf[2 * r] = make_uint4(xh.x, xh.y, xh.z, xb);
+                sb_leaf[2 * r + 1] = make_uint4(bs.z & 0xFFFFu, child_slot, 0u, 0u);
+              }
+            }
+            if ((lane >> 4) == r) {
+              if (isnew) {
+                L(leafD) = lev + 1;
+                L(act) = 0;
+              } else {
+                L(X) = bs.x;
+                L(slot) = child_slot;
+                L(cs) = bs;
+              }
+            }
+          }
+        }
+        WAVE_SYNC();
+        CO_PH(8);
+        continue;
+      }
+    }
+    CO_SBS(23, 1);
     /* the nodes of this level: header and up to 64 edge slots, four per lane */
     LV(uint4, h0);
     LV(uint32_t, dnb);
@@ -1105,6 +1256,7 @@ CO_DEV int co_search_rows(CoWave &w, CoTree &t, CoRoot &rc, int m) {
       }
       const uint64_t tm = WAVE_BALLOT(todo);
       if (!tm) break;
+      CO_SBS(24, 1);
       /* a row waits while an earlier row of the same node has yet to scan it */
       const uint32_t x0 = WAVE_BCAST(X, 0), x1 = WAVE_BCAST(X, 16), x2 = WAVE_BCAST(X, 32);
       const int t0 = (int)(tm & 1ull), t1 = (int)((tm >> 16) & 1ull), t2 = (int)((tm >> 32) & 1ull);
@@ -1204,6 +1356,11 @@ CO_DEV int co_search_rows(CoWave &w, CoTree &t, CoRoot &rc, int m) {
           } else {
             if (none) CO_SBS(3, (lane & 15) == 0);
             else CO_SBS(4, (lane & 15) == 0);
+            if (none && (lane & 15) == 0) {
+              sb_slot[r * (CO_SB_DEPTH + 1) + lev] = L(slot);
+              sb_cs[r * CO_SB_DEPTH + lev] = L(cs);
+              sb_kn[r] = lev;
+            }
             L(act) = 0;
           }
           L(todo) = 0;
@@ -1468,6 +1625,30 @@ CO_DEV int co_search_rows(CoWave &w, CoTree &t, CoRoot &rc, int m) {
     rc.valid = 0;
     CO_PH(12);
   }
+  int dead_end = 0;
+  if (term < 0 && done < m && done == bad) {
+    WAVE_SYNC();
+    const int D = sb_kn[bad];
+    if (D >= 0) {
+      /* ---- simulation `bad` found nothing searchable below the node at level D (kNone, trainmc.cpp:625-640), on the tree
+       * the simulations before it have been committed to: the node becomes all_visited, the passes along the path are
+       * taken back (+1 visit, +1.0 and then -1 visit, -1.0: two float operations, as the reference does them), the search
+       * is not counted.  The root copy is dropped. */
+      const int j = bad;
+      FOR_LANES_HOT {
+        if (lane <= D) {
+          uint4 v = sb_cs[j * CO_SB_DEPTH + lane];
+          if (lane == D) v = co_slot_set_all_visited(v, 1);
+          v = co_slot_set_visits(v, co_slot_visits(v) - 1);
+          v.y = co_f2u(co_u2f(v.y) - 1.0f);
+          A[sb_slot[j * (CO_SB_DEPTH + 1) + lane]] = v;
+        }
+      }
+      WAVE_SYNC();
+      rc.valid = 0;
+      dead_end = 1;
+    }
+  }
   CO_SBS(0, 1);
   CO_SBS(1, m);
   CO_SBS(2, done);
@@ -1475,12 +1656,12 @@ CO_DEV int co_search_rows(CoWave &w, CoTree &t, CoRoot &rc, int m) {
   CO_SBP(w, 1, m);
   CO_SBP(w, 2, done);
   CO_SBP(w, 3, term >= 0);
-  CO_SBP(w, 4, term < 0 && done < m);
+  CO_SBP(w, 4, term < 0 && !dead_end && done < m);
   CO_SBS(12 + done, 1);
   CO_PROF_ADD(w, 5, (unsigned long long)done);
   /* simulations committed | 0x100: a terminal leaf behind them ended the group (done here) | 0x200: the group stopped at a
    * simulation that is neither ordinary nor a terminal leaf -- the caller's next simulation takes co_search */
-  return done | (term >= 0 ? 0x100 : 0) | (term < 0 && done < m ? 0x200 : 0);
+  return done | (term >= 0 || dead_end ? 0x100 : 0) | (term < 0 && !dead_end && done < m ? 0x200 : 0);
 }
 #endif
 
@@ -1530,7 +1711,11 @@ CO_DEV int co_mc_do_iteration(CoWave &w, CoTree &t, const float *eval, const flo
   rc.e0 = 0u;
   rc.ne = 0u;
 #if CO_SB > 1
-  int cap = w.gc.sb_cap > 0 && w.gc.sb_cap < CO_SB ? w.gc.sb_cap : CO_SB;
+  /* How many to select together follows from how the position's simulations have been ending: everything behind one that
+   * is not ordinary is selected in vain (endgames of a trained network: every second simulation a terminal leaf or a
+   * dead end, ten levels down).  pe = running share of such simulations in 1/256 (seven eighths of the old estimate per
+   * simulation, kept with the game from step to step): above 3/8 they run one after the other, above 5/32 two at a time. */
+  int pe = w.gc.sb_cap > 0 && w.gc.sb_cap <= 256 ? w.gc.sb_cap : 0;
 #endif
   for (;;) {
     if (!(w.gc.n_pending < w.spe && t.tc.searches_done < w.max_searches)) break;
@@ -1540,33 +1725,37 @@ CO_DEV int co_mc_do_iteration(CoWave &w, CoTree &t, const float *eval, const flo
     if (w.gc.error) break;
     CO_PH_MEM(20);
 #if CO_SB > 1
+    int counted = 0;
     {
-      /* How many to select together: everything behind a simulation that is not ordinary is selected in vain, so a
-       * position whose simulations keep ending in terminal leaves (endgames: a quarter of them and more) gets groups of
-       * the size that would just have fitted, and grows back by doubling. */
+      const int cap = pe > CO_SB_PE_ONE ? 1 : pe > CO_SB_PE_TWO ? 2 : CO_SB;
       int m = w.spe - w.gc.n_pending;
       if (w.max_searches - t.tc.searches_done < m) m = w.max_searches - t.tc.searches_done;
       if (m > cap) m = cap;
       if (m > 1 && (int)CO_META_NEDGES(rc.h0.z) <= CO_WAVE) {
         const int r = co_search_rows(w, t, rc, m);
-        if (!(r & 0x300)) {
-          cap = 2 * cap < CO_SB ? 2 * cap : CO_SB;
-          continue;
+        for (int i = 0; i < (r & 0xFF); ++i) pe -= pe >> 3;
+        if (r & 0x300) {
+          pe += (256 - pe) >> 3;
+          counted = 1;
         }
-        cap = (r & 0xFF) + 1 < CO_SB ? (r & 0xFF) + 1 : CO_SB;
-        if (r & 0x100) continue;
-      } else if (cap < 2) {
-        cap = 2;
+        if (!(r & 0x200)) continue;
       }
     }
+    const int pending_before = w.gc.n_pending;
 #endif
     CO_SBS(8, 1);
     CO_SBP(w, 6, 1);
     co_search(w, t, rc);
     CO_PROF_ADD(w, 5, 1ull);
+#if CO_SB > 1
+    if (!counted) {
+      if (w.gc.n_pending > pending_before) pe -= pe >> 3; /* (it queued a leaf: ordinary) */
+      else pe += (256 - pe) >> 3;
+    }
+#endif
   }
 #if CO_SB > 1
-  w.gc.sb_cap = cap;
+  w.gc.sb_cap = pe > 0 ? pe : 0;
 #endif
   rs = co_load_unit(t.A, co_load_unit(t.A, t.tc.root + 1).x);
   return (t.tc.searches_done == w.max_searches || co_res_known(co_slot_result(rs))) && w.gc.n_pending == 0;
@@ -2470,7 +2659,10 @@ CO_DEV void co_mcts_step_wave(const EngineParams &P, int g) {
 #ifndef CO_PROF_SLOW_FROM
 #define CO_PROF_SLOW_FROM 0
 #endif
-    if (dt > 280000ull && P.iteration >= CO_PROF_SLOW_FROM) { /* the waves a launch waits for: their phases apart (slot 4 counts them) */
+#ifndef CO_PROF_SLOW_CYCLES
+#define CO_PROF_SLOW_CYCLES 280000ull
+#endif
+    if (dt > CO_PROF_SLOW_CYCLES && P.iteration >= CO_PROF_SLOW_FROM) { /* the waves a launch waits for: their phases apart (slot 4 counts them) */
       for (int i = 0; i < CO_NPROF; ++i) atomicAdd(glob + 24 + i, w.pacc[i]);
     }
     int bucket = (int)(dt / 50000ull);

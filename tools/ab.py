@@ -22,6 +22,9 @@ pools = int(rest[3]) if len(rest) > 3 else 1
 kind = {"mlp12x100": NET_MLP12X100, "mlp12x100x3": 4, "rescnn4": NET_RESCNN4, "rescnn4x3": NET_RESCNN4_X3, "rescnn4h3": 8, "mlp12x100h3": 9,
         "rescnn4x6": 5, "mlp12x100x6": 6}[net]
 w = nets.init_mlp12x100(0) if net.startswith("mlp12x100") else nets.init_rescnn4(0)
+if os.environ.get("AB_TRAINED") and net.startswith("mlp12x100"):  # the reference's last checkpoint instead of random init: narrow, deep trees
+    import numpy as np
+    w = np.load(os.path.join(ROOT, "tests", "golden", "trained_last.npz"))["weights"]
 ts = []
 for spec in libs:
     path, _, envs = spec.partition(":")

@@ -14,14 +14,19 @@ out = os.path.join(ROOT, "gpurun_out", "libcorintho_hip_prof.so")
 os.makedirs(os.path.dirname(out), exist_ok=True)
 extra = [a for a in sys.argv[1:] if a.startswith("-D")]
 sys.argv = [a for a in sys.argv if not a.startswith("-D")]
-cmd = [build.hipcc()] + build.FLAGS + ["-DCO_PROF"] + extra + ["-o", out] + [os.path.join(build.CSRC, s) for s in build.SOURCES]
+csrc = os.environ.get("PROF_CSRC", build.CSRC)  # another tree of the kernel source (an earlier round's, for comparison)
+cmd = [build.hipcc()] + build.FLAGS + ["-DCO_PROF"] + extra + ["-o", out] + [os.path.join(csrc, s) for s in build.SOURCES]
 subprocess.check_call(cmd)
 L = _lib.declare(C.CDLL(out))
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 pools = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 t = Trainer(G, "", 12345, S, 16, 1.0, 0.25, 0, 1, False, stagger=False, pools=pools, _cdll=L)
-t.set_net(9, nets.init_mlp12x100(0))
+import numpy as np  # noqa: E402
+wts = nets.init_mlp12x100(0)
+if os.environ.get("AB_TRAINED"):  # the reference's last checkpoint instead of random init: narrow, deep trees
+    wts = np.load(os.path.join(ROOT, "tests", "golden", "trained_last.npz"))["weights"]
+t.set_net(9, wts)
 t.run()
 st = t.stats()
 NP = 32

@@ -54,6 +54,8 @@ def main():
           (s[3], s[4], s[5], s[6], s[7]))
     print("  levels per group %.2f, scans per committed simulation %.2f, patches below the root per scan %.3f" %
           (s[9] / max(s[0], 1), s[10] / max(s[2], 1), s[11] / max(s[10], 1)))
+    print("  levels below the root per group: shared %.2f, wave-wide for one row %.2f / two rows %.2f, row form %.2f (%.2f turns per such level)" %
+          (s[20] / max(s[0], 1), s[21] / max(s[0], 1), s[22] / max(s[0], 1), s[23] / max(s[0], 1), s[24] / max(s[23], 1)))
     L.co_emu_sb_ply.restype = C.POINTER(C.c_ulonglong)
     pl = [int(L.co_emu_sb_ply()[i]) for i in range(64)]
     print("  by game progress (plies / 4): groups, committed per group, groups ended by a terminal leaf / by the sequential path, sequential simulations")
