@@ -88,6 +88,11 @@ struct CoWave {
   const int32_t *csrc;
   uint32_t *noise_raw;
   int noise_words; /* generator outputs owed to the leaves queued so far in this step */
+  /* the records of up to CO_PRE pending leaves, in the wavefront's LDS: pre[f * CO_PRE + k] = field f (CO_PRE_*) of leaf
+   * pre_c0 + k, k < pre_n.  Requested with the game's other first loads (co_mcts_step_wave) -- in registers until
+   * co_receive_eval they cost 44 spilled registers in the search -- and read by co_receive_eval */
+  int pre_n, pre_c0;
+  uint32_t *pre;
   float *req;
   float *samples;
   int32_t *trace;
@@ -329,118 +334,225 @@ CO_DEV uint32_t co_wave_mt_next(CoWave &w) {
  *   (trainmc.cpp:219-229, 238-241) then run over all 96 move ids in order -- x + 0.0 == x -- as 96 v_add_f32 with a
  *   row_newbcast source each (ROW_SEQ_SUM16), the two chains interleaved.  Weights, row maximum, 9-bit quantisation, the
  *   integer sum and the denominator as in co_prior_leaf. */
-CO_DEV void co_prior_rows(CoWave &w, CoTree &t, int k0, int nk, const float *probs) {
+#define CO_SB_ROWS 4 /* rows of a wavefront */
+/* (-DCO_PROF_PRIORS: the pass split over six stamp slots that are empty otherwise, every stamp behind a full wait) */
+#if defined(CO_PROF_PRIORS) && defined(CO_PROF) && !defined(CO_EMU)
+#define CO_PPH(slot)                                            \
+  do {                                                          \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+    CO_PH(slot);                                                \
+  } while (0)
+#else
+#define CO_PPH(slot) ((void)0)
+#endif
+#define CO_PRE 16
+#define CO_PRE_LEAF 0
+#define CO_PRE_NOFF 1
+#define CO_PRE_L0 2
+#define CO_PRE_L1 3
+#define CO_PRE_L2 4
+#define CO_PRE_ROFF 5 /* where the leaf's row of priors starts, in floats from cval / from the step's probs */
+#define CO_PRE_DEPTH 6
+#define CO_PRE_WORDS (7 * CO_PRE)
+/* the records of pending leaves c0 .. c0 + nc - 1 (nc <= CO_PRE) -> w.pre */
+CO_DEV void co_pending_records(CoWave &w, int c0, int nc) {
+  const uint32_t *pend_leaf = w.pend_leaf;
+  const uint4 *pend_n = (const uint4 *)w.pend_n;
+  const int32_t *pend_depth = w.pend_depth;
+  const int has_cval = w.cval != 0;
+  const int32_t *csrc = w.csrc;
+  uint32_t *pre = w.pre;
+  FOR_LANES_HOT {
+    if (lane < nc) {
+      const int k = c0 + lane;
+      const uint32_t lf = pend_leaf[k];
+      const uint4 pn = pend_n[k];
+      const int dp = pend_depth[k];
+      const uint32_t ro = has_cval ? (uint32_t)csrc[k] * (uint32_t)CO_CACHE_VAL_FLOATS + 4u : (uint32_t)k * (uint32_t)CO_NUM_MOVES;
+      pre[CO_PRE_LEAF * CO_PRE + lane] = lf;
+      pre[CO_PRE_NOFF * CO_PRE + lane] = pn.x >> 8;
+      pre[CO_PRE_L0 * CO_PRE + lane] = pn.y;
+      pre[CO_PRE_L1 * CO_PRE + lane] = pn.z;
+      pre[CO_PRE_L2 * CO_PRE + lane] = pn.w;
+      pre[CO_PRE_ROFF * CO_PRE + lane] = ro;
+      pre[CO_PRE_DEPTH * CO_PRE + lane] = (uint32_t)dp;
+    }
+  }
+  WAVE_SYNC();
+  w.pre_c0 = c0;
+  w.pre_n = nc;
+}
+
+/* is move id column + 16 q legal in the leaf whose 96-bit mask is (l0, l1, l2), and which edge is it */
+CO_DEV int co_prior_legal(uint32_t l0, uint32_t l1, uint32_t l2, int q, int c) {
+  const uint32_t wd = q < 2 ? l0 : q < 4 ? l1 : l2;
+  return (int)((wd >> ((16 * q + c) & 31)) & 1u);
+}
+CO_DEV int co_prior_rank(uint32_t l0, uint32_t l1, uint32_t l2, int q, int c) {
+  const uint32_t wd = q < 2 ? l0 : q < 4 ? l1 : l2;
+  const int bit = (16 * q + c) & 31;
+  const int before = q < 2 ? 0 : q < 4 ? co_popc32(l0) : co_popc32(l0) + co_popc32(l1);
+  return before + co_popc32(wd & ((1u << bit) - 1u));
+}
+/* The passes of a step, four leaves each.  Round 5 stamps (tools/prof_phases.py -DCO_PROF_PRIORS) put a pass at ~9 k
+ * cycles: two trips to memory one behind the other (the leaf's record, then the row of priors and the generator words it
+ * points to), the sequential sums, and the stores of the quantised priors -- behind which the NEXT pass's loads waited, the
+ * counter of outstanding memory operations being retired in order.  So:
+ *   - the records of ALL pending leaves are fetched once, lane k = leaf k, and a pass takes its four by a shuffle;
+ *   - the loads of pass p + 1 are issued BEFORE the stores of pass p (two register sets, X and Y). */
+#define CO_PRIOR_FETCH(K0, on_, leaf_, l0_, l1_, l2_, pq_, rw_)                                                          \
+  {                                                                                                                      \
+    LV(uint32_t, noff_);                                                                                                 \
+    LV(uint32_t, roff_);                                                                                                 \
+    FOR_LANES_HOT {                                                                                                      \
+      int i = (K0)-c0 + (lane >> 4);                                                                                     \
+      i = i < nc ? i : 0;                                                                                                \
+      L(leaf_) = pre[CO_PRE_LEAF * CO_PRE + i];                                                                          \
+      L(noff_) = pre[CO_PRE_NOFF * CO_PRE + i];                                                                          \
+      L(roff_) = pre[CO_PRE_ROFF * CO_PRE + i];                                                                          \
+      L(l0_) = pre[CO_PRE_L0 * CO_PRE + i];                                                                              \
+      L(l1_) = pre[CO_PRE_L1 * CO_PRE + i];                                                                              \
+      L(l2_) = pre[CO_PRE_L2 * CO_PRE + i];                                                                              \
+    }                                                                                                                    \
+    FOR_LANES_HOT {                                                                                                      \
+      const int c = lane & 15;                                                                                           \
+      const int has = (K0) + (lane >> 4) < n;                                                                            \
+      L(on_) = has;                                                                                                      \
+      L(l0_) = has ? L(l0_) : 0u;                                                                                        \
+      L(l1_) = has ? L(l1_) : 0u;                                                                                        \
+      L(l2_) = has ? L(l2_) : 0u;                                                                                        \
+      const float *row = rbase + L(roff_);                                                                               \
+      const uint32_t *raw = noise_raw + L(noff_);                                                                        \
+      _Pragma("unroll") for (int q = 0; q < 6; ++q) {                                                                    \
+        const int legal = co_prior_legal(L(l0_), L(l1_), L(l2_), q, c);                                                  \
+        L(pq_[q]) = row[16 * q + c]; /* (all loads first: their latencies overlap) */                                    \
+        L(rw_[q]) = raw[legal ? co_prior_rank(L(l0_), L(l1_), L(l2_), q, c) : 0];                                        \
+      }                                                                                                                  \
+    }                                                                                                                    \
+  }
+CO_DEV void co_prior_all(CoWave &w, CoTree &t, int c0, int nc, const float *probs) {
   uint4 *A = t.A;
-  LV(int, on);
-  LV(uint32_t, leaf);
-  LV(uint32_t, l0);
-  LV(uint32_t, l1);
-  LV(uint32_t, l2);
-  LV(float, pq[6]);
-  LV(float, gq[6]);
-  LV(int, rk[6]); /* the edge of move id column + 16 q, or -1 */
-  {
-    const uint32_t *pend_leaf = w.pend_leaf;
-    const uint4 *pend_n = (const uint4 *)w.pend_n;
-    const uint32_t *noise_raw = w.noise_raw;
-    const uint32_t *gam = w.gamma;
-    const float *cval = w.cval;
-    const int32_t *csrc = w.csrc;
-    FOR_LANES_HOT {
-      const int r = lane >> 4, c = lane & 15, k = k0 + r;
-      L(on) = r < nk;
-      const int kk = L(on) ? k : k0;
-      L(leaf) = pend_leaf[kk];
-      const uint4 pn = pend_n[kk];
-      L(l0) = pn.y;
-      L(l1) = pn.z;
-      L(l2) = pn.w;
-      const float *row = cval ? cval + (size_t)csrc[kk] * CO_CACHE_VAL_FLOATS + 4 : probs + (size_t)kk * CO_NUM_MOVES;
-      const uint32_t *raw = noise_raw + (pn.x >> 8);
-      const int c0 = co_popc32(pn.y), c01 = c0 + co_popc32(pn.z);
-      uint32_t rw[6];
-#pragma unroll
-      for (int q = 0; q < 6; ++q) {
-        const int id = 16 * q + c, bit = id & 31;
-        const uint32_t wd = q < 2 ? pn.y : q < 4 ? pn.z : pn.w;
-        const int legal = L(on) && ((wd >> bit) & 1u);
-        const int rank = (q < 2 ? 0 : q < 4 ? c0 : c01) + co_popc32(wd & ((1u << bit) - 1u));
-        L(rk[q]) = legal ? rank : -1;
-        L(pq[q]) = row[id]; /* (all loads first: their latencies overlap) */
-        rw[q] = raw[legal ? rank : 0];
-      }
-#pragma unroll
-      for (int q = 0; q < 6; ++q) {
-        const int legal = L(rk[q]) >= 0;
-        const float g = co_u2f(gam[co_mt_temper(rw[q]) % CO_NUM_GAMMA]);
-        L(gq[q]) = legal ? g : 0.0f;
-        L(pq[q]) = legal ? L(pq[q]) : 0.0f;
-      }
-    }
-  }
-  /* a block of sixteen move ids none of the four leaves has a legal move in (the stack moves of an early position: three
-   * of the six blocks) adds sixteen zeros: skipped, here and below */
-  int live[6];
-#pragma unroll
-  for (int q = 0; q < 6; ++q) {
-    LV(int, lq);
-    FOR_LANES_HOT { L(lq) = L(rk[q]) >= 0; }
-    live[q] = WAVE_BALLOT(lq) != 0ull;
-  }
-  LV(float, sum);
-  LV(float, dsum);
-  FOR_LANES_HOT { L(sum) = L(dsum) = 0.0f; }
-#pragma unroll
-  for (int q = 0; q < 6; ++q) {
-    if (!live[q]) continue;
-    ROW_SEQ_SUM16(sum, pq[q]);
-    ROW_SEQ_SUM16(dsum, gq[q]);
-  }
-  LV(float, wt[6]);
-  LV(float, mxl);
+  const uint32_t *noise_raw = w.noise_raw;
+  const uint32_t *gam = w.gamma;
+  const float *rbase = w.cval ? w.cval : probs;
   const float eps = w.epsilon;
-  FOR_LANES_HOT {
-    const float one_minus = (float)1 - eps;
-    const float scalar = (float)(1.0 / (double)L(sum) * (double)one_minus);
-    const float dscalar = (float)(1.0 / (double)L(dsum) * (double)eps);
-    float mx = 0.0f; /* weights are >= 0, as the reference's max_prob start value */
+  const int n = c0 + nc;
+  const uint32_t *pre = w.pre;
+  { /* leaves c0 .. c0 + nc - 1, whose records are in w.pre */
+    CO_PPH(19);
+    LV(int, on);
+    LV(uint32_t, leaf);
+    LV(uint32_t, l0); /* the leaf's legal moves; all zero in a row without a leaf */
+    LV(uint32_t, l1);
+    LV(uint32_t, l2);
+    LV(float, pq[6]);
+    LV(uint32_t, rw[6]);
+    CO_PRIOR_FETCH(c0, on, leaf, l0, l1, l2, pq, rw)
+    for (int k0 = c0; k0 < c0 + nc; k0 += CO_SB_ROWS) {
+      const int more = k0 + CO_SB_ROWS < c0 + nc;
+      CO_PPH(16);
+      LV(float, gq[6]);
+      FOR_LANES_HOT {
+        const int c = lane & 15;
 #pragma unroll
-    for (int q = 0; q < 6; ++q) {
-      const float a = L(pq[q]) * scalar;
-      const float d = L(gq[q]) * dscalar;
-      const float x = a + d;
-      L(wt[q]) = x;
-      if (L(rk[q]) >= 0) mx = x > mx ? x : mx;
-    }
-    L(mxl) = mx;
-  }
-  LV(float, mxr);
-  ROW_MAX_F32(mxr, mxl);
-  LV(int, qs);
-  FOR_LANES_HOT {
-    const float denom = 511.0f / L(mxr);
-    int s = 0;
-#pragma unroll
-    for (int q = 0; q < 6; ++q) {
-      if (L(rk[q]) >= 0) {
-        const float x = L(wt[q]) * denom;
-        /* lround: half away from zero (x >= 0 here; NaN/neg handled like max(1, .)) */
-        const float fl = __builtin_truncf(x);
-        int qq = (int)fl;
-        if (x - fl >= 0.5f) qq += 1;
-        if (!(qq >= 1)) qq = 1;
-        s += qq;
-        A[L(leaf) + 2u + (uint32_t)L(rk[q])].z = (uint32_t)(16 * q + (lane & 15)) | ((uint32_t)(qq & 511) << 7);
+        for (int q = 0; q < 6; ++q) {
+          const int legal = co_prior_legal(L(l0), L(l1), L(l2), q, c);
+          const float g = co_u2f(gam[co_mt_temper(L(rw[q])) % CO_NUM_GAMMA]);
+          L(gq[q]) = legal ? g : 0.0f;
+          L(pq[q]) = legal ? L(pq[q]) : 0.0f;
+        }
       }
-    }
-    L(qs) = s;
-  }
-  LV(int, fs);
-  ROW_SUM_I32(fs, qs);
-  FOR_LANES_HOT {
-    if (L(on) && (lane & 15) == 0) {
-      const float denominator = (float)(1.0 / (double)(float)L(fs));
-      A[L(leaf) + 1u].y = co_f2u(denominator);
+      /* a block of sixteen move ids none of the four leaves has a legal move in (the stack moves of an early position:
+       * three of the six blocks) adds sixteen zeros: skipped */
+      int live[6];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        LV(int, lq);
+        FOR_LANES_HOT {
+          const uint32_t m = q < 2 ? L(l0) : q < 4 ? L(l1) : L(l2);
+          L(lq) = ((q & 1) ? m >> 16 : m & 0xFFFFu) != 0u;
+        }
+        live[q] = WAVE_BALLOT(lq) != 0ull;
+      }
+      CO_PPH(10);
+      LV(float, sum);
+      LV(float, dsum);
+      FOR_LANES_HOT { L(sum) = L(dsum) = 0.0f; }
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        if (!live[q]) continue;
+        ROW_SEQ_SUM16_2(sum, pq[q], dsum, gq[q]);
+      }
+      CO_PPH(25);
+      LV(float, mxl);
+      FOR_LANES_HOT {
+        const int c = lane & 15;
+        const float one_minus = (float)1 - eps;
+        const float scalar = (float)(1.0 / (double)L(sum) * (double)one_minus);
+        const float dscalar = (float)(1.0 / (double)L(dsum) * (double)eps);
+        float mx = 0.0f; /* weights are >= 0, as the reference's max_prob start value */
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          const float a = L(pq[q]) * scalar;
+          const float d = L(gq[q]) * dscalar;
+          const float x = a + d;
+          L(pq[q]) = x; /* the move's weight from here on */
+          if (co_prior_legal(L(l0), L(l1), L(l2), q, c)) mx = x > mx ? x : mx;
+        }
+        L(mxl) = mx;
+      }
+      LV(float, mxr);
+      ROW_MAX_F32(mxr, mxl);
+      CO_PPH(29);
+      /* the next pass's loads, in front of this pass's stores */
+      LV(int, on_y);
+      LV(uint32_t, leaf_y);
+      LV(uint32_t, l0_y);
+      LV(uint32_t, l1_y);
+      LV(uint32_t, l2_y);
+      LV(float, pq_y[6]);
+      if (more) CO_PRIOR_FETCH(k0 + CO_SB_ROWS, on_y, leaf_y, l0_y, l1_y, l2_y, pq_y, rw)
+      LV(int, qs);
+      FOR_LANES_HOT {
+        const int c = lane & 15;
+        const float denom = 511.0f / L(mxr);
+        int sm = 0;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          if (co_prior_legal(L(l0), L(l1), L(l2), q, c)) {
+            const float x = L(pq[q]) * denom;
+            /* lround: half away from zero (x >= 0 here; NaN/neg handled like max(1, .)) */
+            const float fl = __builtin_truncf(x);
+            int qq = (int)fl;
+            if (x - fl >= 0.5f) qq += 1;
+            if (!(qq >= 1)) qq = 1;
+            sm += qq;
+            const uint32_t edge = (uint32_t)co_prior_rank(L(l0), L(l1), L(l2), q, c);
+            A[L(leaf) + 2u + edge].z = (uint32_t)(16 * q + c) | ((uint32_t)(qq & 511) << 7);
+          }
+        }
+        L(qs) = sm;
+      }
+      LV(int, fs);
+      ROW_SUM_I32(fs, qs);
+      FOR_LANES_HOT {
+        if (L(on) && (lane & 15) == 0) {
+          const float denominator = (float)(1.0 / (double)(float)L(fs));
+          A[L(leaf) + 1u].y = co_f2u(denominator);
+        }
+      }
+      if (more) {
+        FOR_LANES_HOT {
+          L(on) = L(on_y);
+          L(leaf) = L(leaf_y);
+          L(l0) = L(l0_y);
+          L(l1) = L(l1_y);
+          L(l2) = L(l2_y);
+#pragma unroll
+          for (int q = 0; q < 6; ++q) L(pq[q]) = L(pq_y[q]);
+        }
+      }
+      CO_PPH(18);
     }
   }
 }
@@ -452,12 +564,18 @@ CO_DEV void co_prior_rows(CoWave &w, CoTree &t, int k0, int nk, const float *pro
  * the value left by the latest earlier leaf of the batch that touched the same slot (register
  * forwarding) instead of re-reading memory. */
 #define CO_RB 8
-#define CO_SB_ROWS 4 /* rows of a wavefront */
-CO_DEV void co_backup_batch(CoWave &w, CoTree &t, int k0, int nb, const float *eval) {
+/* the paths of leaves k0 .. k0 + nb - 1 -> at[k][lane = level] (all CO_PATH_MAX entries whatever the leaf's depth: the
+ * loads do not wait for the depths) */
+CO_DEV void co_backup_paths(CoWave &w, int k0, int nb, LVPA(uint32_t, at, CO_RB)) {
+#pragma unroll
+  for (int k = 0; k < CO_RB; ++k) {
+    const uint32_t *pp = w.pend_path + (size_t)(k < nb ? k0 + k : k0) * CO_PATH_MAX;
+    FOR_LANES { L(at[k]) = pp[lane < CO_PATH_MAX ? lane : 0]; }
+  }
+}
+/* evl: the evaluation (bits) of leaf c0 + k in lane k, its depth in w.pre */
+CO_DEV void co_backup_batch(CoWave &w, CoTree &t, int c0, int k0, int nb, LVP(uint32_t, evl), LVPA(uint32_t, at, CO_RB)) {
   uint4 *A = t.A;
-  LV(int, dv);
-  FOR_LANES { L(dv) = w.pend_depth[lane < nb ? k0 + lane : k0]; }
-  LV(uint32_t, at[CO_RB]);
   LV(uint32_t, ny[CO_RB]);
   LV(uint32_t, nw[CO_RB]);
   LV(uint32_t, nx[CO_RB]); /* (the slot's other two words, so that a slot goes back as ONE 16-byte store) */
@@ -465,12 +583,8 @@ CO_DEV void co_backup_batch(CoWave &w, CoTree &t, int k0, int nb, const float *e
   LV(int, on[CO_RB]);
 #pragma unroll
   for (int k = 0; k < CO_RB; ++k) {
-    int D = WAVE_BCAST(dv, k);
-    const uint32_t *pp = w.pend_path + (size_t)(k < nb ? k0 + k : k0) * CO_PATH_MAX;
-    FOR_LANES {
-      L(on[k]) = (k < nb && lane <= D);
-      L(at[k]) = pp[L(on[k]) ? lane : 0];
-    }
+    const int D = (int)w.pre[CO_PRE_DEPTH * CO_PRE + (k < nb ? k0 - c0 + k : k0 - c0)];
+    FOR_LANES { L(on[k]) = (k < nb && lane <= D); }
   }
   CO_PH_MEM(0);
 #pragma unroll
@@ -487,9 +601,8 @@ CO_DEV void co_backup_batch(CoWave &w, CoTree &t, int k0, int nb, const float *e
   CO_PH_MEM(1);
 #pragma unroll
   for (int k = 0; k < CO_RB; ++k) {
-    int D = WAVE_BCAST(dv, k);
-    float leaf_eval = 0.0f;
-    if (k < nb) leaf_eval = w.cval ? w.cval[(size_t)w.csrc[k0 + k] * CO_CACHE_VAL_FLOATS] : eval[k0 + k];
+    const int D = (int)w.pre[CO_PRE_DEPTH * CO_PRE + (k < nb ? k0 - c0 + k : k0 - c0)];
+    const float leaf_eval = k < nb ? co_u2f(WAVE_BCAST(evl, k0 - c0 + k)) : 0.0f;
     FOR_LANES {
       if (L(on[k])) {
         uint32_t cur = L(ny[k]);
@@ -517,13 +630,34 @@ CO_DEV void co_backup_batch(CoWave &w, CoTree &t, int k0, int nb, const float *e
 /* trainmc.cpp:269-296, the game's share: the priors of the pending leaves are in the tree already
  * (co_k_priors ran on this launch's rows) */
 CO_DEV void co_receive_eval(CoWave &w, CoTree &t, const float *eval, const float *probs) {
-  int n = w.gc.n_pending;
-  for (int k0 = 0; k0 < n; k0 += CO_SB_ROWS) co_prior_rows(w, t, k0, n - k0 < CO_SB_ROWS ? n - k0 : CO_SB_ROWS, probs);
-  WAVE_SYNC();
-  CO_PH_MEM(13);
-  for (int k0 = 0; k0 < n; k0 += CO_RB) {
-    int nb = n - k0 < CO_RB ? n - k0 : CO_RB;
-    co_backup_batch(w, t, k0, nb, eval);
+  const int n = w.gc.n_pending;
+  for (int c0 = 0; c0 < n; c0 += CO_PRE) { /* (one round: searches_per_eval is 16, or 1) */
+    const int nc = n - c0 < CO_PRE ? n - c0 : CO_PRE;
+    /* what the backups need of the leaves' records, requested beside the priors' own first loads: depth and evaluation
+     * of leaf c0 + k in lane k (one trip for the step instead of two dependent scalar loads per leaf behind the priors'
+     * stores) */
+    if (c0 > 0 || w.pre_n != nc) co_pending_records(w, c0, nc); /* (else: requested when the step began) */
+    w.pre_n = 0;
+    LV(uint32_t, evl);
+    {
+      const float *cval = w.cval;
+      const uint32_t *pre = w.pre;
+      FOR_LANES_HOT {
+        const int i = lane < nc ? lane : 0;
+        L(evl) = co_f2u(cval ? cval[pre[CO_PRE_ROFF * CO_PRE + i] - 4u] : eval[c0 + i]);
+      }
+    }
+    LV(uint32_t, pa[CO_RB]);
+    co_prior_all(w, t, c0, nc, probs);
+    WAVE_SYNC();
+    CO_PH_MEM(13);
+    for (int k0 = c0; k0 < c0 + nc; k0 += CO_RB) {
+      const int nb = c0 + nc - k0 < CO_RB ? c0 + nc - k0 : CO_RB;
+      /* (requested in front of the priors' passes instead -- 8 or 16 registers across them: +-0 with the first batch's,
+       * 4 % slower with both, the product build's allocation gives way; round 5) */
+      co_backup_paths(w, k0, nb, pa);
+      co_backup_batch(w, t, c0, k0, nb, evl, pa);
+    }
   }
   CO_PROF_ADD(w, 6, (unsigned long long)n);
   w.gc.n_pending = 0;
@@ -1697,11 +1831,13 @@ CO_DEV int co_mc_do_iteration(CoWave &w, CoTree &t, const float *eval, const flo
     co_request_root(w, t);
     return 0;
   }
-  uint4 rs = co_load_unit(t.A, co_load_unit(t.A, t.tc.root + 1).x);
-  if (t.tc.searches_done == 0 && co_slot_visits(rs) == 1 && co_slot_all_visited(rs)) {
-    t.tc.searches_done = 1;
-    co_request_root(w, t);
-    return 0;
+  if (t.tc.searches_done == 0) { /* (only then: the root's slot is two dependent trips to memory in front of everything else) */
+    const uint4 rs = co_load_unit(t.A, co_load_unit(t.A, t.tc.root + 1).x);
+    if (co_slot_visits(rs) == 1 && co_slot_all_visited(rs)) {
+      t.tc.searches_done = 1;
+      co_request_root(w, t);
+      return 0;
+    }
   }
   if (w.gc.n_pending > 0) co_receive_eval(w, t, eval, probs);
   WAVE_SHARED(uint4, root_ev, CO_WAVE);
@@ -1757,8 +1893,11 @@ CO_DEV int co_mc_do_iteration(CoWave &w, CoTree &t, const float *eval, const flo
 #if CO_SB > 1
   w.gc.sb_cap = pe > 0 ? pe : 0;
 #endif
-  rs = co_load_unit(t.A, co_load_unit(t.A, t.tc.root + 1).x);
-  return (t.tc.searches_done == w.max_searches || co_res_known(co_slot_result(rs))) && w.gc.n_pending == 0;
+  /* (the root's slot only when the answer depends on it: with leaves pending -- nearly every step -- it does not) */
+  if (w.gc.n_pending != 0) return 0;
+  if (t.tc.searches_done == w.max_searches) return 1;
+  const uint4 rs = co_load_unit(t.A, co_load_unit(t.A, t.tc.root + 1).x);
+  return co_res_known(co_slot_result(rs));
 }
 
 /* TrainMC::moveDown, trainmc.cpp:475-495: the chosen child becomes the root.
@@ -2611,6 +2750,8 @@ CO_DEV void co_mcts_step_wave(const EngineParams &P, int g) {
   CoWave w;
   WAVE_SHARED(uint32_t, mt_stage, CO_MT_STAGE);
   w.mt_stage = mt_stage;
+  WAVE_SHARED(uint32_t, pre_rec, CO_PRE_WORDS);
+  w.pre = pre_rec;
   WG_SHARED(uint32_t, lb, CO_LB_WORDS);
   co_line_breakers_to_lds(lb);
   w.lb = lb;
@@ -2629,6 +2770,9 @@ CO_DEV void co_mcts_step_wave(const EngineParams &P, int g) {
   w.tph = t_wave0;
 #endif
   co_wave_init(P, g, gc, tc0, tc1, w);
+  /* (in front of the generator's state: the counter of outstanding loads retires in order, and the step needs these first) */
+  w.pre_n = 0;
+  if (w.gc.n_pending > 0) co_pending_records(w, 0, w.gc.n_pending < CO_PRE ? w.gc.n_pending : CO_PRE);
   co_mt_stage_load(w.mt, w.mt_stage);
   w.mt_staged = 1;
   CO_PROF_ADD(w, 4, 1ull);

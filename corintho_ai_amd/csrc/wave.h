@@ -51,6 +51,7 @@ static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
 #define CO_CONST static const
 #define LV(T, x) T x[CO_WAVE]
 #define LVP(T, x) T *x /* an LV variable as a function parameter */
+#define LVPA(T, x, N) T (*x)[CO_WAVE] /* ... an array of N of them */
 #define CO_OPAQUE_V(x) ((void)0)
 #define L(x) x[lane]
 #define LAT(x, i) x[(i)]
@@ -144,6 +145,11 @@ static inline void emu_row_shfl_u32(uint32_t *d, const uint32_t *s, const int *c
   for (int l = 0; l < CO_WAVE; ++l) t[l] = s[(l & ~(CO_ROW_LANES - 1)) + (col[l] & (CO_ROW_LANES - 1))];
   memcpy(d, t, sizeof t);
 }
+static inline void emu_wave_shfl_u32(uint32_t *d, const uint32_t *s, const int *src) {
+  uint32_t t[CO_WAVE];
+  for (int l = 0; l < CO_WAVE; ++l) t[l] = s[src[l] & (CO_WAVE - 1)];
+  memcpy(d, t, sizeof t);
+}
 static inline void emu_row_sum_i32(int *d, const int *s) {
   int t[CO_WAVE];
   for (int r = 0; r < CO_WAVE; r += CO_ROW_LANES) {
@@ -164,10 +170,12 @@ static inline void emu_row_seq_sum16(float *acc, const float *v) {
 }
 #define ROW_SUM_I32(d, s) emu_row_sum_i32(d, s)
 #define ROW_SEQ_SUM16(acc, v) emu_row_seq_sum16(acc, v)
+#define ROW_SEQ_SUM16_2(a0, v0, a1, v1) (emu_row_seq_sum16(a0, v0), emu_row_seq_sum16(a1, v1))
 #define ROW_MAX_F32(d, s) emu_row_max_f32(d, s)
 #define ROW_MIN_U32(d, s) emu_row_min_u32(d, s)
 #define ROW_BALLOT(d, p) emu_row_ballot(d, p)           /* d = the 16 predicate bits of the lane's row */
 #define ROW_SHFL_U32(d, s, col) emu_row_shfl_u32(d, s, col) /* d = s of lane `col` (an LV int, 0..15) of the same row */
+#define WAVE_SHFL_U32(d, s, src) emu_wave_shfl_u32(d, s, src) /* d = s of lane `src` (an LV int, 0..63) */
 extern thread_local int co_emu_block_idx;
 #define CO_BLOCK_IDX co_emu_block_idx
 /* kernels whose wavefronts are independent may pack several per workgroup on the GPU (fewer, fatter
@@ -194,6 +202,7 @@ extern thread_local int co_emu_block_idx;
 #define CO_CONST __device__ const
 #define LV(T, x) T x
 #define LVP(T, x) T &x
+#define LVPA(T, x, N) T (&x)[N]
 /* the compiler may not look through x from here on.  For values derived from the lane index in hot sections: left
  * transparent, every such expression (1 << column, row * stride, ...) is hoisted to the kernel's entry, lives across the
  * whole step and is spilled -- and a reload from scratch behind a store waits for the store (round 5: six of them in the
@@ -401,36 +410,79 @@ __device__ __forceinline__ int co_row_sum_i32(int v) {
   v += CO_DPP_I(v, CO_DPP_MIRROR);
   return v;
 }
-/* sixteen v_add_f32 with a DPP source (row_newbcast:c = column c of the lane's own row), one after the other */
-template <int C>
-__device__ __forceinline__ float co_row_col(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + C, 0xF, 0xF, false));
-}
+/* sixteen v_add_f32 with a DPP source (row_newbcast:c = column c of the lane's own row), one after the other.  Written as
+ * the instructions themselves: from the builtin (update_dpp, then an addition) the compiler makes a v_mov_b32 of the "old"
+ * value, a v_mov_b32_dpp and a packed addition per column -- five instructions where two chains need two, and a step's
+ * priors are issue-bound there (round 5: 3.0 k of a pass's 9 k cycles).  The leading s_nop covers the two wait states
+ * between a VALU write of the DPP source and its DPP read, which the hazard recogniser cannot see into the asm for. */
 __device__ __forceinline__ float co_row_seq_sum16(float a, float v) {
-  a += co_row_col<0>(v);
-  a += co_row_col<1>(v);
-  a += co_row_col<2>(v);
-  a += co_row_col<3>(v);
-  a += co_row_col<4>(v);
-  a += co_row_col<5>(v);
-  a += co_row_col<6>(v);
-  a += co_row_col<7>(v);
-  a += co_row_col<8>(v);
-  a += co_row_col<9>(v);
-  a += co_row_col<10>(v);
-  a += co_row_col<11>(v);
-  a += co_row_col<12>(v);
-  a += co_row_col<13>(v);
-  a += co_row_col<14>(v);
-  a += co_row_col<15>(v);
+  asm("s_nop 1\n\t"
+      "v_add_f32_dpp %0, %1, %0 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %1, %0 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %1, %0 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %1, %0 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %1, %0 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %1, %0 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %1, %0 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %1, %0 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %1, %0 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %1, %0 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %1, %0 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %1, %0 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %1, %0 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %1, %0 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %1, %0 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %1, %0 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+      : "+v"(a)
+      : "v"(v));
   return a;
+}
+/* two independent sums, interleaved */
+__device__ __forceinline__ void co_row_seq_sum16_2(float &a0, float v0, float &a1, float v1) {
+  asm("s_nop 1\n\t"
+      "v_add_f32_dpp %0, %2, %0 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %3, %1 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %2, %0 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %3, %1 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %2, %0 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %3, %1 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %2, %0 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %3, %1 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %2, %0 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %3, %1 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %2, %0 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %3, %1 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %2, %0 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %3, %1 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %2, %0 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %3, %1 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %2, %0 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %3, %1 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %2, %0 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %3, %1 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %2, %0 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %3, %1 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %2, %0 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %3, %1 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %2, %0 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %3, %1 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %2, %0 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %3, %1 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %2, %0 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %3, %1 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %2, %0 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %3, %1 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+      : "+v"(a0), "+v"(a1)
+      : "v"(v0), "v"(v1));
 }
 #define ROW_SUM_I32(d, s) ((d) = co_row_sum_i32(s))
 #define ROW_SEQ_SUM16(acc, v) ((acc) = co_row_seq_sum16((acc), (v)))
+#define ROW_SEQ_SUM16_2(a0, v0, a1, v1) co_row_seq_sum16_2((a0), (v0), (a1), (v1))
 #define ROW_MAX_F32(d, s) ((d) = co_row_max_f32(s))
 #define ROW_MIN_U32(d, s) ((d) = co_row_min_u32(s))
 #define ROW_BALLOT(d, p) ((d) = co_row_ballot(p))
 #define ROW_SHFL_U32(d, s, col) ((d) = co_row_shfl_u32((s), (col)))
+#define WAVE_SHFL_U32(d, s, src) ((d) = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((unsigned)(src) & 63u) << 2), (int)(s)))
 #define CO_BLOCK_IDX ((int)blockIdx.x)
 #define CO_WAVES_PER_BLOCK 4
 #define CO_WAVE_IN_BLOCK ((int)(threadIdx.x >> 6))
