@@ -475,6 +475,22 @@ __device__ __forceinline__ void rcs_stage(const uint32_t *wtrunk, uint32_t lds_a
  * terms keep 2 x 11 = 22 significand bits) */
 template <int NT, bool F16 = false>
 __device__ __forceinline__ void rcs_split(float a, float b, uint32_t (&t)[NT]) {
+  if constexpr (F16 && NT == 2) {
+    /* three instructions instead of five: the pair's first terms, then each second term as ONE mixed-precision fma,
+     * f16(a - float(t0.lo)) -- the difference is exact in float32 (see above), so the one rounding is the conversion's,
+     * as before: the same bits.  (An epilogue of the f16x3 kernels is vector-issue-bound: 336 -> 272 instructions per
+     * wave in the pixel-major kernel; round 5.) */
+    const f32x2 v2 = {a, b};
+    const uint32_t t0 = __builtin_bit_cast(uint32_t, __builtin_convertvector(v2, f16x2));
+    uint32_t t1;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(t1)
+        : "v"(t0), "v"(a), "v"(b));
+    t[0] = t0;
+    t[1] = t1;
+    return;
+  }
   f32x2 v = {a, b};
 #pragma unroll
   for (int i = 0; i < NT; ++i) {
@@ -495,6 +511,18 @@ __device__ __forceinline__ void rcs_split(float a, float b, uint32_t (&t)[NT]) {
     }
   }
 }
+
+/* The range guard of the f16x3 kinds (nn.h range_exceeded) follows the FIRST terms as they are split: the running maximum
+ * of the packed fp16 pairs, one v_pk_max_f16 per pair of activations (on the float32 values it was two v_max_f32 per pair
+ * in a vector-issue-bound epilogue).  What is split is an input plane or the output of a ReLU, never negative; an
+ * activation beyond fp16's range has the first term +inf -- exactly the event the guard reports (a NaN can only follow an
+ * infinity, which is reported when it appears). */
+__device__ __forceinline__ uint32_t rcs_pk_max_f16(uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_pk_max_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ bool rcs_pk_f16_finite(uint32_t pk) { return (pk & 0x7FFFu) < 0x7C00u && ((pk >> 16) & 0x7FFFu) < 0x7C00u; }
 
 /* one v_mfma_f32_32x32x16 on packed 16-bit operands: bf16 terms, or fp16 terms */
 template <bool F16>
@@ -645,7 +673,7 @@ __device__ __forceinline__ void rcs_conv3x3(f32x16 (&acc)[NP][2], const uint32_t
 
 /* fp32 tile values -> the packed operands of the next convolution */
 template <int NP, int NT, bool F16 = false>
-__device__ __forceinline__ void rcs_pack(uint32_t (&p)[NT][NP][4][4], const float (&v)[NP][2][16], float &amax) {
+__device__ __forceinline__ void rcs_pack(uint32_t (&p)[NT][NP][4][4], const float (&v)[NP][2][16], uint32_t &amax) {
 #pragma unroll
   for (int np = 0; np < NP; ++np)
 #pragma unroll
@@ -656,8 +684,8 @@ __device__ __forceinline__ void rcs_pack(uint32_t (&p)[NT][NP][4][4], const floa
         for (int m = 0; m < 4; ++m) {
           uint32_t t[NT];
           /* (what is packed is an input plane or the output of a ReLU: never negative) */
-          if constexpr (F16) amax = __builtin_fmaxf(amax, __builtin_fmaxf(v[np][T][8 * a + 2 * m], v[np][T][8 * a + 2 * m + 1]));
           rcs_split<NT, F16>(v[np][T][8 * a + 2 * m], v[np][T][8 * a + 2 * m + 1], t);
+          if constexpr (F16) amax = rcs_pk_max_f16(amax, t[0]);
 #pragma unroll
           for (int i = 0; i < NT; ++i) p[i][np][2 * T + a][m] = t[i];
         }
@@ -762,7 +790,7 @@ __device__ __forceinline__ void rcs_forward(const Rc3Params &Q, const int rbase 
     }
   }
   uint32_t pk[NT][NP][4][4];
-  float amax = 0.0f;
+  uint32_t amax = 0u; /* (packed fp16 pair: rcs_pk_max_f16) */
   rcs_pack<NP, NT, F16>(pk, x, amax);
   /* weight stream, requested behind the input loads (vmcnt retires in issue order): group 0, the
    * epilogue constants and, with two terms, the head weights (the wait before the first MFMA
@@ -793,7 +821,7 @@ __device__ __forceinline__ void rcs_forward(const Rc3Params &Q, const int rbase 
     RC3_STAMP(2)
   }
   if constexpr (F16) {
-    if (!(amax <= CO_F16_MAX)) atomicOr(Q.range_flag, 1u); /* (never in range: no lane enters) */
+    if (!rcs_pk_f16_finite(amax)) atomicOr(Q.range_flag, 1u); /* (never in range: no lane enters) */
   }
   if (NT != 2) {
     /* the head weights were requested behind the last group */
@@ -1043,7 +1071,7 @@ __device__ __forceinline__ void rcp_conv3x3(f32x16 (&acc)[2][2], int &g, const R
  * epilogue while the slower SIMDs still multiply, and only the sixteen stores per pixel stand behind the barrier. */
 template <bool ADD_SKIP, bool KEEP>
 __device__ __forceinline__ void rcp_epilogue(float (&x)[2][2][16], const f32x16 (&acc)[2][2], const float *epi, uint32_t *X, int P0, int P1,
-                                             int h, int lane, float &amax) {
+                                             int h, int lane, uint32_t &amax) {
   u32x4 hi[2][2][2], lo[2][2][2]; /* [pixel][tile][half of the tile's registers] */
 #pragma unroll
   for (int T = 0; T < 2; ++T) {
@@ -1076,9 +1104,9 @@ __device__ __forceinline__ void rcp_epilogue(float (&x)[2][2][16], const f32x16 
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
           const float u0 = out[pi][8 * a2 + 2 * m], u1 = out[pi][8 * a2 + 2 * m + 1];
-          amax = __builtin_fmaxf(amax, __builtin_fmaxf(u0, u1));
           uint32_t t[2];
           rcs_split<2, true>(u0, u1, t);
+          amax = rcs_pk_max_f16(amax, t[0]);
           hi[pi][T][a2][m] = t[0];
           lo[pi][T][a2][m] = t[1];
         }
@@ -1174,7 +1202,7 @@ __global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_h3p(Rc3Params Q) {
       *reinterpret_cast<u32x4 *>(X + ((p * 4 + 0) * 2 + 0) * 256 + lane * 4) = f;
     }
   }
-  float amax = 0.0f;
+  uint32_t amax = 0u; /* (packed fp16 pair: rcs_pk_max_f16) */
   f32x16 acc[2][2];
   float x[2][2][16];
 #pragma unroll
@@ -1200,7 +1228,7 @@ __global__ __launch_bounds__(512, 2) void co_k_rescnn_forward_h3p(Rc3Params Q) {
     rcp_epilogue<true, true>(x, acc, epi + (2 + 2 * b) * 192, X, P0, P1, h, lane, amax);
     RCP_PHASE(2)
   }
-  if (!(amax <= CO_F16_MAX)) atomicOr(Q.range_flag, 1u); /* (never in range: no lane enters) */
+  if (!rcs_pk_f16_finite(amax)) atomicOr(Q.range_flag, 1u); /* (never in range: no lane enters) */
   /* heads: item 81 = the 1x1 convolutions' fragments (rows 0..3 policy planes, 4..5 value planes), in buffer 1; the head
    * features of the 32 positions go to buffer 0, which tap 80 has left */
   CO_WAIT_VMCNT(0);
