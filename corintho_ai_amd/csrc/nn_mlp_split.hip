@@ -82,6 +82,20 @@ __device__ __forceinline__ void m3_stage(const uint32_t *w, uint32_t lds_slot_ad
 /* (a, b) -> NT packed 16-bit pairs: the values rounded to bf16 (F16: fp16), then the successive remainders */
 template <int NT, bool F16 = false>
 __device__ __forceinline__ void m3_split(float a, float b, uint32_t (&t)[NT]) {
+  if constexpr (F16 && NT == 2) {
+    /* (as nn_rescnn.hip rcs_split: each second term is one mixed-precision fma, f16(a - float(t0.lo)); the difference is
+     * exact in float32, the one rounding is the conversion's -- the same bits in three instructions instead of five) */
+    const m3_f32x2 v2 = {a, b};
+    const uint32_t t0 = __builtin_bit_cast(uint32_t, __builtin_convertvector(v2, m3_f16x2));
+    uint32_t t1;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(t1)
+        : "v"(t0), "v"(a), "v"(b));
+    t[0] = t0;
+    t[1] = t1;
+    return;
+  }
   m3_f32x2 v = {a, b};
 #pragma unroll
   for (int i = 0; i < NT; ++i) {
@@ -221,7 +235,8 @@ __global__ __launch_bounds__(256, 1) void co_k_mlp_forward_split_t(const float *
   m3_stage<NT>(wfrag, lds_base, 0, wave, lane);
   m3_stage<NT>(wfrag, lds_base + M3_CHUNK_WORDS(NT) * 4u, 1, wave, lane);
   m3_f32x16 acc[4];
-  float amax = 0.0f; /* F16: the largest activation split into fp16 terms (nn.h range_exceeded) */
+  uint32_t amax = 0u; /* F16: the running maximum of the packed first terms (nn.h range_exceeded; nn_rescnn.hip rcs_pk_max_f16: an
+                       * activation beyond fp16's range has the first term +inf; ReLU outputs are never negative) */
   for (int l = 0; l < M3_NLAYERS; ++l) {
     const int c0 = 2 * l;
     {
@@ -249,16 +264,16 @@ __global__ __launch_bounds__(256, 1) void co_k_mlp_forward_split_t(const float *
             float v0 = acc[T][8 * a + 2 * m], v1 = acc[T][8 * a + 2 * m + 1];
             v0 = v0 > 0.0f ? v0 : 0.0f;
             v1 = v1 > 0.0f ? v1 : 0.0f;
-            if constexpr (F16) amax = __builtin_fmaxf(amax, __builtin_fmaxf(v0, v1));
             uint32_t t[NT];
             m3_split<NT, F16>(v0, v1, t);
+            if constexpr (F16) asm("v_pk_max_f16 %0, %1, %2" : "=v"(amax) : "v"(amax), "v"(t[0]));
 #pragma unroll
             for (int i = 0; i < NT; ++i) b[i][2 * T + a][m] = t[i];
           }
     }
   }
   if constexpr (F16) {
-    if (!(amax <= CO_F16_MAX)) atomicOr(range_flag, 1u); /* (never in range: no lane enters) */
+    if (!((amax & 0x7FFFu) < 0x7C00u && ((amax >> 16) & 0x7FFFu) < 0x7C00u)) atomicOr(range_flag, 1u); /* (never in range: no lane enters) */
   }
   /* heads: features 0..95 = policy logits (tiles 0..2), feature 96 = value (tile 3, g 0, h 0, i 0) */
   float mx = -INFINITY;
