@@ -231,6 +231,7 @@ CASES = [
     (6, 400, 16, 0.25),   # BASELINE sims/move
     (40, 8, 4, 0.25),     # staggered start, tiny trees
     (5, 1, 1, 0.25), (5, 2, 1, 0.25), (5, 3, 2, 0.25),  # selfplayer_test.cpp FewSearches corner
+    (6, 120, 40, 0.25),   # more leaves pending than one round of the step's staged records (16) and two backup batches hold
 ]
 
 
