@@ -91,7 +91,9 @@ struct DevBuf {
 };
 
 #define CO_MAX_POOLS 4
-#define CO_POOL_POLL 8 /* fused training: iterations between polls of a pool's counter */
+#ifndef CO_POOL_POLL
+#define CO_POOL_POLL 16 /* fused training: iterations between polls of a pool's counter (round 5, three pools: 4 / 8 / 16 / 32 / 64 = 134.4 / 131.6 / 130.0 / 129.8 / 130.0 ms per mlp12x100 generation, 395.0 / 393.6 / 391.9 / 391.8 / 392.9 with rescnn4) */
+#endif
 
 /* one independent slice of the games in fused training (run_pools) */
 struct Pool {
