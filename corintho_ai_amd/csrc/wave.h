@@ -227,7 +227,9 @@ __device__ __forceinline__ int co_lane_opaque() {
  * each, CO_K3_WPB = 16 packs them onto half of the CUs at four waves per SIMD and leaves the other CUs to the
  * network kernel of the other pool (whose waves take a SIMD's whole register file). */
 #ifndef CO_K3_WPB
-#define CO_K3_WPB 16 /* measured (round 3, rescnn4h3, two pools): 1 -> 466.7 ms, 4 -> 463.6, 16 -> 455.6 per generation; the MLP: +-0 */
+#define CO_K3_WPB 16 /* measured (round 3, rescnn4h3, two pools): 1 -> 466.7 ms, 4 -> 463.6, 16 -> 455.6 per generation; the MLP: +-0.
+                     * Round 5, three pools, grouped search: 16 / 8 / 4 -> 397.2 / 397.2 / 398.8 (rescnn4h3), 130.3 / 130.2 / 129.8 (mlp12x100h3): the
+                     * search's device time falls 5 % with fewer wavefronts per SIMD and the network's rises by as much */
 #endif
 #if CO_K3_WPB == 1
 #define WAVE_SHARED(T, name_, n) __shared__ T name_[n]
