@@ -112,6 +112,10 @@ def parse():
     ap.add_argument("--no-eval-cache", action="store_true",
                     help="evaluate every request row (the engine's evaluation cache off); the default run reports this as the "
                          "`no_eval_cache` variant")
+    ap.add_argument("--check-gather", action="store_true",
+                    help="with a process group (N > 1, or CORINTHO_FORCE_DIST=1 at N = 1): behind the timed region every rank compares "
+                         "its block of one more gathered generation with its own export_samples() byte for byte "
+                         "(detail.collectives_per_step.gather_check)")
     ap.add_argument("--engine", default="hip", choices=("hip", "emu"),
                     help="hip = the product (libcorintho_hip.so on an MI355X).  emu = CPU rehearsal of the multi-rank path for "
                          "the tests only: the lane-loop build of the same kernel source (tests/emu) over gloo; never a result")
@@ -529,6 +533,28 @@ def main():
         job_searches, job_evals, job_rows = float(totals["searches"]), float(totals["evals"]), float(totals["nn_rows"])
         job_samples = float(totals["samples"])
 
+    gather_check = None
+    if use_dist and args.check_gather:
+        # Trainer::writeSamples order over the whole job (trainer.cpp:103-113): rank r's rows stand behind those of the
+        # ranks before it; each rank holds the bytes it contributed, so each checks its own block of what came back
+        tr.reset(424242)
+        assert tr.run()
+        t0 = time.perf_counter()
+        sp_all, oc_all = gatherer.rows()
+        g_ms = (time.perf_counter() - t0) * 1e3
+        counts = gatherer.all_cnt.cpu().numpy().astype(np.int64)
+        lo = int(counts[:rank].sum())
+        sp_own, oc_own = tr.export_samples()
+        equal = (sp_all.shape[0] == int(counts.sum()) and int(counts[rank]) == sp_own.shape[0] == tr.num_samples()
+                 and sp_all[lo:lo + sp_own.shape[0]].tobytes() == sp_own.tobytes()
+                 and oc_all[lo:lo + oc_own.shape[0]].tobytes() == oc_own.tobytes())
+        flag = torch.tensor([0.0 if equal else 1.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(flag)
+        gather_check = {"rows_gathered": int(sp_all.shape[0]), "rows_own": int(sp_own.shape[0]), "num_samples": tr.num_samples(),
+                        "ranks_with_a_difference": int(flag.item()), "bytes_equal_to_export_samples": int(flag.item()) == 0,
+                        "gather_and_copy_back_ms": g_ms, "payload_on": gatherer.dev, "backend": dist.get_backend(),
+                        "payload_bytes": gatherer.bytes_moved}
+
     if rank == 0:
         _, arch, dtype, peak, issued, kname = NETS[args.net]
         flop_per_row = flop_by_arch[arch]
@@ -606,6 +632,8 @@ def main():
                 "sample_bytes_gathered_per_step": totals["gather_bytes"] / max(args.steps, 1),
                 "generation_score": totals["score"] / max(args.steps, 1), "unfinished_games": totals["unfinished"],
                 "samples_gathered": totals["gathered_samples"], "samples_of_all_shards": job_samples}
+            if gather_check is not None:
+                out["detail"]["collectives_per_step"]["gather_check"] = gather_check
         if world == 1 and not args.no_variants:
             # the other network kinds on the same pool: the same timed loop, each with its own roofline object
             vsteps = max(1, min(args.variant_steps, args.steps))

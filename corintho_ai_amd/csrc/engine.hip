@@ -950,12 +950,14 @@ struct ca_trainer {
   bool net_used = false; /* a network launch has been queued since the range flags were last read */
   void check_net_range() {
     if (!net_used) return; /* (no copy and stream wait per slot when nothing ran) */
-    net_used = false;
+    /* the device flag is sticky for the life of the network object: net_used is cleared only when every slot is clean, so
+     * that every later check (export, score, write samples) raises again until set_net replaces the slot */
     for (int slot = 0; slot < 2; ++slot)
       if (nets[slot] && nets[slot]->range_exceeded(stream))
         throw EngineError(CA_ERR_ENGINE, std::string("network slot ") + std::to_string(slot) +
                                              ": an activation left the fp16 range of the f16x3 kernels (|x| > 65504); the evaluations "
                                              "are not valid -- use the float32-equivalent x6 kind of the same network");
+    net_used = false;
   }
 
   /* host rows in, host results out (ca_trainer_net_forward): persistent device buffers; the rows travel as
@@ -1173,8 +1175,11 @@ struct ca_trainer {
         if (guard_from >= 0 && trainer_iteration <= guard_from + 2 * poll + 1) {
           /* (the streams are within two windows of each other: the host waits for window w - 1 before it queues w + 1) */
           pp.cache.guard_from = (uint32_t)guard_from;
+          /* the OTHER pools only: this pool's own reads of the old contents happened in its launch of iteration
+           * guard_from, which stands in front of this launch in its stream -- with its own bit set, every wavefront
+           * that runs before the launch's first wave has stored done[p] would lose its claims for nothing */
           for (int p2 = 0; p2 < npools; ++p2)
-            if (!pools[p2].finished) pp.cache.guard_pools |= 1u << p2;
+            if (p2 != p && !pools[p2].finished) pp.cache.guard_pools |= 1u << p2;
         }
         const bool timed = in_window == poll - 1 || (max_iterations > 0 && it + 1 == max_iterations);
         /* The network launch is sized by what the batch can hold: the games still running at the pool's last poll (they
@@ -1238,7 +1243,10 @@ struct ca_trainer {
         if (!failure.empty()) break;
       }
     }
-    /* drain: read what is still in flight (the last window, or both after an iteration cap) */
+    /* drain: read what is still in flight (the last window, or both after an iteration cap).  EVERY pool's stream is
+     * synchronised here, whichever way the loop ended: that is what allows `guard_from` to be a local of this call -- a
+     * later call (an iteration-capped run resumed) starts with no launch of any pool in flight, so no pool can still be
+     * reading elements of a table emptied in an earlier call. */
     for (auto &q : pools) {
       rt_sync(q.st);
       for (int w = 0; w < 2; ++w) collect(q, (window + w) & 1);
@@ -1732,8 +1740,10 @@ extern "C" int ca_tourney_stats(ca_tourney *t, ca_stats *out) {
 /* diagnostic builds (-DCO_PROF): summed in-kernel cycle stamps, see mcts.h; not in the public header */
 extern "C" int ca_trainer_prof(ca_trainer *t, unsigned long long out[2 * CO_NPROF + 24]) {
   CA_TGUARD({
-    for (int i = 0; i < 2 * CO_NPROF + 24; ++i) out[i] = 0;
+    /* nothing is written to `out` unless this is a stamped build: a caller of the shipped library with a buffer sized for
+     * an earlier round's layout gets the error, not an overflow */
     if (!t->prof.p) throw EngineError(CA_ERR_STATE, "not a -DCO_PROF build");
+    for (int i = 0; i < 2 * CO_NPROF + 24; ++i) out[i] = 0;
     std::vector<unsigned long long> h((size_t)t->R * CO_NPROF);
     rt_d2h(h.data(), t->prof.p, h.size() * 8, t->stream);
     rt_sync(t->stream);

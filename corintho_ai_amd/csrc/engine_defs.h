@@ -186,12 +186,12 @@ struct EngineParams {
   uint32_t *pend_path;  /* [G][spe][CO_PATH_MAX] */
   uint4 *pend_key;      /* [G][spe] cache keys of the pending leaves' request rows (fused training with the evaluation cache) */
   int32_t *pend_src;    /* [G][spe] element of the cache's value array that holds the outputs of pending leaf k (resolved at
-                         * the end of the step that queued the leaf): K2b and K3 fetch it with the leaf's other words */
+                         * the end of the step that queued the leaf): K3's receive phase fetches it with the leaf's other words */
   uint32_t *pend_n;     /* [G][spe][4] {(first noise word of the leaf << 8) | legal moves of the leaf, legal-move mask [3]}:
-                         * everything co_k_priors needs to fetch the leaf's priors without walking the tree first */
+                         * everything the priors pass (mcts.h co_prior_all) needs to fetch the leaf's priors without walking the tree first */
   uint32_t *noise_raw;  /* [G][spe * CO_NUM_MOVES] generator outputs (untempered state words) reserved for the pending
                          * leaves' Dirichlet noise, in request order: drawn when the leaves are queued (mcts.h
-                         * co_capture_noise), consumed by co_k_priors */
+                         * co_capture_noise), consumed by the priors pass of the step that receives the evaluations */
   uint32_t *rng;        /* [G][624] */
   float *req;           /* [G][spe][CO_STATE_STRIDE] */
   int32_t *req_offset;  /* [G+1] exclusive prefix of the active games' request counts; [G] = total */

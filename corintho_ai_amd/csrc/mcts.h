@@ -238,10 +238,11 @@ CO_DEV void co_request(CoWave &w, uint64_t board, uint32_t meta, uint32_t leaf, 
  * outputs owed to it, and of nothing else.  (2) The backup of the value along the path to the root
  * (:280-295), which touches slots shared with other leaves and must run in request order.
  * Round 1 ran both inside the game's wavefront, leaf after leaf: 37 % of the search kernel's wave
- * cycles, serial per game, with ~28 of 64 lanes busy.  Part (1) is independent per LEAF: it is its
- * own kernel now (co_k_priors, kernels.h: one wavefront per pending leaf of every game that steps in
- * this launch, tens of thousands at once), run right before the search kernel; the game's wavefront
- * keeps part (2) only.
+ * cycles, serial per game, with ~28 of 64 lanes busy.  Part (1) is independent per LEAF: rounds 2-4 ran
+ * it as a kernel of its own in front of the search launch (one wavefront per pending leaf); since round 5
+ * it is back inside the step, FOUR LEAVES AT A TIME, one per 16-lane row of the game's wavefront
+ * (co_prior_all / co_prior_rows below, called from co_receive_eval in front of part (2)) -- no launch of
+ * its own, and no second kernel that has to agree with this one on which games step.
  *
  * The generator: a game's two searchers share one std::mt19937 (selfplayer.cpp:23-28) and the
  * reference draws a leaf's noise when the leaf's evaluation is received.  Between queueing a leaf
@@ -627,8 +628,8 @@ CO_DEV void co_backup_batch(CoWave &w, CoTree &t, int c0, int k0, int nb, LVP(ui
   w.gc.evals += (uint32_t)nb;
 }
 
-/* trainmc.cpp:269-296, the game's share: the priors of the pending leaves are in the tree already
- * (co_k_priors ran on this launch's rows) */
+/* trainmc.cpp:269-296: the priors of the pending leaves (co_prior_all, four leaves per pass), then the backups in
+ * request order */
 CO_DEV void co_receive_eval(CoWave &w, CoTree &t, const float *eval, const float *probs) {
   const int n = w.gc.n_pending;
   for (int c0 = 0; c0 < n; c0 += CO_PRE) { /* (one round: searches_per_eval is 16, or 1) */
@@ -2447,8 +2448,7 @@ CO_DEV int co_game_step(CoWave &w, const float *eval, const float *probs) {
 }
 
 /* Does game g step in this launch?  0 no, 1 yes, 2 not yet released by the staggered start.
- * (trainer.cpp:176-196 training, :216-229 arena, tourney.cpp:63-72; shared by the search kernel and
- * by co_k_priors, which must agree on the games whose evaluations are consumed) */
+ * (trainer.cpp:176-196 training, :216-229 arena, tourney.cpp:63-72) */
 CO_DEV int co_step_gate(const EngineParams &P, int g, const GameCtl &gc) {
   if (gc.done || gc.error) return 0;
   const int tp = P.arena_state ? P.arena_state[0] : P.to_play;

@@ -26,7 +26,7 @@
 /* two fp16 terms per operand (22 significand bits), three MFMA products: float32-class arithmetic at the cost of bf16x3 */
 #define CO_NET_RESCNN4_H3 8
 #define CO_NET_MLP12X100_H3 9
-/* (7 was round 2's Winograd experiment, tools/exp/archive) */
+/* (7 was round 2's Winograd experiment, git 22960a5:tools/exp/archive, removed from the tree in round 6) */
 
 /* mlp12x100 flat weight layout (float32), matching Keras get_weights() order of
  * wrapper.py:256-271:

@@ -1,7 +1,8 @@
 """The reference's own rule tests (tests/cpp/game_test.cpp, move_test.cpp,
 node_test.cpp) restated over an abstract backend, so the same known-answer
 scenarios run against the CPU oracle (tests/test_oracle_reference_tests.py)
-and against the HIP rule kernels (tests/test_gpu_rules.py).
+and against the HIP rule kernels through the C ABI (tests/test_engine_parity.py::test_reference_rule_scenarios,
+`hip` and `emu` engines).
 
 A backend provides:
   new_game() -> game with .legal_moves() -> (list[96] of bool, is_lines),

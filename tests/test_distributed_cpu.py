@@ -39,8 +39,20 @@ dist.destroy_process_group()
 """
 
 
-@pytest.mark.parametrize("world,games,port", [(2, 6, "29533"), (8, 3, "29541")], ids=["2_ranks", "8_ranks"])
-def test_sharded_generation_matches_single_trainer(tmp_path, world, games, port):
+def _free_port():
+    """a port nobody holds right now (two test runs on one host must not meet on a fixed one: ADVICE round 5)"""
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return str(port)
+
+
+@pytest.mark.parametrize("world,games", [(2, 6), (8, 3)], ids=["2_ranks", "8_ranks"])
+def test_sharded_generation_matches_single_trainer(tmp_path, world, games):
+    port = _free_port()
     out = str(tmp_path / "gathered.npz")
     script = tmp_path / "worker.py"
     script.write_text(WORKER % {"root": ROOT, "out": out, "games": games})
@@ -85,7 +97,7 @@ def test_bench_gpus_2_launches_two_ranks_itself():
     over gloo: the rehearsal of the RCCL path on the GPU-less machine)"""
     import json
 
-    r = _bench(["--gpus", "2"] + TINY)
+    r = _bench(["--gpus", "2", "--check-gather"] + TINY)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, r.stdout
@@ -95,6 +107,9 @@ def test_bench_gpus_2_launches_two_ranks_itself():
     assert d["world_size"] == 2 and d["ranks_seen"] == 2 and len(d["per_rank_games_per_s"]) == 2
     c = d["collectives_per_step"]
     assert c["samples_gathered"] == c["samples_of_all_shards"] > 0 and c["unfinished_games"] == 0
+    # every rank found its own export_samples() bytes at its place in what the gather returned
+    k = c["gather_check"]
+    assert k["bytes_equal_to_export_samples"] and k["ranks_with_a_difference"] == 0 and k["rows_gathered"] > k["rows_own"] > 0
     assert abs(out["value"] - 12 / (out["ms_per_step"] * 1e-3)) < 1e-6 * out["value"]
     # one rank: unchanged single-process path
     r1 = _bench(["--gpus", "1"] + TINY)
