@@ -112,6 +112,13 @@ def parse():
     ap.add_argument("--no-eval-cache", action="store_true",
                     help="evaluate every request row (the engine's evaluation cache off); the default run reports this as the "
                          "`no_eval_cache` variant")
+    ap.add_argument("--trained", action="store_true",
+                    help="the mlp12x100 kinds search with the reference's last checkpoint (tests/golden/trained_last.npz) instead of "
+                         "random-init weights: the narrow, deep trees of every generation after the first (profiling runs)")
+    ap.add_argument("--no-trained", action="store_true",
+                    help="skip detail.trained_checkpoint (the reference's last checkpoint through the same workload)")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip detail.configs (one generation of each other BASELINE configuration: cfg1, cfg4, cfg5, tournament, compat)")
     ap.add_argument("--check-gather", action="store_true",
                     help="with a process group (N > 1, or CORINTHO_FORCE_DIST=1 at N = 1): behind the timed region every rank compares "
                          "its block of one more gathered generation with its own export_samples() byte for byte "
@@ -391,6 +398,8 @@ def main():
         from corintho_ai_amd.tflite_import import mlp12x100_from_tflite
 
         weights_by_arch["mlp12x100"] = mlp12x100_from_tflite(args.tflite)
+    if args.trained:
+        weights_by_arch["mlp12x100"] = np.load(os.path.join(ROOT, "tests", "golden", "trained_last.npz"))["weights"]
     flop_by_arch = {"rescnn4": nets.rescnn4_flop_per_row(), "mlp12x100": MLP_FLOP}
 
     def make_trainer(pools, games=None, resident=-1, eval_cache=None):
@@ -424,10 +433,10 @@ def main():
             if not emu:
                 torch.cuda.synchronize()
 
-    def run_generations(trainer, net, steps, warmup, seed0, collective):
+    def run_generations(trainer, net, steps, warmup, seed0, collective, weights=None):
         """`warmup` untimed + `steps` timed generations of `net`; -> (seconds, totals)"""
         kind_name, arch = NETS[net][0], NETS[net][1]
-        trainer.set_net(getattr(CA, kind_name), weights_by_arch[arch])
+        trainer.set_net(getattr(CA, kind_name), weights_by_arch[arch] if weights is None else weights)
         totals = dict.fromkeys(STAT_KEYS, 0)
         totals.update(gather_ms=0.0, samples=0, peak_arena_units=0, pools=1, gather_bytes=0, score=0.0, unfinished=0,
                       gathered_samples=0)
@@ -590,9 +599,11 @@ def main():
             "dtype": dtype,
             "data": "synthetic",
             "config": {
-                "workload": "%d parallel self-play games per GPU, %d sims/move, %d searches/eval, %s (random init, seed 0), "
+                "workload": "%d parallel self-play games per GPU, %d sims/move, %d searches/eval, %s (%s), "
                             "fused on-device search + inference, %d pool(s) per GPU, %s"
-                            % (G, args.sims, args.spe, args.net, npools, "staggered start" if args.stagger else "no stagger"),
+                            % (G, args.sims, args.spe, args.net,
+                               "the reference's last checkpoint" if args.trained and "mlp" in args.net else "random init, seed 0", npools,
+                               "staggered start" if args.stagger else "no stagger"),
                 "games_per_gpu": G, "sims_per_move": args.sims, "searches_per_eval": args.spe, "net": args.net,
                 "arithmetic": ARITHMETIC[dtype],
                 "c_puct": args.c_puct, "epsilon": args.epsilon, "parallelism": "games sharded x%d" % world,
@@ -681,6 +692,31 @@ def main():
                 "iterations_per_step": t2["iterations"] / rsteps,
                 "note": "same workload per game; %d games per generation on %d slots" % (args.recycle_games, G)}
             del tr2
+        trained_path = os.path.join(ROOT, "tests", "golden", "trained_last.npz")
+        if world == 1 and not args.no_trained and not emu and os.path.exists(trained_path):
+            # The regime every generation after the first lives in (main.pyx:285-322): the search guided by a TRAINED
+            # network -- narrow, deep trees, in late plies every second simulation terminal.  The reference's own
+            # architecture with the reference's last checkpoint (rating/tflite_models, imported once by
+            # tools/gen_trained_golden.py and committed as data), same 4096 x 400 workload, f16x3 arithmetic.
+            wt = np.load(trained_path)["weights"]
+            nt = min(5, args.steps)
+            dtc, ttc = run_generations(tr, "mlp12x100h3", nt, 1, 15000, False, weights=wt)
+            rt_dom, rt_both = rooflines_of("mlp12x100h3", ttc, int(ttc.get("pools", 1)), wall_s=dtc)
+            out["detail"]["trained_checkpoint"] = {
+                "net": "mlp12x100h3", "weights": "tests/golden/trained_last.npz (the reference's last TFLite checkpoint)",
+                "games_per_s": G * nt / dtc, "ms_per_step": dtc * 1e3 / nt, "steps": nt, "warmup": 1,
+                "plies_per_game": ttc["plies"] / max(G * nt, 1), "evals_per_game": ttc["evals"] / max(G * nt, 1),
+                "sims_per_s": ttc["searches"] / dtc, "iterations_per_step": ttc["iterations"] / nt,
+                "device_ms_per_step": {"mcts": ttc["mcts_ms"] / nt, "network": ttc["nn_ms"] / nt},
+                "roofline": rt_dom, "roofline_search": rt_both["search"], "roofline_network": rt_both["network"]}
+        if world == 1 and not args.no_configs and not emu and (G, args.sims, args.spe) == (4096, 400, 16):
+            # BASELINE.json's other configurations, one generation each on the final tree (tools/run_configs.py), each with
+            # its roofline objects: cfg1 (64 x 50), cfg4 (4096 x 1600 + Dirichlet noise: toml/train.toml:2-18), cfg5 (arena,
+            # main.pyx:329-349), a tournament, and the host-driven reference protocol (PCIe-inclusive, never `value`)
+            tr.close()  # cfg4's trees take 118 GB: give the default pool's memory back first
+            from tools import run_configs as RC
+
+            out["detail"]["configs"] = RC.measure_all(device=local_rank)
         # the numbers a reader compares `value` with, in one place (each is measured above, same workload)
         d = out["detail"]
         out["detail"]["summary"] = {
@@ -691,6 +727,8 @@ def main():
             "reference_network_mlp12x100h3_games_per_s": d.get("variants", {}).get("mlp12x100h3", {}).get("games_per_s"),
             "recycled_games_per_s": d.get("recycled", {}).get("games_per_s"),
             "two_pools_games_per_s": d.get("two_pools", {}).get("games_per_s"),
+            "trained_checkpoint_mlp12x100h3_games_per_s": d.get("trained_checkpoint", {}).get("games_per_s"),
+            "configs_games_per_s": {k: v.get("games_per_s", v.get("matches_per_s")) for k, v in d.get("configs", {}).items()},
         }
         if world == 1 and args.cpu_games > 0:
             out["cpu_baseline"] = cpu_baseline(args, arch, weights_by_arch, out["detail"]["evals_per_game"])

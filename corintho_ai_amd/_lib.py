@@ -38,6 +38,7 @@ class CaConfig(C.Structure):
         ("analyse", C.c_int32),
         ("resident", C.c_int32),
         ("eval_cache", C.c_int32),
+        ("step_budget", C.c_int32),
     ]
 
 
@@ -62,6 +63,8 @@ class CaStats(C.Structure):
         ("nn_timed_ms", C.c_double),
         ("resident_slots", C.c_int64),
         ("nn_rows_evaluated", C.c_int64),
+        ("steps_cut", C.c_int64),
+        ("step_budget_last", C.c_int64),
     ]
 
 

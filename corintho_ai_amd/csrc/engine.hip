@@ -145,7 +145,7 @@ struct ca_trainer {
   bool logs_written = false;
   DevBuf<float> req, nn_in, nn_in70, nn_eval, nn_probs, samples;
   DevBuf<int32_t> row_idx;
-  DevBuf<unsigned long long> row_counter, pack_counter, prof, next_game;
+  DevBuf<unsigned long long> row_counter, pack_counter, work_counter, prof, next_game;
   DevBuf<GameCtl> results;   /* [G] finished games by index (recycling pools) */
   DevBuf<uint32_t> seeds_dev; /* [G] per-game generator seeds (recycling pools) */
   DevBuf<int32_t> ctl;
@@ -171,6 +171,7 @@ struct ca_trainer {
   double mcts_timed_ms = 0, nn_timed_ms = 0, pack_timed_ms = 0;
   int64_t timed_launches = 0, nn_timed_rows = 0;
   int64_t nn_rows_evaluated = 0; /* rows the network kernels worked on (= nn_rows without the evaluation cache) */
+  int64_t steps_cut = 0, step_budget_last = 0; /* ca_config.step_budget: steps of the last run that stopped at their budget; the last budget */
   bool cache_clean = false;      /* the pools' tables hold nothing of an earlier generation */
   int64_t cache_clears = 0;
   /* the evaluation cache serves fused training (and fused analysis): one network, rows packed by the search kernel */
@@ -329,6 +330,7 @@ struct ca_trainer {
     all_done.alloc(1, stream);
     row_counter.alloc(1, stream);
     pack_counter.alloc(2 * CO_MAX_POOLS, stream);
+    work_counter.alloc((size_t)CO_WC_WORDS * CO_MAX_POOLS, stream);
     arena_state.alloc(8, stream);
     if (tourney) {
       pcfg.alloc(host_pcfg.size(), stream);
@@ -403,6 +405,7 @@ struct ca_trainer {
     rt_h2d(next_game.p, &first_unstarted, 8, stream);
     rt_memset(row_counter.p, 0, 8, stream);
     rt_memset(pack_counter.p, 0, 16 * CO_MAX_POOLS, stream);
+    rt_memset(work_counter.p, 0, (size_t)8 * CO_WC_WORDS * CO_MAX_POOLS, stream);
     rt_memset(arena_state.p, 0, 32, stream);
     rt_sync(stream);
     iterations = 0;
@@ -545,6 +548,11 @@ struct ca_trainer {
     P.row_counter = nullptr; /* counted in fused mode only */
     P.fused_pack = 0;
     P.defer_handover = 0;
+    /* ca_config.step_budget: n > 0 that many scans, 0 automatic (CO_STEP_BUDGET_K16 / 16 x the pool's mean), -1 none;
+     * below -1 (diagnostic): automatic with the factor -n / 16 */
+    P.step_budget = cfg.step_budget > 0 ? cfg.step_budget : 0;
+    P.step_budget_k16 = cfg.step_budget == 0 ? CO_STEP_BUDGET_K16 : cfg.step_budget < -1 ? -cfg.step_budget : 0;
+    P.work_counter = nullptr; /* a pool's own, set by run_pools */
     P.pool_lo = 0;
     P.pool_n = R;
     P.pool_row_base = 0;
@@ -1121,7 +1129,10 @@ struct ca_trainer {
         /* main.pyx:161-163 raises when NO game has a request.  A pool whose first game the
          * staggered start (trainer.cpp:184-186) has not released yet has running games and no
          * rows by construction: that is not the reference's error condition */
-        if (q.word_iter[parity] > q.first_start && ++q.idle > 16) failure = "No requests during training";
+        /* (64 polls in a row: with a step budget a pool's last games may pass a few iterations submitting nothing --
+         * a step that stopped at its budget holds its leaves back -- but every such step runs simulations of a move's
+         * bounded number) */
+        if (q.word_iter[parity] > q.first_start && ++q.idle > 64) failure = "No requests during training";
       } else {
         q.idle = 0;
       }
@@ -1168,6 +1179,7 @@ struct ca_trainer {
         pp.pool_n = q.n;
         pp.pool_row_base = q.row_base;
         pp.pack_counter = pack_counter.p + 2 * p;
+        pp.work_counter = work_counter.p + (size_t)CO_WC_WORDS * p;
         pp.cache = q.cache; /* (hdr null: no cache) */
         pp.cache.no_claim = emptied ? 1u : 0u;
         if (emptied) guard_from = trainer_iteration;
@@ -1282,6 +1294,15 @@ struct ca_trainer {
         rt_sync(q.st);
         nn_rows_evaluated += (int64_t)tot[0] + cnt[0] + cnt[4];
       }
+    }
+    {
+      /* step budget: [7] of a pool's words counts the steps that were cut, [3], [4] hold the last two budgets */
+      std::vector<unsigned long long> wc((size_t)CO_WC_WORDS * CO_MAX_POOLS);
+      rt_d2h(wc.data(), work_counter.p, wc.size() * 8, stream);
+      rt_sync(stream);
+      steps_cut = 0;
+      for (size_t p = 0; p < pools.size(); ++p) steps_cut += (int64_t)wc[CO_WC_WORDS * p + CO_WC_CUTS];
+      step_budget_last = P.step_budget > 0 ? P.step_budget : (int64_t)std::max(wc[CO_WC_BUDGET], wc[CO_WC_BUDGET + 1]);
     }
     if (timed_launches > 0) pack_ms = pack_timed_ms * (double)nn_launches / (double)timed_launches;
     return finished;
@@ -1832,6 +1853,8 @@ extern "C" int ca_trainer_stats(ca_trainer *t, ca_stats *out) {
     out->pools = t->pools.empty() ? 1 : (int64_t)t->pools.size();
     out->resident_slots = t->R;
     out->nn_rows_evaluated = t->nn_rows_evaluated;
+    out->steps_cut = t->steps_cut;
+    out->step_budget_last = t->step_budget_last;
     out->timed_launches = t->timed_launches;
     out->nn_timed_rows = t->nn_timed_rows;
     out->mcts_timed_ms = t->mcts_timed_ms;

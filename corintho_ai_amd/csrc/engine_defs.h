@@ -62,6 +62,21 @@
 #define CO_ERR_INTERNAL 8
 #define CO_ERR_STUCK 16
 
+/* ca_config.step_budget = 0: the number of PUCT scans after which a game's step of fused training stops selecting and
+ * carries on in the next launch follows the pool's mean (EngineParams::step_budget_k16; measured: DESIGN section 6
+ * "K3, round 6") */
+#ifndef CO_STEP_BUDGET_K16
+#define CO_STEP_BUDGET_K16 28 /* automatic: 1.75 x the mean of the launch before */
+#endif
+#define CO_STEP_BUDGET_MIN 24
+/* A pool's words of EngineParams::work_counter, 64 per pool.  The words every wavefront READS (the budget) lie in another
+ * 128-byte line than the ones every wavefront adds to with device-scope atomics: in one line with them (and with the next
+ * pool's) the read cost 15 % of a generation -- 152 against 132 ms with a budget no step reaches (round 6). */
+#define CO_WC_WORDS 64
+#define CO_WC_BUDGET 16 /* [2] by launch parity */
+#define CO_WC_MEAN 18   /* [2] the smoothed mean, in 1/256 scans */
+#define CO_WC_CUTS 32   /* steps cut (ca_stats.steps_cut) */
+
 struct GameCtl {
   int32_t to_play;    /* SelfPlayer::to_play_ */
   int32_t done;       /* Trainer::is_done_[i] */
@@ -87,6 +102,12 @@ struct GameCtl {
   /* the search's hint to itself (mcts.h co_mc_do_iteration): running share, in 1/256, of this game's recent simulations that
    * ended in a terminal leaf or a dead end; decides how many simulations are selected together.  Results do not depend on it. */
   int32_t sb_cap;
+  /* Fused training, EngineParams::step_budget: the step before this one ran out of its budget of scans and stopped with
+   * fewer than searches_per_eval leaves queued -- none of them was submitted, no evaluation is on its way; this step
+   * goes on selecting where that one stopped (mcts.h co_mc_do_iteration).  noise_held = generator outputs owed to the
+   * leaves queued so far (CoWave::noise_words, carried over).  The game's own sequence of operations is unchanged. */
+  int32_t held;       /* bit 0: as described; bit 1 (within a step only): this step continues one that was cut */
+  int32_t noise_held;
 };
 
 /* one side of a tournament match: Player, match.h:13-31 */
@@ -218,6 +239,20 @@ struct EngineParams {
    * cleared for the next iteration.  The network kernels read the low word. */
   int32_t fused_pack;
   int32_t defer_handover; /* fused mode: end a game's step at the hand-over (see mcts.h co_choose_move_and_continue) */
+  /* fused training: a game's step stops selecting after this many PUCT scans and carries on in the next launch, its
+   * queued leaves held back until there are searches_per_eval of them (or the searches run out) -- a launch lasts as long
+   * as its slowest wavefront, and the slowest are steps of 25-30 simulations ten levels deep (half of them ending in
+   * terminal leaves, which queue nothing).  0 = no limit.  Per-game results do not depend on it. */
+  int32_t step_budget;
+  /* step_budget_k16 > 0 (and step_budget == 0): the budget follows the games -- k16 / 16 times the mean number of scans
+   * the pool's stepping games made in the launch before this one (early plies: wide shallow trees, a step is ~35 scans;
+   * endgames under a trained network: ~70).  work_counter[CO_WC_WORDS] per pool: [0..2] by iteration mod 3, (steps << 32) |
+   * scans of the launch -- this launch adds to [iteration % 3], its first wavefront reads [(iteration - 1) % 3], writes the
+   * budget of the NEXT launch to [CO_WC_BUDGET + (iteration & 1)] and clears [(iteration + 1) % 3]; every wavefront reads
+   * its budget from [CO_WC_BUDGET + ((iteration + 1) & 1)], the word the launch before wrote (mcts.h
+   * co_pool_housekeeping); [CO_WC_MEAN ..]: the mean smoothed over ~8 launches, carried from launch to launch the same way. */
+  int32_t step_budget_k16;
+  unsigned long long *work_counter;
   /* fused training runs the games as independent pools on separate streams, so that one pool's
    * search overlaps another pool's network kernel: this launch covers games [pool_lo, pool_lo +
    * pool_n) and its batch rows start at row pool_row_base of nn_in / nn_eval / nn_probs */

@@ -87,7 +87,10 @@ struct CoWave {
   const float *cval;    /* evaluation cache: outputs live in cval[csrc[k] * CO_CACHE_VAL_FLOATS] for pending leaf k; null = in place */
   const int32_t *csrc;
   uint32_t *noise_raw;
-  int noise_words; /* generator outputs owed to the leaves queued so far in this step */
+  int noise_words; /* generator outputs owed to the leaves queued so far (in this step, and in the steps before it that were
+                    * cut short with their leaves held back: GameCtl::held) */
+  int work; /* PUCT scans of this step so far MINUS its budget (co_step_budget): the step stops selecting when this reaches zero
+             * (one live scalar instead of two: with the budget kept beside the count the kernel spills 170 more SGPRs) */
   /* the records of up to CO_PRE pending leaves, in the wavefront's LDS: pre[f * CO_PRE + k] = field f (CO_PRE_*) of leaf
    * pre_c0 + k, k < pre_n.  Requested with the game's other first loads (co_mcts_step_wave) -- in registers until
    * co_receive_eval they cost 44 spilled registers in the search -- and read by co_receive_eval */
@@ -742,6 +745,8 @@ CO_DEV double co_div_small(double x, float df) { return co_div_with(x, df, co_re
 struct CoRoot {
   uint4 h0, h1, cs;
   int valid;
+  int hdr;        /* h0, h1, e0, ne are the root's (they do not change while a step searches): a dropped copy is made good
+                   * again by ONE trip to memory -- own slot and edge slots together -- instead of two dependent ones */
   uint4 *ev;      /* LDS: edge slots 0..63 of the root */
   uint32_t e0;    /* unit offset of the root's edge slot 0 */
   uint32_t ne;    /* edge slots held: min(edges, 64) */
@@ -753,12 +758,15 @@ struct CoRoot {
 CO_DEV float co_vsqrt(float c_puct, int visits) { return (float)((double)c_puct * co_sqrt_f64((double)(float)visits)); }
 
 CO_DEV void co_root_load(CoTree &t, CoRoot &rc) {
-  rc.h0 = co_load_unit(t.A, t.tc.root);
-  rc.h1 = co_load_unit(t.A, t.tc.root + 1);
+  if (!rc.hdr) {
+    rc.h0 = co_load_unit(t.A, t.tc.root);
+    rc.h1 = co_load_unit(t.A, t.tc.root + 1);
+    rc.e0 = t.tc.root + 2u;
+    uint32_t n = CO_META_NEDGES(rc.h0.z);
+    rc.ne = n < (uint32_t)CO_WAVE ? n : (uint32_t)CO_WAVE;
+    rc.hdr = 1;
+  }
   rc.cs = co_load_unit(t.A, rc.h1.x);
-  rc.e0 = t.tc.root + 2u;
-  uint32_t n = CO_META_NEDGES(rc.h0.z);
-  rc.ne = n < (uint32_t)CO_WAVE ? n : (uint32_t)CO_WAVE;
   const uint4 *A = t.A;
   FOR_LANES { rc.ev[lane] = A[rc.e0 + lane]; } /* arena is padded: lanes >= n read unused units */
   WAVE_SYNC();
@@ -790,6 +798,8 @@ CO_DEV float co_puct_u(uint4 s, float denom, float v_sqrt) {
   int searchable = ((r == CO_RESULT_NONE) | drawn) & !((s.w >> 8) & 1u);
   int vis = co_slot_visits(s);
   float cv = (float)(vis > 0 ? vis : 1); /* 1 .. 32767 */
+  /* (Measured in round 6: with both quotients as single-precision products with v_rcp_f32 -- NOT the reference's bits; the
+   * ceiling of any scheme that scans approximately and verifies -- a generation is 1-2.6 % shorter: not what a scan costs.) */
   double a = co_div_small(-(double)co_u2f(s.y), cv);
   double b = co_div_small((double)pv, cv + 1.0f);
   float uv = (float)(a + b);
@@ -832,11 +842,12 @@ CO_COLD2 void co_search(CoWave &w, CoTree &t, CoRoot &rc) {
   }
   WAVE_SYNC();
   CO_PH_MEM(19);
+  float v_sqrt_next = co_vsqrt(w.c_puct, co_slot_visits(cs));
   while (!co_res_terminal(co_slot_result(cs))) {
     int n = (int)CO_META_NEDGES(h0.z);
     float denom = co_u2f(h1.y);
     int visits = co_slot_visits(cs);
-    const float v_sqrt = co_vsqrt(w.c_puct, visits);
+    const float v_sqrt = v_sqrt_next;
     /* ---- chooseNext: u for every edge, strict first maximum */
     float best_u = CO_NEG_INF;
     int best_e = -1;
@@ -863,6 +874,7 @@ CO_COLD2 void co_search(CoWave &w, CoTree &t, CoRoot &rc) {
     }
     CO_PH(8);
     CO_PROF_ADD(w, 23, 1ull);
+    ++w.work;
     /* ---- visit the current node (virtual loss on every node of the path) */
     cs = co_slot_set_visits(cs, visits + 1);
     cs.y = co_f2u(co_u2f(cs.y) + 1.0f);
@@ -934,6 +946,8 @@ CO_COLD2 void co_search(CoWave &w, CoTree &t, CoRoot &rc) {
     h0 = co_load_unit(A, cur);
     h1 = co_load_unit(A, cur + 1);
     FOR_LANES { L(ev) = A[cur + 2 + lane]; }
+    v_sqrt_next = co_vsqrt(w.c_puct, co_slot_visits(cs)); /* under the fetch (see co_search_rows) */
+    CO_OPAQUE_V(v_sqrt_next);
     CO_PH_MEM(11);
     ++D;
     FOR_LANES {
@@ -1092,6 +1106,7 @@ CO_DEV int co_search_rows(CoWave &w, CoTree &t, CoRoot &rc, int m) {
       for (int j = 0; j < msel; ++j) {
         CO_SBS(10, 1);
         CO_PROF_ADD(w, 23, 1ull);
+        ++w.work;
         const float v_sqrt = WAVE_BCAST(vsl, j);
         LV(float, u);
         FOR_LANES_HOT {
@@ -1248,6 +1263,15 @@ CO_DEV int co_search_rows(CoWave &w, CoTree &t, CoRoot &rc, int m) {
           const uint32_t e0 = wx[i] + 2u;
           FOR_LANES_HOT { L(we[i]) = A[e0 + lane]; }
         }
+        /* the exploration factors (a double-precision square root each: ~20 dependent instructions) depend on the rows'
+         * own slots only: computed HERE, while the blocks are on their way -- left to the compiler they stand behind the
+         * first use of the headers (the wide-node test), i.e. behind the wait */
+        float wvs[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          wvs[i] = co_vsqrt(w.c_puct, co_slot_visits(wc[i]));
+          CO_OPAQUE_V(wvs[i]);
+        }
         CO_PH_MEM(11);
         uint32_t pX = CO_NONE;
         int pe = -1;
@@ -1258,6 +1282,7 @@ CO_DEV int co_search_rows(CoWave &w, CoTree &t, CoRoot &rc, int m) {
           if (r < 0 || r >= bad) continue;
           CO_SBS(10, 1);
           CO_PROF_ADD(w, 23, 1ull);
+          ++w.work;
           const int n = (int)CO_META_NEDGES(wh[i].z);
           int gone = 0; /* the row's simulation is not ordinary */
           int le = 0;
@@ -1267,7 +1292,7 @@ CO_DEV int co_search_rows(CoWave &w, CoTree &t, CoRoot &rc, int m) {
             gone = 1;
           } else {
             const float denom = co_u2f(wd[i]);
-            const float v_sqrt = co_vsqrt(w.c_puct, co_slot_visits(wc[i]));
+            const float v_sqrt = wvs[i];
             LV(float, u);
             FOR_LANES_HOT {
               uint4 sl = L(we[i]);
@@ -1366,6 +1391,11 @@ CO_DEV int co_search_rows(CoWave &w, CoTree &t, CoRoot &rc, int m) {
         L(e3) = A[c + 48u];
       }
     }
+    LV(float, vs); /* (a row's exploration factor is its node's: once per level, under the fetch -- not once per turn) */
+    FOR_LANES_HOT {
+      L(vs) = co_vsqrt(w.c_puct, co_slot_visits(L(cs)));
+      CO_OPAQUE_V(L(vs));
+    }
     CO_PH_MEM(11);
     LV(int, todo);
     LV(int, wide);
@@ -1392,6 +1422,7 @@ CO_DEV int co_search_rows(CoWave &w, CoTree &t, CoRoot &rc, int m) {
       const uint64_t tm = WAVE_BALLOT(todo);
       if (!tm) break;
       CO_SBS(24, 1);
+      w.work += 2; /* (a turn in row form: the instructions of two to three wave-wide scans) */
       /* a row waits while an earlier row of the same node has yet to scan it */
       const uint32_t x0 = WAVE_BCAST(X, 0), x1 = WAVE_BCAST(X, 16), x2 = WAVE_BCAST(X, 32);
       const int t0 = (int)(tm & 1ull), t1 = (int)((tm >> 16) & 1ull), t2 = (int)((tm >> 32) & 1ull);
@@ -1402,7 +1433,6 @@ CO_DEV int co_search_rows(CoWave &w, CoTree &t, CoRoot &rc, int m) {
       LV(uint32_t, by);
       LV(uint32_t, bz);
       LV(uint32_t, bw);
-      LV(float, vs);
       FOR_LANES_HOT {
         const int r = lane >> 4;
         const int blocked = (r > 0 && t0 && x0 == L(X)) || (r > 1 && t1 && x1 == L(X)) || (r > 2 && t2 && x2 == L(X));
@@ -1410,7 +1440,6 @@ CO_DEV int co_search_rows(CoWave &w, CoTree &t, CoRoot &rc, int m) {
         L(bu) = CO_NEG_INF;
         L(be) = 255u;
         L(bx) = L(by) = L(bz) = L(bw) = 0u;
-        L(vs) = co_vsqrt(w.c_puct, co_slot_visits(L(cs)));
         if (L(ready)) {
           CO_SBS(10, (lane & 15) == 0);
           CO_PROF_ADD(w, 23, 0ull);
@@ -1840,10 +1869,13 @@ CO_DEV int co_mc_do_iteration(CoWave &w, CoTree &t, const float *eval, const flo
       return 0;
     }
   }
-  if (w.gc.n_pending > 0) co_receive_eval(w, t, eval, probs);
+  /* (held: the step before stopped at its budget; its leaves were not submitted -- nothing to receive, the search goes on) */
+  if (w.gc.n_pending > 0 && !(w.gc.held & 1)) co_receive_eval(w, t, eval, probs);
+  w.gc.held = (w.gc.held & 2) | ((w.gc.held & 1) << 1); /* bit 1: this step continues one that was cut (co_step_tail's statistics) */
   WAVE_SHARED(uint4, root_ev, CO_WAVE);
   CoRoot rc;
   rc.valid = 0;
+  rc.hdr = 0;
   rc.ev = root_ev;
   rc.e0 = 0u;
   rc.ne = 0u;
@@ -1860,6 +1892,12 @@ CO_DEV int co_mc_do_iteration(CoWave &w, CoTree &t, const float *eval, const flo
 
     if (co_res_known(co_slot_result(rc.cs)) || co_slot_all_visited(rc.cs)) break;
     if (w.gc.error) break;
+    if (w.work >= 0) {
+      /* more simulations are due and this step has done its share: the next launch continues here (co_step_tail holds
+       * the queued leaves back).  Everything the loop carries is in the tree, in the game's record or in `pe`. */
+      w.gc.held |= 1;
+      break;
+    }
     CO_PH_MEM(20);
 #if CO_SB > 1
     int counted = 0;
@@ -1895,7 +1933,7 @@ CO_DEV int co_mc_do_iteration(CoWave &w, CoTree &t, const float *eval, const flo
   w.gc.sb_cap = pe > 0 ? pe : 0;
 #endif
   /* (the root's slot only when the answer depends on it: with leaves pending -- nearly every step -- it does not) */
-  if (w.gc.n_pending != 0) return 0;
+  if (w.gc.n_pending != 0 || (w.gc.held & 1)) return 0;
   if (t.tc.searches_done == w.max_searches) return 1;
   const uint4 rs = co_load_unit(t.A, co_load_unit(t.A, t.tc.root + 1).x);
   return co_res_known(co_slot_result(rs));
@@ -2316,6 +2354,7 @@ CO_DEV int co_game_step(CoWave &w, const float *eval, const float *probs) {
     w.gc.resume = 0;
     ev = pr = (const float *)0;
   }
+  if (w.gc.held & 1) ev = pr = (const float *)0; /* continuation of a step cut at its budget: nothing was submitted */
   int skip_iteration = (w.pc && w.pc[w.gc.to_play].random) /* match.cpp:68-70 */ || w.force_choose;
   int fresh_root = 0;
   for (;;) {
@@ -2590,6 +2629,32 @@ CO_DEV void co_pool_housekeeping(const EngineParams &P, int g) {
     FOR_LANES {
       if (lane == 0) {
         P.pack_counter[(P.iteration + 1) & 1] = 0ull;
+        if (P.work_counter) {
+          /* step budget that follows the games (EngineParams::step_budget_k16): this launch's first wavefront turns the
+           * scans of the launch before (complete: a kernel boundary lies between) into the budget of the launch after --
+           * the division is this one wavefront's, every other one reads a finished word */
+          const unsigned long long wc = P.work_counter[(P.iteration + 2) % 3];
+          const uint32_t steps = (uint32_t)(wc >> 32), scans = (uint32_t)wc;
+          /* the mean, smoothed over ~8 launches (in 1/256 scans; [5 + parity] carries it from launch to launch): the games
+           * of a generation that started together also choose their moves together, and a launch of first steps on
+           * fresh roots (16 scans) says nothing about the launch two later */
+          unsigned long long sm = P.work_counter[CO_WC_MEAN + ((P.iteration + 1) & 1)];
+          if (steps > 0u) {
+            const unsigned long long inst = ((unsigned long long)scans << 8) / steps;
+            sm = sm ? (7ull * sm + inst) >> 3 : inst;
+          }
+          uint32_t b = 0u; /* (no limit) */
+          if (sm > 0ull && P.step_budget_k16 > 0) {
+            b = (uint32_t)((sm * (uint32_t)P.step_budget_k16) >> 12);
+            if (b < CO_STEP_BUDGET_MIN) b = CO_STEP_BUDGET_MIN;
+          }
+#if defined(CO_EMU) && defined(CO_DEBUG_BUDGET)
+          fprintf(stderr, "it %d steps %u scans %u mean %.1f -> budget %u\n", P.iteration, steps, scans, (double)sm / 256.0, b);
+#endif
+          P.work_counter[CO_WC_MEAN + (P.iteration & 1)] = sm;
+          P.work_counter[CO_WC_BUDGET + (P.iteration & 1)] = (unsigned long long)b;
+          P.work_counter[(P.iteration + 1) % 3] = 0ull;
+        }
         if (P.cache.hdr) {
           /* the other parity's counter of rows to evaluate was the previous iteration's (its network launch is
            * over): book it, clear it for the next iteration */
@@ -2603,6 +2668,17 @@ CO_DEV void co_pool_housekeeping(const EngineParams &P, int g) {
       }
     }
   }
+}
+
+/* The scans a game's step may make in this launch before it stops selecting (EngineParams::step_budget), fused training
+ * only.  Automatic: what the first wavefront of the launch before this one made of the launch before that
+ * (co_pool_housekeeping).  No limit = a number no step reaches. */
+#define CO_STEP_BUDGET_NONE (1 << 28)
+CO_DEV int co_step_budget(const EngineParams &P) {
+  if (!(P.fused_pack && !P.testing && !P.analyse && !P.pcfg)) return CO_STEP_BUDGET_NONE;
+  int b = P.step_budget;
+  if (P.step_budget == 0 && P.step_budget_k16 > 0 && P.work_counter) b = (int)(uint32_t)P.work_counter[CO_WC_BUDGET + ((P.iteration + 1) & 1)];
+  return b > 0 ? b : CO_STEP_BUDGET_NONE;
 }
 
 /* the wavefront's view of game slot g.  (Fields a kernel never touches cost nothing: they are never loaded.) */
@@ -2626,7 +2702,8 @@ CO_DEV void co_wave_init(const EngineParams &P, int g, const GameCtl &gc, const 
   w.pend_n = P.pend_n + (size_t)g * P.searches_per_eval * 4;
   w.pend_key = P.cache.hdr ? P.pend_key + (size_t)g * P.searches_per_eval : (uint4 *)0;
   w.noise_raw = P.noise_raw + (size_t)g * P.searches_per_eval * CO_NUM_MOVES;
-  w.noise_words = 0; /* a step consumes every pending leaf before it queues new ones */
+  w.noise_words = (gc.held & 1) ? gc.noise_held : 0; /* a step consumes every pending leaf before it queues new ones -- unless they were held back */
+  w.work = -co_step_budget(P);
   w.req = P.req + (size_t)g * P.searches_per_eval * CO_STATE_STRIDE;
   /* samples and traces belong to the GAME, not to the slot */
   w.samples = P.samples ? P.samples + (size_t)gc.gid * CO_MAX_PLIES * CO_SAMPLE_FLOATS : (float *)0;
@@ -2682,6 +2759,8 @@ CO_COLD int co_slot_next_game(const EngineParams &P, CoWave &w) {
   fresh.row_off = 0; fresh.resume = 0; fresh.pos_lo = 0u; fresh.pos_hi = 0u; fresh.pos_meta = CO_META_START;
   fresh.gid = gid;
   fresh.sb_cap = 0;
+  fresh.held = 0;
+  fresh.noise_held = 0;
   w.gc = fresh;
   w.me.tc.root = CO_NONE; w.me.tc.searches_done = 0; w.me.tc.units_used = 0u;   /* peak_units: high-water of the slot */
   w.opp.tc.root = CO_NONE; w.opp.tc.searches_done = 0; w.opp.tc.units_used = 0u;
@@ -2701,6 +2780,21 @@ CO_DEV void co_step_tail(const EngineParams &P, CoWave &w, int g, int done) {
   const int packs = P.fused_pack && !w.gc.done && !w.gc.error;
   unsigned long long old = 0ull;
   CO_PH_MEM(25);
+  if (packs && P.work_counter) {
+    const int scans = w.work + co_step_budget(P); /* (the budget once more, from where it lies: not kept across the step) */
+    /* scans of the launch over the steps BEGUN in it: the pieces of a step that was cut add their scans, not a step -- counted
+     * as steps of their own they pull the mean down, the budget follows, more steps are cut: it collapses to its floor */
+    if (scans > 0) co_atomic_add_u64_noret(P.work_counter + P.iteration % 3, ((w.gc.held & 2) ? 0ull : 1ull << 32) | (unsigned long long)scans);
+  }
+  w.gc.held &= 1;
+  if (packs && w.gc.held) {
+    /* the step stopped at its budget: the game is running and submits nothing; its leaves (request rows, records and keys
+     * are in place) wait for the rest of their batch, the generator outputs owed to them are reserved with the others' */
+    co_atomic_add_u64(P.pack_counter + (P.iteration & 1), 1ull << 32);
+    if (P.work_counter) co_atomic_add_u64_noret(P.work_counter + CO_WC_CUTS, 1ull); /* (ca_stats.steps_cut) */
+    w.gc.noise_held = w.noise_words;
+    return;
+  }
   if (packs) old = co_atomic_add_u64(P.pack_counter + (P.iteration & 1), (1ull << 32) | (unsigned long long)w.gc.n_pending);
   CO_PH_MEM(26);
   if (!done && !w.gc.error && w.gc.n_pending > 0) co_capture_noise(w);
@@ -2772,7 +2866,7 @@ CO_DEV void co_mcts_step_wave(const EngineParams &P, int g) {
   co_wave_init(P, g, gc, tc0, tc1, w);
   /* (in front of the generator's state: the counter of outstanding loads retires in order, and the step needs these first) */
   w.pre_n = 0;
-  if (w.gc.n_pending > 0) co_pending_records(w, 0, w.gc.n_pending < CO_PRE ? w.gc.n_pending : CO_PRE);
+  if (w.gc.n_pending > 0 && !(w.gc.held & 1)) co_pending_records(w, 0, w.gc.n_pending < CO_PRE ? w.gc.n_pending : CO_PRE);
   co_mt_stage_load(w.mt, w.mt_stage);
   w.mt_staged = 1;
   CO_PROF_ADD(w, 4, 1ull);

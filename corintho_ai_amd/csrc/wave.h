@@ -93,6 +93,7 @@ static inline double co_sqrt_f64(double x) { return sqrt(x); }
 static inline unsigned long long co_atomic_add_u64(unsigned long long *p, unsigned long long v) {
   return __atomic_fetch_add(p, v, __ATOMIC_RELAXED);
 }
+static inline void co_atomic_add_u64_noret(unsigned long long *p, unsigned long long v) { (void)__atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 /* 32-bit atomics of the evaluation cache (kernels.h): compare-and-swap returning the old value, add, and a load /
  * store that other workgroups' atomics are coherent with */
 static inline uint32_t co_atomic_cas_u32(uint32_t *p, uint32_t expected, uint32_t desired) {
@@ -331,6 +332,10 @@ __device__ __forceinline__ unsigned long long co_atomic_add_u64(unsigned long lo
   unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)old);
   unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(old >> 32));
   return ((unsigned long long)hi << 32) | lo;
+}
+/* the same, nobody waits for the old value */
+__device__ __forceinline__ void co_atomic_add_u64_noret(unsigned long long *p, unsigned long long v) {
+  if ((threadIdx.x & 63) == 0) (void)atomicAdd(p, v);
 }
 /* 32-bit device-scope atomics of the evaluation cache (kernels.h), one per wave (lane 0), result broadcast.  The
  * 8 XCDs of the chip have separate L2s: a header word another workgroup may be writing in the same launch is

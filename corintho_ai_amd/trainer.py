@@ -55,7 +55,7 @@ def _eval_cache_cfg(eval_cache):
 class Trainer:
     def __init__(self, num_games, log_folder="", seed=0, max_searches=1600, searches_per_eval=16, c_puct=1.0,
                  epsilon=0.25, num_logged=0, num_threads=1, testing=False, *, device=0, stagger=True, arena_units=0,
-                 trace=False, game_base=0, total_games=0, pools=0, analyse=False, resident=0, eval_cache=True, _cdll=None):
+                 trace=False, game_base=0, total_games=0, pools=0, analyse=False, resident=0, eval_cache=True, step_budget=0, _cdll=None):
         self._L = _cdll if _cdll is not None else _lib.load()
         self._t = C.c_void_p()
         cfg = _lib.CaConfig(num_games=num_games, seed=int(seed) & 0x7FFFFFFF if seed >= 0 else int(seed),
@@ -63,7 +63,7 @@ class Trainer:
                             epsilon=epsilon, num_logged=0, num_threads=num_threads, testing=int(bool(testing)),
                             device=device, no_stagger=int(not stagger), arena_units=arena_units, trace=int(bool(trace)),
                             game_base=game_base, total_games=total_games, pools=pools, analyse=int(bool(analyse)),
-                            resident=int(resident), eval_cache=_eval_cache_cfg(eval_cache))
+                            resident=int(resident), eval_cache=_eval_cache_cfg(eval_cache), step_budget=int(step_budget))
         self.num_games = num_games
         self.searches_per_eval = searches_per_eval
         self.testing = bool(testing)

@@ -293,3 +293,58 @@ def test_more_logged_games_than_resident_slots_is_an_error(engine, tmp_path):
         make_trainer(engine, 12, str(tmp_path), 3, 30, 8, 1.0, 0.25, 6, 1, False, stagger=False, resident=4)
     t = make_trainer(engine, 12, str(tmp_path), 3, 30, 8, 1.0, 0.25, 4, 1, False, stagger=False, resident=4)  # 4 on 4: fine
     t.close()
+
+
+# Step budget (ca_config.step_budget, round 6): a game's step stops selecting after so many PUCT scans and goes on in the
+# next iteration with its queued leaves held back until the batch is complete.  The game performs the reference's
+# sequence of operations spread over more iterations: everything per game equals the unlimited run -- and the oracle.
+@pytest.mark.parametrize("engine", ENGINES)
+def test_step_budget_changes_nothing_but_the_iterations(engine):
+    G, S_, spe, seed = 24, 60, 8, 31
+    w = nets.init_mlp12x100(seed=3, bn_noise=True)
+    runs = {}
+    for budget, R, pools, cache in ((-1, -1, 1, False), (1, -1, 1, False), (3, -1, 2, 18), (7, 7, 2, 6), (12, -1, 3, False), (40, -1, 1, 18),
+                                     (0, -1, 3, 18), (-17, -1, 2, False)):  # 0: automatic (the default); -17: automatic, 17/16 of the mean
+        t = make_trainer(engine, G, "", seed, S_, spe, 1.0, 0.25, 0, 1, False, stagger=False, trace=True, resident=R, pools=pools,
+                         eval_cache=cache, step_budget=budget)
+        t.set_net(1, w)
+        assert t.run()
+        st = t.stats()
+        runs[budget] = (_digest(t, G), [t.trace(g).tobytes() for g in range(G)], st)
+        # every leaf that was queued was submitted exactly once
+        assert st["nn_rows"] == st["evals"]
+        # a second generation in the same pool: nothing of a held step survives a reset
+        t.reset(seed)
+        assert t.run()
+        assert _digest(t, G) == runs[budget][0]
+        t.close()
+    ref = runs[-1]
+    for budget, (dig, traces, st) in runs.items():
+        assert dig == ref[0], budget
+        assert traces == ref[1], budget
+        assert st["searches"] == ref[2]["searches"] and st["evals"] == ref[2]["evals"], budget
+    # a budget of one scan cuts every step after its first simulation: many more iterations, the same games
+    assert runs[1][2]["iterations"] > 1.5 * ref[2]["iterations"]  # (a group of four simulations passes between two looks at the budget)
+    assert runs[40][2]["iterations"] >= ref[2]["iterations"]
+    # the automatic budget has a floor of 24 scans, which no step of this size reaches; steps of 16 simulations at 160 per
+    # move do: a budget just above the pool's mean is met by many of them
+    big = {}
+    for budget in (-1, -17, 0):
+        t = make_trainer(engine, 6, "", seed, 160, 16, 1.0, 0.25, 0, 1, False, stagger=False, trace=True, pools=1, step_budget=budget)
+        t.set_net(1, w)
+        assert t.run()
+        big[budget] = (_digest(t, 6), [t.trace(g).tobytes() for g in range(6)], t.stats()["iterations"])
+        t.close()
+    assert big[-17][:2] == big[-1][:2] and big[0][:2] == big[-1][:2]
+    assert big[-17][2] > big[-1][2] and big[0][2] >= big[-1][2]
+    # ... and the oracle plays those games (the network's rows through the engine's own forward)
+    t = make_trainer(engine, G, "", seed, S_, spe, 1.0, 0.25, 0, 1, False, stagger=False, trace=True, step_budget=3)
+    t.set_net(1, w)
+    assert t.run()
+    o = O.Trainer(G, seed=seed, max_searches=S_, searches_per_eval=spe)
+    o.enable_trace()
+    o.set_stagger(False)
+    H.play_generation(o, G, spe, lambda s: t.net_forward(s))
+    for g in range(G):
+        assert np.array_equal(t.trace(g), o.trace(g)), g
+    assert all(x.tobytes() == y.tobytes() for x, y in zip(H.get_samples(t), H.get_samples(o)))

@@ -31,7 +31,8 @@ for spec in libs:
     for kv in filter(None, envs.split(",")):
         os.environ[kv.split("=")[0]] = kv.split("=")[1]
     L = _lib.declare(C.CDLL(os.path.abspath(path)))
-    t = Trainer(G, "", 12345, 400, 16, 1.0, 0.25, 0, 1, False, stagger=False, pools=pools, _cdll=L)
+    kw = {"step_budget": int(os.environ["AB_BUDGET"])} if "AB_BUDGET" in os.environ else {}  # lib.so:AB_BUDGET=96 (a library that knows the field)
+    t = Trainer(G, "", 12345, 400, 16, 1.0, 0.25, 0, 1, False, stagger=False, pools=pools, _cdll=L, **kw)
     t.set_net(kind, w)
     t.reset(1)
     t.run()
@@ -39,6 +40,7 @@ for spec in libs:
     for kv in filter(None, envs.split(",")):
         del os.environ[kv.split("=")[0]]
 acc = [[0.0, 0.0, 0.0] for _ in libs]
+extra = ["" for _ in libs]
 for r in range(reps):
     for i, t in enumerate(ts):
         t.reset(100 + r)
@@ -50,6 +52,7 @@ for r in range(reps):
         acc[i][1] += st["mcts_ms"]
         acc[i][2] += st["nn_ms"]
         acc[i].append(st.get("nn_rows_evaluated", 0) / max(st.get("nn_rows", 1), 1))
-for path, a in zip(libs, acc):
-    print("%-44s wall %.1f ms  search %.1f ms  network %.1f ms   (%d games, %s, %d pool(s), mean of %d; rows evaluated %.4f of the requested)" %
-          (os.path.basename(path), a[0] / reps, a[1] / reps, a[2] / reps, G, net, pools, reps, sum(a[3:]) / max(len(a[3:]), 1)))
+        extra[i] = "iterations %d, steps cut %d, last budget %d" % (st["iterations"], st.get("steps_cut", 0), st.get("step_budget_last", 0))
+for path, a, x in zip(libs, acc, extra):
+    print("%-44s wall %.1f ms  search %.1f ms  network %.1f ms   (%d games, %s, %d pool(s), mean of %d; rows evaluated %.4f of the requested; %s)" %
+          (os.path.basename(path), a[0] / reps, a[1] / reps, a[2] / reps, G, net, pools, reps, sum(a[3:]) / max(len(a[3:]), 1), x))
