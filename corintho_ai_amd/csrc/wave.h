@@ -422,65 +422,21 @@ __device__ __forceinline__ int co_row_sum_i32(int v) {
  * value, a v_mov_b32_dpp and a packed addition per column -- five instructions where two chains need two, and a step's
  * priors are issue-bound there (round 5: 3.0 k of a pass's 9 k cycles).  The leading s_nop covers the two wait states
  * between a VALU write of the DPP source and its DPP read, which the hazard recogniser cannot see into the asm for. */
+/* (one instruction per column, generated: the sixteen columns of a row in order) */
+#define CO_NEWBCAST_ADD(D, S, C) "v_add_f32_dpp " D ", " S ", " D " row_newbcast:" #C " row_mask:0xf bank_mask:0xf\n\t"
+#define CO_FOR_16_COLUMNS(X)                                                                                              \
+  X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
 __device__ __forceinline__ float co_row_seq_sum16(float a, float v) {
-  asm("s_nop 1\n\t"
-      "v_add_f32_dpp %0, %1, %0 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %0, %1, %0 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %0, %1, %0 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %0, %1, %0 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %0, %1, %0 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %0, %1, %0 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %0, %1, %0 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %0, %1, %0 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %0, %1, %0 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %0, %1, %0 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %0, %1, %0 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %0, %1, %0 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %0, %1, %0 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %0, %1, %0 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %0, %1, %0 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %0, %1, %0 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
-      : "+v"(a)
-      : "v"(v));
+#define CO_SUM1(C) CO_NEWBCAST_ADD("%0", "%1", C)
+  asm("s_nop 1\n\t" CO_FOR_16_COLUMNS(CO_SUM1) : "+v"(a) : "v"(v));
+#undef CO_SUM1
   return a;
 }
-/* two independent sums, interleaved */
+/* two independent sums, interleaved column by column */
 __device__ __forceinline__ void co_row_seq_sum16_2(float &a0, float v0, float &a1, float v1) {
-  asm("s_nop 1\n\t"
-      "v_add_f32_dpp %0, %2, %0 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %1, %3, %1 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %0, %2, %0 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %1, %3, %1 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %0, %2, %0 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %1, %3, %1 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %0, %2, %0 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %1, %3, %1 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %0, %2, %0 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %1, %3, %1 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %0, %2, %0 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %1, %3, %1 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %0, %2, %0 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %1, %3, %1 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %0, %2, %0 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %1, %3, %1 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %0, %2, %0 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %1, %3, %1 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %0, %2, %0 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %1, %3, %1 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %0, %2, %0 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %1, %3, %1 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %0, %2, %0 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %1, %3, %1 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %0, %2, %0 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %1, %3, %1 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %0, %2, %0 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %1, %3, %1 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %0, %2, %0 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %1, %3, %1 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %0, %2, %0 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %1, %3, %1 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
-      : "+v"(a0), "+v"(a1)
-      : "v"(v0), "v"(v1));
+#define CO_SUM2(C) CO_NEWBCAST_ADD("%0", "%2", C) CO_NEWBCAST_ADD("%1", "%3", C)
+  asm("s_nop 1\n\t" CO_FOR_16_COLUMNS(CO_SUM2) : "+v"(a0), "+v"(a1) : "v"(v0), "v"(v1));
+#undef CO_SUM2
 }
 #define ROW_SUM_I32(d, s) ((d) = co_row_sum_i32(s))
 #define ROW_SEQ_SUM16(acc, v) ((acc) = co_row_seq_sum16((acc), (v)))
