@@ -1009,7 +1009,11 @@ struct ca_trainer {
       pools.resize(npools);
       for (int p = 0; p < npools; ++p) {
         Pool &q = pools[p];
+#ifdef CO_EXP_CU_MASK /* diagnostic build (profiles/r06_cu_mask.md): every pool's stream on its own share of the compute units */
+        rt_stream_create_masked(&q.st, p, npools, CO_EXP_CU_MASK);
+#else
         rt_stream_create(&q.st);
+#endif
         q.lo = (int)((int64_t)R * p / npools);
         q.n = (int)((int64_t)R * (p + 1) / npools) - q.lo;
         q.row_base = q.lo * spe;

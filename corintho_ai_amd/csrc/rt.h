@@ -93,6 +93,18 @@ inline void rt_memset(void *d, int v, size_t n, rt_stream_t s) {
 }
 inline void rt_sync(rt_stream_t s) { RT_CHECK(hipStreamSynchronize(s)); }
 inline void rt_stream_create(rt_stream_t *s) { RT_CHECK(hipStreamCreateWithFlags(s, hipStreamNonBlocking)); }
+#ifdef CO_EXP_CU_MASK
+/* diagnostic builds only: stream `p` of `n` restricted to a share of the 256 compute units.  mode 1: a contiguous range of
+ * mask bits, mode 2: every n-th bit, mode 3: all bits (the masked API with nothing masked: the control) */
+inline void rt_stream_create_masked(rt_stream_t *s, int p, int n, int mode) {
+  uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int cu = 0; cu < 256; ++cu) {
+    const bool mine = mode == 1 ? (cu * n / 256 == p) : mode == 2 ? (cu % n == p) : true;
+    if (mine) mask[cu >> 5] |= 1u << (cu & 31);
+  }
+  RT_CHECK(hipExtStreamCreateWithCUMask(s, 8, mask));
+}
+#endif
 inline void rt_stream_destroy(rt_stream_t s) {
   if (s) (void)hipStreamDestroy(s);
 }
