@@ -1306,7 +1306,7 @@ struct ca_trainer {
       rt_sync(stream);
       steps_cut = 0;
       for (size_t p = 0; p < pools.size(); ++p) steps_cut += (int64_t)wc[CO_WC_WORDS * p + CO_WC_CUTS];
-      step_budget_last = P.step_budget > 0 ? P.step_budget : (int64_t)std::max(wc[CO_WC_BUDGET], wc[CO_WC_BUDGET + 1]);
+      step_budget_last = P.step_budget > 0 ? P.step_budget : (int64_t)std::max(wc[CO_WC_BUDGET], wc[CO_WC_BUDGET + 1]) / CO_STEP_UNITS_PER_CONFIG_UNIT;
     }
     if (timed_launches > 0) pack_ms = pack_timed_ms * (double)nn_launches / (double)timed_launches;
     return finished;

@@ -66,9 +66,9 @@
  * carries on in the next launch follows the pool's mean (EngineParams::step_budget_k16; measured: DESIGN section 6
  * "K3, round 6") */
 #ifndef CO_STEP_BUDGET_K16
-#define CO_STEP_BUDGET_K16 26 /* automatic: 1.625 x the smoothed mean of the launches before (measured: 22 / 26 / 30 / 34 within 1 %) */
+#define CO_STEP_BUDGET_K16 24 /* automatic: 1.5 x the smoothed mean of the launches before (measured, clock: 20 / 24 / 28 / 34 -> trained checkpoint 211 / 207 / 210 / 221 ms, random-init MLP 116.2 / 116.8 / 120.2 / 125.4, CNN 383.9 / 383.0 / 385.7 / 388.6) */
 #endif
-#define CO_STEP_BUDGET_MIN 24
+#define CO_STEP_BUDGET_MIN (24 * CO_STEP_UNITS_PER_CONFIG_UNIT) /* 24 us / 24 scans */
 /* A pool's words of EngineParams::work_counter, 64 per pool.  The words every wavefront READS (the budget) lie in another
  * 128-byte line than the ones every wavefront adds to with device-scope atomics: in one line with them (and with the next
  * pool's) the read cost 15 % of a generation -- 152 against 132 ms with a budget no step reaches (round 6). */

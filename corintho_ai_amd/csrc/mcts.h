@@ -58,6 +58,26 @@ CO_CONST uint32_t CO_GAMMA_BITS[CO_NUM_GAMMA] = CO_GAMMA_BITS_INIT;
 #define CO_PH_MEM(slot) ((void)0)
 #endif
 
+/* What a step's budget is counted in (EngineParams::step_budget).  The device build measures TIME -- ticks of the 100 MHz
+ * real-time counter since the step began: what a launch waits for is its slowest wavefront's time, whatever made it slow
+ * (depth, terminal leaves and their propagation, a SIMD shared with another pool's kernel) -- and the emulation build, which
+ * has no clock and must stay deterministic, counts PUCT scans (1 scan ~ 1.6 us).  Either way ONE scalar lives across the
+ * step: the deadline (device) or the scans so far minus the budget (emulation). */
+#if !defined(CO_EMU) && !defined(CO_BUDGET_SCANS)
+#define CO_STEP_CLOCK() ((uint32_t)__builtin_amdgcn_s_memrealtime())
+#define CO_STEP_UNITS_PER_CONFIG_UNIT 100 /* ca_config.step_budget > 0 is in microseconds */
+#define CO_STEP_WORK(w, n) ((void)0)
+#define CO_STEP_START(budget) ((int)(CO_STEP_CLOCK() + (uint32_t)(budget)))
+#define CO_STEP_SPENT(w) ((int)(CO_STEP_CLOCK() - (uint32_t)(w).work) >= 0)
+#define CO_STEP_DONE(w, budget) ((int)(CO_STEP_CLOCK() - ((uint32_t)(w).work - (uint32_t)(budget))))
+#else
+#define CO_STEP_UNITS_PER_CONFIG_UNIT 1 /* ca_config.step_budget > 0 is in scans */
+#define CO_STEP_WORK(w, n) ((w).work += (n))
+#define CO_STEP_START(budget) (-(budget))
+#define CO_STEP_SPENT(w) ((w).work >= 0)
+#define CO_STEP_DONE(w, budget) ((w).work + (budget))
+#endif
+
 struct CoTree {
   uint4 *A;      /* arena of this tree */
   TreeCtl tc;    /* register copy, written back at the end of the step */
@@ -89,8 +109,9 @@ struct CoWave {
   uint32_t *noise_raw;
   int noise_words; /* generator outputs owed to the leaves queued so far (in this step, and in the steps before it that were
                     * cut short with their leaves held back: GameCtl::held) */
-  int work; /* PUCT scans of this step so far MINUS its budget (co_step_budget): the step stops selecting when this reaches zero
-             * (one live scalar instead of two: with the budget kept beside the count the kernel spills 170 more SGPRs) */
+  int work; /* CO_STEP_*: the step's deadline (device), or its PUCT scans so far MINUS its budget (emulation) -- the step stops
+             * selecting when the clock passes it / when it reaches zero (one live scalar instead of two: with the budget kept
+             * beside a count the kernel spills 170 more SGPRs) */
   /* the records of up to CO_PRE pending leaves, in the wavefront's LDS: pre[f * CO_PRE + k] = field f (CO_PRE_*) of leaf
    * pre_c0 + k, k < pre_n.  Requested with the game's other first loads (co_mcts_step_wave) -- in registers until
    * co_receive_eval they cost 44 spilled registers in the search -- and read by co_receive_eval */
@@ -874,7 +895,7 @@ CO_COLD2 void co_search(CoWave &w, CoTree &t, CoRoot &rc) {
     }
     CO_PH(8);
     CO_PROF_ADD(w, 23, 1ull);
-    ++w.work;
+    CO_STEP_WORK(w, 1);
     /* ---- visit the current node (virtual loss on every node of the path) */
     cs = co_slot_set_visits(cs, visits + 1);
     cs.y = co_f2u(co_u2f(cs.y) + 1.0f);
@@ -1106,7 +1127,7 @@ CO_DEV int co_search_rows(CoWave &w, CoTree &t, CoRoot &rc, int m) {
       for (int j = 0; j < msel; ++j) {
         CO_SBS(10, 1);
         CO_PROF_ADD(w, 23, 1ull);
-        ++w.work;
+        CO_STEP_WORK(w, 1);
         const float v_sqrt = WAVE_BCAST(vsl, j);
         LV(float, u);
         FOR_LANES_HOT {
@@ -1282,7 +1303,7 @@ CO_DEV int co_search_rows(CoWave &w, CoTree &t, CoRoot &rc, int m) {
           if (r < 0 || r >= bad) continue;
           CO_SBS(10, 1);
           CO_PROF_ADD(w, 23, 1ull);
-          ++w.work;
+          CO_STEP_WORK(w, 1);
           const int n = (int)CO_META_NEDGES(wh[i].z);
           int gone = 0; /* the row's simulation is not ordinary */
           int le = 0;
@@ -1422,7 +1443,7 @@ CO_DEV int co_search_rows(CoWave &w, CoTree &t, CoRoot &rc, int m) {
       const uint64_t tm = WAVE_BALLOT(todo);
       if (!tm) break;
       CO_SBS(24, 1);
-      w.work += 2; /* (a turn in row form: the instructions of two to three wave-wide scans) */
+      CO_STEP_WORK(w, 2); /* (a turn in row form: the instructions of two to three wave-wide scans) */
       /* a row waits while an earlier row of the same node has yet to scan it */
       const uint32_t x0 = WAVE_BCAST(X, 0), x1 = WAVE_BCAST(X, 16), x2 = WAVE_BCAST(X, 32);
       const int t0 = (int)(tm & 1ull), t1 = (int)((tm >> 16) & 1ull), t2 = (int)((tm >> 32) & 1ull);
@@ -1892,7 +1913,7 @@ CO_DEV int co_mc_do_iteration(CoWave &w, CoTree &t, const float *eval, const flo
 
     if (co_res_known(co_slot_result(rc.cs)) || co_slot_all_visited(rc.cs)) break;
     if (w.gc.error) break;
-    if (w.work >= 0) {
+    if (CO_STEP_SPENT(w)) {
       /* more simulations are due and this step has done its share: the next launch continues here (co_step_tail holds
        * the queued leaves back).  Everything the loop carries is in the tree, in the game's record or in `pe`. */
       w.gc.held |= 1;
@@ -2676,7 +2697,7 @@ CO_DEV void co_pool_housekeeping(const EngineParams &P, int g) {
 #define CO_STEP_BUDGET_NONE (1 << 28)
 CO_DEV int co_step_budget(const EngineParams &P) {
   if (!(P.fused_pack && !P.testing && !P.analyse && !P.pcfg)) return CO_STEP_BUDGET_NONE;
-  int b = P.step_budget;
+  int b = P.step_budget * CO_STEP_UNITS_PER_CONFIG_UNIT;
   if (P.step_budget == 0 && P.step_budget_k16 > 0 && P.work_counter) b = (int)(uint32_t)P.work_counter[CO_WC_BUDGET + ((P.iteration + 1) & 1)];
   return b > 0 ? b : CO_STEP_BUDGET_NONE;
 }
@@ -2703,7 +2724,7 @@ CO_DEV void co_wave_init(const EngineParams &P, int g, const GameCtl &gc, const 
   w.pend_key = P.cache.hdr ? P.pend_key + (size_t)g * P.searches_per_eval : (uint4 *)0;
   w.noise_raw = P.noise_raw + (size_t)g * P.searches_per_eval * CO_NUM_MOVES;
   w.noise_words = (gc.held & 1) ? gc.noise_held : 0; /* a step consumes every pending leaf before it queues new ones -- unless they were held back */
-  w.work = -co_step_budget(P);
+  w.work = CO_STEP_START(co_step_budget(P));
   w.req = P.req + (size_t)g * P.searches_per_eval * CO_STATE_STRIDE;
   /* samples and traces belong to the GAME, not to the slot */
   w.samples = P.samples ? P.samples + (size_t)gc.gid * CO_MAX_PLIES * CO_SAMPLE_FLOATS : (float *)0;
@@ -2781,7 +2802,7 @@ CO_DEV void co_step_tail(const EngineParams &P, CoWave &w, int g, int done) {
   unsigned long long old = 0ull;
   CO_PH_MEM(25);
   if (packs && P.work_counter) {
-    const int scans = w.work + co_step_budget(P); /* (the budget once more, from where it lies: not kept across the step) */
+    const int scans = CO_STEP_DONE(w, co_step_budget(P)); /* (the budget once more, from where it lies: not kept across the step) */
     /* scans of the launch over the steps BEGUN in it: the pieces of a step that was cut add their scans, not a step -- counted
      * as steps of their own they pull the mean down, the budget follows, more steps are cut: it collapses to its floor */
     if (scans > 0) co_atomic_add_u64_noret(P.work_counter + P.iteration % 3, ((w.gc.held & 2) ? 0ull : 1ull << 32) | (unsigned long long)scans);

@@ -82,12 +82,13 @@ typedef struct ca_config {
    * negative = off.  (The reference evaluates every request, main.pyx:70-83; results are identical either way.) */
   int32_t eval_cache;
   /* Fused training: a game's step (the body of Trainer::doIteration's loop for that game, trainer.cpp:175-196) stops
-   * selecting after this many PUCT scans and goes on in the next iteration; the leaves it has queued are held back until
+   * selecting once it has run for this long and goes on in the next iteration; the leaves it has queued are held back until
    * the batch of searches_per_eval is complete (or the move's searches run out), so the game performs exactly the
    * reference's sequence of operations -- only spread over more iterations.  It bounds what a launch waits for: its
-   * slowest game (endgame positions under a trained network: 25-30 simulations ten levels deep per step, half of them
-   * ending in terminal leaves that queue nothing).  0 = automatic, n > 0 = n scans, negative = no limit.  Results are
-   * identical either way; the number of iterations of a generation is not. */
+   * slowest game (endgame positions under a trained network: simulations ten levels deep, half of them ending in
+   * terminal leaves that queue nothing).  0 = automatic (1.6 x the running mean of the pool's steps), n > 0 = n
+   * microseconds, -1 = no limit (below -1, diagnostic: automatic with the factor -n / 16).  Results are identical either
+   * way; the number of iterations of a generation is not. */
   int32_t step_budget;
 } ca_config;
 
@@ -228,7 +229,7 @@ typedef struct ca_stats {
   int64_t resident_slots; /* slots of the pool (= num_games unless it recycles, ca_config.resident) */
   int64_t nn_rows_evaluated; /* rows the network kernels worked on; nn_rows - this = rows served by the evaluation cache */
   int64_t steps_cut;         /* ca_config.step_budget: game steps of the last ca_trainer_run that stopped at their budget and went on in the next iteration */
-  int64_t step_budget_last;  /* the budget (PUCT scans) the first pool's last launch worked under; 0 = none */
+  int64_t step_budget_last;  /* the budget (microseconds) the first pool's last launch worked under; 0 = none */
 } ca_stats;
 int ca_trainer_stats(ca_trainer *t, ca_stats *out);
 /* per-game: {to_play, done, result, n_samples, n_pending, error, mate_turn, plies} */
