@@ -329,7 +329,7 @@ struct ca_trainer {
     next_game.alloc(1, stream);
     all_done.alloc(1, stream);
     row_counter.alloc(1, stream);
-    pack_counter.alloc(2 * CO_MAX_POOLS, stream);
+    pack_counter.alloc((size_t)CO_PACK_STRIDE * CO_MAX_POOLS, stream); /* a 128-byte line per pool: every wavefront of a launch adds to its pool's words */
     work_counter.alloc((size_t)CO_WC_WORDS * CO_MAX_POOLS, stream);
     arena_state.alloc(8, stream);
     if (tourney) {
@@ -404,7 +404,7 @@ struct ca_trainer {
     const unsigned long long first_unstarted = (unsigned long long)R;
     rt_h2d(next_game.p, &first_unstarted, 8, stream);
     rt_memset(row_counter.p, 0, 8, stream);
-    rt_memset(pack_counter.p, 0, 16 * CO_MAX_POOLS, stream);
+    rt_memset(pack_counter.p, 0, (size_t)8 * CO_PACK_STRIDE * CO_MAX_POOLS, stream);
     rt_memset(work_counter.p, 0, (size_t)8 * CO_WC_WORDS * CO_MAX_POOLS, stream);
     rt_memset(arena_state.p, 0, 32, stream);
     rt_sync(stream);
@@ -1115,7 +1115,8 @@ struct ca_trainer {
       rt_event_sync(q.polled[parity]);
       unsigned long long c = q.word[parity];
       const unsigned long long evaluated = q.cache.hdr ? q.word[2 + parity] & 0xFFFFFFFFull : c & 0xFFFFFFFFull;
-      q.running = (int)(c >> 32);
+      q.running = (int)((c >> 32) & 0xFFFFFFull); /* (bits 56..: games of the iteration that held their leaves back, mcts.h co_step_tail) */
+      const bool holding = (c >> 56) != 0;
       if (q.timed[parity]) {
         /* one iteration per window is timed (three event records per launch pair cost 1-4 % of
          * the wall time); its batch size is the counter word just read */
@@ -1128,15 +1129,13 @@ struct ca_trainer {
         q.timed[parity] = 0;
       }
       q.launched[parity] = 0;
-      q.finished = (c >> 32) == 0;
-      if (!q.finished && (c & 0xFFFFFFFFull) == 0) {
+      q.finished = ((c >> 32) & 0xFFFFFFull) == 0;
+      if (!q.finished && (c & 0xFFFFFFFFull) == 0 && !holding) {
         /* main.pyx:161-163 raises when NO game has a request.  A pool whose first game the
          * staggered start (trainer.cpp:184-186) has not released yet has running games and no
          * rows by construction: that is not the reference's error condition */
-        /* (64 polls in a row: with a step budget a pool's last games may pass a few iterations submitting nothing --
-         * a step that stopped at its budget holds its leaves back -- but every such step runs simulations of a move's
-         * bounded number) */
-        if (q.word_iter[parity] > q.first_start && ++q.idle > 64) failure = "No requests during training";
+        /* (an iteration whose games all stopped at their step budget has no rows either -- `holding`: that is not it) */
+        if (q.word_iter[parity] > q.first_start && ++q.idle > 16) failure = "No requests during training";
       } else {
         q.idle = 0;
       }
@@ -1182,7 +1181,7 @@ struct ca_trainer {
         pp.pool_lo = q.lo;
         pp.pool_n = q.n;
         pp.pool_row_base = q.row_base;
-        pp.pack_counter = pack_counter.p + 2 * p;
+        pp.pack_counter = pack_counter.p + CO_PACK_STRIDE * p;
         pp.work_counter = work_counter.p + (size_t)CO_WC_WORDS * p;
         pp.cache = q.cache; /* (hdr null: no cache) */
         pp.cache.no_claim = emptied ? 1u : 0u;
@@ -1223,7 +1222,7 @@ struct ca_trainer {
           if (timed) rt_event_record(e[3], q.st);
         } else {
           if (timed) rt_event_record(e[2], q.st);
-          const int32_t *d_rows = (const int32_t *)(pack_counter.p + 2 * p + (trainer_iteration & 1));
+          const int32_t *d_rows = (const int32_t *)(pack_counter.p + CO_PACK_STRIDE * p + (trainer_iteration & 1));
           CoNetIO io;
           io.alone = npools == 1;
           io.in_idx = row_idx.p + q.row_base; /* the rows stay where the games wrote them (co_step_tail) */
@@ -1244,7 +1243,7 @@ struct ca_trainer {
       if (in_window == poll || (max_iterations > 0 && it == max_iterations)) {
         for (auto &q : pools) {
           if (q.finished) continue;
-          rt_d2h(&q.word[parity], pack_counter.p + 2 * (&q - &pools[0]) + counter_slot, 8, q.st);
+          rt_d2h(&q.word[parity], pack_counter.p + CO_PACK_STRIDE * (&q - &pools[0]) + counter_slot, 8, q.st);
           if (q.cache.hdr) rt_d2h(&q.word[2 + parity], q.c_count + 4 * counter_slot, 4, q.st);
           q.word_iter[parity] = trainer_iteration - 1;
           rt_event_record(q.polled[parity], q.st);

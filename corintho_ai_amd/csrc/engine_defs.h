@@ -72,6 +72,7 @@
 /* A pool's words of EngineParams::work_counter, 64 per pool.  The words every wavefront READS (the budget) lie in another
  * 128-byte line than the ones every wavefront adds to with device-scope atomics: in one line with them (and with the next
  * pool's) the read cost 15 % of a generation -- 152 against 132 ms with a budget no step reaches (round 6). */
+#define CO_PACK_STRIDE 16 /* words between two pools' pack counters: a line each */
 #define CO_WC_WORDS 64
 #define CO_WC_BUDGET 16 /* [2] by launch parity */
 #define CO_WC_MEAN 18   /* [2] the smoothed mean, in 1/256 scans */
@@ -106,7 +107,7 @@ struct GameCtl {
    * fewer than searches_per_eval leaves queued -- none of them was submitted, no evaluation is on its way; this step
    * goes on selecting where that one stopped (mcts.h co_mc_do_iteration).  noise_held = generator outputs owed to the
    * leaves queued so far (CoWave::noise_words, carried over).  The game's own sequence of operations is unchanged. */
-  int32_t held;       /* bit 0: as described; bit 1 (within a step only): this step continues one that was cut */
+  int32_t held;       /* bit 0: as described; within a step only: bit 1 this step continues one that was cut, bit 2 it has run a simulation */
   int32_t noise_held;
 };
 

@@ -1907,13 +1907,16 @@ CO_DEV int co_mc_do_iteration(CoWave &w, CoTree &t, const float *eval, const flo
    * simulation, kept with the game from step to step): above 3/8 they run one after the other, above 5/32 two at a time. */
   int pe = w.gc.sb_cap > 0 && w.gc.sb_cap <= 256 ? w.gc.sb_cap : 0;
 #endif
+  /* (bit 2 of gc.held: this call has run a simulation.  A step whose budget is spent before its first one -- a deadline
+   * already behind the receive phase -- still makes progress: else it would stop again and again, for ever.  In the
+   * game's record because one more scalar kept across the loop costs the kernel 200 spilled registers.) */
   for (;;) {
     if (!(w.gc.n_pending < w.spe && t.tc.searches_done < w.max_searches)) break;
     if (!rc.valid) co_root_load(t, rc);
 
     if (co_res_known(co_slot_result(rc.cs)) || co_slot_all_visited(rc.cs)) break;
     if (w.gc.error) break;
-    if (CO_STEP_SPENT(w)) {
+    if ((w.gc.held & 4) && CO_STEP_SPENT(w)) {
       /* more simulations are due and this step has done its share: the next launch continues here (co_step_tail holds
        * the queued leaves back).  Everything the loop carries is in the tree, in the game's record or in `pe`. */
       w.gc.held |= 1;
@@ -1929,6 +1932,7 @@ CO_DEV int co_mc_do_iteration(CoWave &w, CoTree &t, const float *eval, const flo
       if (m > cap) m = cap;
       if (m > 1 && (int)CO_META_NEDGES(rc.h0.z) <= CO_WAVE) {
         const int r = co_search_rows(w, t, rc, m);
+        w.gc.held |= 4;
         for (int i = 0; i < (r & 0xFF); ++i) pe -= pe >> 3;
         if (r & 0x300) {
           pe += (256 - pe) >> 3;
@@ -1942,6 +1946,7 @@ CO_DEV int co_mc_do_iteration(CoWave &w, CoTree &t, const float *eval, const flo
     CO_SBS(8, 1);
     CO_SBP(w, 6, 1);
     co_search(w, t, rc);
+    w.gc.held |= 4;
     CO_PROF_ADD(w, 5, 1ull);
 #if CO_SB > 1
     if (!counted) {
@@ -2811,7 +2816,8 @@ CO_DEV void co_step_tail(const EngineParams &P, CoWave &w, int g, int done) {
   if (packs && w.gc.held) {
     /* the step stopped at its budget: the game is running and submits nothing; its leaves (request rows, records and keys
      * are in place) wait for the rest of their batch, the generator outputs owed to them are reserved with the others' */
-    co_atomic_add_u64(P.pack_counter + (P.iteration & 1), 1ull << 32);
+    /* (bits 56..: games that hold their leaves back -- the host tells an iteration without rows from "no game has a request") */
+    co_atomic_add_u64(P.pack_counter + (P.iteration & 1), (1ull << 32) | (1ull << 56));
     if (P.work_counter) co_atomic_add_u64_noret(P.work_counter + CO_WC_CUTS, 1ull); /* (ca_stats.steps_cut) */
     w.gc.noise_held = w.noise_words;
     return;
