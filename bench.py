@@ -201,7 +201,7 @@ def measured_traffic(kernel, args, net, npools):
     if (args.games, args.sims, args.spe) != (4096, 400, 16):
         return None
     try:
-        for rnd in ("r05", "r04", "r03", "r02"):
+        for rnd in ("r06", "r05", "r04", "r03", "r02"):
             path = os.path.join(ROOT, "profiles", "%s_%s_pmc.json" % (rnd, net))
             if os.path.exists(path):
                 break

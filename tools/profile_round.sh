@@ -8,7 +8,7 @@ tag=$1; shift
 HB=$!
 trap "kill $HB 2>/dev/null" EXIT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-A="--steps 1 --warmup 0 --cpu-games 0 --no-variants --no-unshared --recycle-games 0 $*"
+A="--steps 1 --warmup 0 --cpu-games 0 --no-variants --no-unshared --recycle-games 0 --no-trained --no-configs $*"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d /tmp/prof/prof_${tag}_stats -o stats -- python3 bench.py $A > gpurun_out/prof_${tag}_stats.log 2>&1
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/prof/prof_${tag}_fetch -o fetch -- python3 bench.py $A > gpurun_out/prof_${tag}_fetch.log 2>&1
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/prof/prof_${tag}_write -o write -- python3 bench.py $A > gpurun_out/prof_${tag}_write.log 2>&1

@@ -29,7 +29,8 @@ def rooflines(st, wall_s, net_name):
     from the HIP-event durations of the timed launches (engine.hip run_pools), as in bench.py"""
     flop = nets.rescnn4_flop_per_row()
     rows = st.get("nn_rows_evaluated", 0) or st.get("evals", 0)
-    nn_s, mc_s = max(st["nn_ms"] * 1e-3, 1e-12), max(st["mcts_ms"] * 1e-3, 1e-12)
+    timed = st["nn_ms"] > 0 and st["mcts_ms"] > 0  # (the tournament's fused loop carries no events: wall level only)
+    nn_s, mc_s = (st["nn_ms"] * 1e-3, st["mcts_ms"] * 1e-3) if timed else (wall_s, wall_s)
     a_n = rows * flop / nn_s / 1e12
     a_s = st["searches"] * BYTES_PER_SIM / mc_s / 1e9
     rn = {"kernel": "network (K6p / K6h3 small and thin paths)" if net_name == "rescnn4h3" else "network", "bound": "mfma",
@@ -39,7 +40,9 @@ def rooflines(st, wall_s, net_name):
     rs = {"kernel": "co_k_mcts_step", "bound": "hbm", "achieved": a_s, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a_s / HBM_PEAK_GBS,
           "traffic": None, "wall": {"achieved": st["searches"] * BYTES_PER_SIM / wall_s / 1e9,
                                     "frac": st["searches"] * BYTES_PER_SIM / wall_s / 1e9 / HBM_PEAK_GBS}}
-    return {"roofline": rn if nn_s >= mc_s else rs, "roofline_network": rn, "roofline_search": rs}
+    if not timed:
+        rn["note"] = rs["note"] = "wall level: this mode's launches carry no HIP events"
+    return {"roofline": rn if (nn_s >= mc_s and rows > 0) else rs, "roofline_network": rn, "roofline_search": rs}
 
 
 def run_trainer(name, G, S, net_name, w0, w1, testing=False, reps=1, device=0):
