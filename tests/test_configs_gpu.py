@@ -78,6 +78,29 @@ def test_cfg2_the_bench_default_whole_on_the_oracle(games, slots, pools):
           % (games, st["resident_slots"], st["plies"], st["searches"], st["nn_rows_evaluated"], st["nn_rows"], t.score()))
 
 
+def test_trained_checkpoint_generation_whole_on_the_oracle():
+    """the regime the step budget was made for (round 6): the reference's last checkpoint guiding 4096 games -- narrow deep
+    trees, in late plies every second simulation terminal, ~100 000 steps of the generation stopped at their budget and
+    resumed -- with every game replayed on the oracle (`detail.trained_checkpoint` of the bench line times this workload)"""
+    import os
+
+    import numpy as np
+
+    from corintho_ai_amd import NET_MLP12X100_H3
+
+    games, S_, spe, seed = 4096, 400, 16, 12345
+    w = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trained_last.npz"))["weights"]
+    t = make_trainer("hip", games, "", seed, S_, spe, 1.0, 0.25, 0, 1, False, stagger=False)
+    t.set_net(NET_MLP12X100_H3, w)
+    assert t.run()
+    st = t.stats()
+    assert st["pools"] == 3 and st["nn_rows"] == st["evals"] > 0
+    assert st["steps_cut"] > 10000 and st["step_budget_last"] > 0  # the budget is on, and it bites
+    _replay_whole_generation(t, games, S_, spe, seed)
+    print("trained checkpoint, %d games: %d plies, %d simulations, %d iterations, %d steps stopped at their budget (last budget %d us)"
+          % (games, st["plies"], st["searches"], st["iterations"], st["steps_cut"], st["step_budget_last"]))
+
+
 def test_cfg4_a_512_game_generation_whole_on_the_oracle():
     """cfg4's setting (1600 sims/move, Dirichlet noise) at the bench's arithmetic, 512 games, every game on the oracle"""
     G, S_, spe, seed = 512, 1600, 16, 4321
