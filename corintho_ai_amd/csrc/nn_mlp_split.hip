@@ -65,15 +65,7 @@ typedef uint32_t m3_u32x4 __attribute__((ext_vector_type(4)));
 #define M3_CHUNK_WORDS(NT) (4 * M3_STEP_WORDS(NT) + M3_BIAS_WORDS) /* NT 2: 36 KB, NT 3: 52 KB */
 #define M3_CHUNK_PIECES_PER_WAVE(NT) (M3_CHUNK_WORDS(NT) / 256 / 4)  /* 9 / 13 */
 #define M3_TOTAL_WORDS(NT) (M3_NCHUNKS * M3_CHUNK_WORDS(NT))
-/* slots of the weight ring: chunk c computes while the M3_RING - 1 chunks behind it are landing or requested.  Three for
- * three terms (3 x 52 KB); FOUR for two terms (4 x 36 KB = 144 KB) since round 6: the stream is latency-bound -- a
- * workgroup pass takes 33 us whether the launch has 8 workgroups or 171, 936 KB of fragments through LDS-DMA at 28 GB/s
- * per compute unit with two chunks in flight -- and a third chunk in flight is what shortens it (measured below) */
-#ifndef M3_RING2
-#define M3_RING2 4
-#endif
-#define M3_RING(NT) ((NT) == 2 ? M3_RING2 : 3)
-#define M3_LDS_BYTES(NT) (M3_RING(NT) * M3_CHUNK_WORDS(NT) * 4)
+#define M3_LDS_BYTES(NT) (3 * M3_CHUNK_WORDS(NT) * 4)
 #define M3_ROWS_PER_WG 128
 
 /* one wave copies 1 KiB per instruction: lane i supplies bytes [16 i, 16 i + 16) */
@@ -188,19 +180,15 @@ __device__ __forceinline__ void m3_init_bias(m3_f32x16 (&acc)[4], const float *b
  * receives chunk c + 2 */
 #define M3_CHUNK_HEAD(NT, c)                                                                         \
   {                                                                                                  \
-    /* chunks still to land behind chunk c: the younger ones of the ring that exist */               \
-    const int behind_ = M3_NCHUNKS - 1 - (c) < M3_RING(NT) - 2 ? M3_NCHUNKS - 1 - (c) : M3_RING(NT) - 2; \
-    if (NT == 2) {                                                                                   \
-      if (behind_ >= 2) CO_WAIT_VMCNT(18);                                                           \
-      else if (behind_ == 1) CO_WAIT_VMCNT(9);                                                       \
-      else CO_WAIT_VMCNT(0);                                                                         \
+    if ((c) + 1 < M3_NCHUNKS) {                                                                      \
+      if (NT == 2) CO_WAIT_VMCNT(9);                                                                 \
+      else CO_WAIT_VMCNT(13);                                                                        \
     } else {                                                                                         \
-      if (behind_ >= 1) CO_WAIT_VMCNT(13);                                                           \
-      else CO_WAIT_VMCNT(0);                                                                         \
+      CO_WAIT_VMCNT(0);                                                                              \
     }                                                                                                \
     co_wg_barrier();                                                                                 \
-    if ((c) + M3_RING(NT) - 1 < M3_NCHUNKS)                                                          \
-      m3_stage<NT>(wfrag, lds_base + (uint32_t)(((c) + M3_RING(NT) - 1) % M3_RING(NT)) * (M3_CHUNK_WORDS(NT) * 4u), (c) + M3_RING(NT) - 1, wave, lane); \
+    if ((c) + 2 < M3_NCHUNKS)                                                                        \
+      m3_stage<NT>(wfrag, lds_base + (uint32_t)(((c) + 2) % 3) * (M3_CHUNK_WORDS(NT) * 4u), (c) + 2, wave, lane); \
   }
 
 template <int NT, bool F16 = false>
@@ -208,7 +196,7 @@ __global__ __launch_bounds__(256, 1) void co_k_mlp_forward_split_t(const float *
                                                                    const uint32_t *__restrict__ wfrag, float *__restrict__ eval,
                                                                    float *__restrict__ probs, CoNetIO io, uint32_t *range_flag) {
   static_assert(M3_CHUNK_PIECES_PER_WAVE(2) == 9 && M3_CHUNK_PIECES_PER_WAVE(3) == 13, "vmcnt immediates of M3_CHUNK_HEAD");
-  extern __shared__ __attribute__((aligned(16))) uint32_t m3_lds[]; /* ring of M3_RING(NT) chunk slots */
+  extern __shared__ __attribute__((aligned(16))) uint32_t m3_lds[]; /* ring of three chunk slots */
   const int rows = *d_rows;
   const int row0 = blockIdx.x * M3_ROWS_PER_WG;
   if (row0 >= rows) return;
@@ -244,8 +232,8 @@ __global__ __launch_bounds__(256, 1) void co_k_mlp_forward_split_t(const float *
   }
   /* the first two chunks are requested behind the input loads: vmcnt retires in issue order, so
    * loads issued behind a transfer would wait for it */
-#pragma unroll
-  for (int c = 0; c < M3_RING(NT) - 1; ++c) m3_stage<NT>(wfrag, lds_base + (uint32_t)c * (M3_CHUNK_WORDS(NT) * 4u), c, wave, lane);
+  m3_stage<NT>(wfrag, lds_base, 0, wave, lane);
+  m3_stage<NT>(wfrag, lds_base + M3_CHUNK_WORDS(NT) * 4u, 1, wave, lane);
   m3_f32x16 acc[4];
   uint32_t amax = 0u; /* F16: the running maximum of the packed first terms (nn.h range_exceeded; nn_rescnn.hip rcs_pk_max_f16: an
                        * activation beyond fp16's range has the first term +inf; ReLU outputs are never negative) */
@@ -253,14 +241,14 @@ __global__ __launch_bounds__(256, 1) void co_k_mlp_forward_split_t(const float *
     const int c0 = 2 * l;
     {
       M3_CHUNK_HEAD(NT, c0)
-      const uint32_t *wl = m3_lds + (c0 % M3_RING(NT)) * M3_CHUNK_WORDS(NT);
+      const uint32_t *wl = m3_lds + (c0 % 3) * M3_CHUNK_WORDS(NT);
       m3_init_bias(acc, reinterpret_cast<const float *>(wl + 4 * M3_STEP_WORDS(NT)), h);
       if (l == 0) m3_steps<NT, 0, 4, 1, F16>(acc, b, wl, lane);
       else m3_steps<NT, 0, 4, NT, F16>(acc, b, wl, lane);
     }
     {
       M3_CHUNK_HEAD(NT, c0 + 1)
-      const uint32_t *wl = m3_lds + ((c0 + 1) % M3_RING(NT)) * M3_CHUNK_WORDS(NT);
+      const uint32_t *wl = m3_lds + ((c0 + 1) % 3) * M3_CHUNK_WORDS(NT);
       if (l == 0) m3_steps<NT, 4, M3_STEPS_L0 - 4, 1, F16>(acc, b, wl, lane);
       else m3_steps<NT, 4, M3_STEPS - 4, NT, F16>(acc, b, wl, lane);
     }
@@ -317,280 +305,6 @@ __global__ __launch_bounds__(256, 1) void co_k_mlp_forward_split_t(const float *
     if (h == 0) eval[orow * (size_t)io.eval_stride] = tanhf(acc[3][0]);
   }
 }
-/* ======================================================================
- * K5h3w (round 6): the two-term kernels with a layer's OUTPUT TILES split over two wavefronts.
- *
- * With the search kernel's step budget an iteration of the reference's own network is the chain search launch (104 us)
- * -> network launch (45 us) -> search launch with no idle time in it, and the 45 us are LATENCY: a batch of 21.8 k rows
- * is 171 workgroups, one per compute unit, one wavefront per SIMD, and a wavefront's 84 MFMAs per layer (2 688 cycles)
- * sit in 7 600 cycles of a layer -- chunk heads, LDS fragment reads behind barriers, the ReLU + split epilogue, all of
- * them exposed because nothing else runs on the SIMD.  Here a workgroup has EIGHT wavefronts for the same 128 rows:
- * wavefront w works on row tile w / 2 and on output tiles {2 (w & 1), 2 (w & 1) + 1}, i.e. half of the MFMAs, half of
- * the weight fragments and half of the epilogue of a layer, with its partner on the same SIMD filling its gaps.  The
- * price: a layer's activations are the B operand of BOTH halves of the next layer, so each wavefront hands its half
- * (4 K steps x 2 terms x 1 KB) to its partner through LDS -- written behind its epilogue, read behind the next chunk
- * head's barrier (no barrier of its own).
- *
- * Same weights, same global layout (the chunks of co_k_mlp_forward_split_t: their first 32 KB, the fragments, go to a
- * slot, the first KB of the bias piece to a ring of its own); per accumulator the same products in the same order: the
- * SAME BITS as the four-wavefront kernel.  LDS: three 32 KB slots + 56 KB of exchange + 3 KB of biases = 155 KB. */
-#define M3W_SLOT_WORDS (4 * M3_STEP_WORDS(2))        /* 8192 words: four K steps of fragments */
-#define M3W_XCH_WORDS (4 * 7 * 2 * 256)               /* [row tile][K step 0..6][term][64 lanes x 4 words] */
-#define M3W_BIAS_WORDS 256                            /* the first KB of a chunk's bias piece: 128 floats + padding */
-#define M3W_LDS_BYTES ((3 * M3W_SLOT_WORDS + M3W_XCH_WORDS + 3 * M3W_BIAS_WORDS) * 4) /* 155 KB */
-
-/* chunk c's fragments into a slot: 32 pieces of 1 KB, four per wavefront; with an even chunk (the first of layer c / 2)
- * wavefront 0 also fetches the layer's biases into their ring (its fifth piece) */
-__device__ __forceinline__ void m3w_stage(const uint32_t *w, uint32_t lds_base, int c, int wave, int lane) {
-  const uint32_t *src = w + (size_t)c * M3_CHUNK_WORDS(2) + lane * 4;
-  const uint32_t slot = lds_base + (uint32_t)(c % 3) * (M3W_SLOT_WORDS * 4u);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int p = wave + 8 * i;
-    co_lds_dma_1k(src + p * 256, slot + (uint32_t)p * 1024u);
-  }
-  if ((c & 1) == 0 && wave == 0)
-    co_lds_dma_1k(src + 4 * M3_STEP_WORDS(2), lds_base + (3 * M3W_SLOT_WORDS + M3W_XCH_WORDS + ((c >> 1) % 3) * M3W_BIAS_WORDS) * 4u);
-}
-
-/* K steps S0 .. S0 + NS - 1 for the two output tiles tile0, tile0 + 1 (m3_steps with half of the tiles) */
-template <int S0, int NS, int XT, bool F16>
-__device__ __forceinline__ void m3w_steps(m3_f32x16 (&acc)[2], const uint32_t (&b)[2][8][4], const uint32_t *wl, int tile0, int lane) {
-  m3_u32x4 a[2][2][2];
-#pragma unroll
-  for (int to = 0; to < 2; ++to)
-#pragma unroll
-    for (int t = 0; t < 2; ++t) a[0][t][to] = *reinterpret_cast<const m3_u32x4 *>(wl + (((0 * 4 + tile0 + to) * 2 + t) * 64 + lane) * 4);
-#pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    const int cur = s & 1, nxt = cur ^ 1;
-    if (s + 1 < NS) {
-#pragma unroll
-      for (int to = 0; to < 2; ++to)
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-          a[nxt][t][to] = *reinterpret_cast<const m3_u32x4 *>(wl + ((((s + 1) * 4 + tile0 + to) * 2 + t) * 64 + lane) * 4);
-    }
-    m3_u32x4 B[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-#pragma unroll
-      for (int m = 0; m < 4; ++m) B[t][m] = b[t][S0 + s][m];
-    }
-#pragma unroll
-    for (int sum = 0; sum < 2; ++sum)
-#pragma unroll
-      for (int i = 0; i <= sum; ++i)
-        if (sum - i < XT) {
-#pragma unroll
-          for (int to = 0; to < 2; ++to) {
-            if constexpr (F16)
-              acc[to] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(m3_f16x8, a[cur][i][to]),
-                                                               __builtin_bit_cast(m3_f16x8, B[sum - i]), acc[to], 0, 0, 0);
-            else
-              acc[to] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(m3_bf16x8, a[cur][i][to]),
-                                                                __builtin_bit_cast(m3_bf16x8, B[sum - i]), acc[to], 0, 0, 0);
-          }
-        }
-  }
-}
-
-/* the body for one half of the output tiles (fh: a template parameter, so that every operand register is named at compile
- * time -- with fh a run-time value the compiler branches around each of the epilogue's 64 register moves) */
-template <bool F16, int fh>
-__device__ __forceinline__ void m3w_body(uint32_t *m3_lds, const float *__restrict__ in, int rows, int row0, const uint32_t *__restrict__ wfrag,
-                                         float *__restrict__ eval, float *__restrict__ probs, const CoNetIO &io, uint32_t *range_flag, int wave,
-                                         int lane) {
-  const int h = lane >> 5, n = lane & 31;
-  const int rt = wave >> 1;
-  constexpr int tile0 = 2 * fh;
-  const uint32_t lds_base = co_lds_addr(m3_lds);
-  uint32_t *xch = m3_lds + 3 * M3W_SLOT_WORDS + rt * (7 * 2 * 256) + lane * 4;
-  const int row = row0 + rt * 32 + n;
-  uint32_t b[2][8][4];
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int s = 0; s < 8; ++s)
-#pragma unroll
-      for (int m = 0; m < 4; ++m) b[t][s][m] = 0u;
-  if (row < rows) {
-    const float *x = in + (size_t)(io.in_idx ? io.in_idx[row] : row) * CO_STATE_STRIDE;
-#pragma unroll
-    for (int s = 0; s < M3_STEPS_L0; ++s) {
-      const float4 v0 = *reinterpret_cast<const float4 *>(x + 16 * s + 4 * h);
-      const float4 v1 = *reinterpret_cast<const float4 *>(x + 16 * s + 8 + 4 * h);
-      uint32_t t[2];
-      m3_split<2, F16>(v0.x, v0.y, t);
-      b[0][s][0] = t[0];
-      m3_split<2, F16>(v0.z, v0.w, t);
-      b[0][s][1] = t[0];
-      m3_split<2, F16>(v1.x, v1.y, t);
-      b[0][s][2] = t[0];
-      m3_split<2, F16>(v1.z, v1.w, t);
-      b[0][s][3] = t[0];
-    }
-  }
-  m3w_stage(wfrag, lds_base, 0, wave, lane);
-  m3w_stage(wfrag, lds_base, 1, wave, lane);
-  m3_f32x16 acc[2];
-  uint32_t amax = 0u;
-/* top of chunk c: everything this wavefront requested except the youngest chunk (four pieces; wavefront 0's fifth of an
- * even chunk then waits with the older one: harmless) has landed; behind the barrier that holds for every wavefront, and
- * everyone has left the slot of chunk c - 1, which receives chunk c + 2 */
-#define M3W_HEAD(c)                                                            \
-  {                                                                            \
-    if ((c) + 1 < M3_NCHUNKS) CO_WAIT_VMCNT(4);                                \
-    else CO_WAIT_VMCNT(0);                                                     \
-    co_wg_barrier();                                                           \
-    if ((c) + 2 < M3_NCHUNKS) m3w_stage(wfrag, lds_base, (c) + 2, wave, lane); \
-  }
-  for (int l = 0; l < M3_NLAYERS; ++l) {
-    const int c0 = 2 * l;
-    {
-      M3W_HEAD(c0)
-      if (l > 0) {
-        /* the partner's half of this layer's inputs: K steps 2T' + a of its tiles T' (step 7 is padding: never multiplied) */
-#pragma unroll
-        for (int T = 0; T < 2; ++T)
-#pragma unroll
-          for (int a = 0; a < 2; ++a) {
-            const int sp = 2 * (2 * (1 - fh) + T) + a; /* (wave-uniform: fh is) */
-            if (sp < 7) {
-#pragma unroll
-              for (int i = 0; i < 2; ++i) {
-                const m3_u32x4 v = *reinterpret_cast<const m3_u32x4 *>(xch + (sp * 2 + i) * 256);
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                  if (fh) b[i][2 * T + a][m] = v[m];     /* partner = tiles 0, 1: steps 0..3 */
-                  else b[i][4 + 2 * T + a][m] = v[m];    /* partner = tiles 2, 3: steps 4..7 */
-                }
-              }
-            }
-          }
-      }
-      {
-        /* accumulators := bias (feature 32 (tile0 + T) + 8g + 4h + i in register 4g + i of tile T) */
-        const float *bias = reinterpret_cast<const float *>(m3_lds + 3 * M3W_SLOT_WORDS + M3W_XCH_WORDS + (l % 3) * M3W_BIAS_WORDS);
-#pragma unroll
-        for (int T = 0; T < 2; ++T)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const float4 b4 = *reinterpret_cast<const float4 *>(bias + 32 * (tile0 + T) + 8 * g + 4 * h);
-            acc[T][4 * g + 0] = b4.x;
-            acc[T][4 * g + 1] = b4.y;
-            acc[T][4 * g + 2] = b4.z;
-            acc[T][4 * g + 3] = b4.w;
-          }
-      }
-      const uint32_t *wl = m3_lds + (c0 % 3) * M3W_SLOT_WORDS;
-      if (l == 0) m3w_steps<0, 4, 1, F16>(acc, b, wl, tile0, lane);
-      else m3w_steps<0, 4, 2, F16>(acc, b, wl, tile0, lane);
-    }
-    {
-      M3W_HEAD(c0 + 1)
-      const uint32_t *wl = m3_lds + ((c0 + 1) % 3) * M3W_SLOT_WORDS;
-      if (l == 0) m3w_steps<4, M3_STEPS_L0 - 4, 1, F16>(acc, b, wl, tile0, lane);
-      else m3w_steps<4, M3_STEPS - 4, 2, F16>(acc, b, wl, tile0, lane);
-    }
-    if (l + 1 < M3_NLAYERS) {
-      /* ReLU and the two terms of this wavefront's tiles: into its own operand registers and, for the partner, into the
-       * exchange area (read behind the next chunk head's barrier; not overwritten before the one after that) */
-#pragma unroll
-      for (int T = 0; T < 2; ++T)
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-          m3_u32x4 w0, w1;
-#pragma unroll
-          for (int m = 0; m < 4; ++m) {
-            float v0 = acc[T][8 * a + 2 * m], v1 = acc[T][8 * a + 2 * m + 1];
-            v0 = v0 > 0.0f ? v0 : 0.0f;
-            v1 = v1 > 0.0f ? v1 : 0.0f;
-            uint32_t t[2];
-            m3_split<2, F16>(v0, v1, t);
-            if constexpr (F16) asm("v_pk_max_f16 %0, %1, %2" : "=v"(amax) : "v"(amax), "v"(t[0]));
-            w0[m] = t[0];
-            w1[m] = t[1];
-            if (fh) {
-              b[0][4 + 2 * T + a][m] = t[0];
-              b[1][4 + 2 * T + a][m] = t[1];
-            } else {
-              b[0][2 * T + a][m] = t[0];
-              b[1][2 * T + a][m] = t[1];
-            }
-          }
-          const int so = 2 * (tile0 + T) + a;
-          if (so < 7) {
-            *reinterpret_cast<m3_u32x4 *>(xch + (so * 2 + 0) * 256) = w0;
-            *reinterpret_cast<m3_u32x4 *>(xch + (so * 2 + 1) * 256) = w1;
-          }
-        }
-    }
-  }
-#undef M3W_HEAD
-  if constexpr (F16) {
-    if (!((amax & 0x7FFFu) < 0x7C00u && ((amax >> 16) & 0x7FFFu) < 0x7C00u)) atomicOr(range_flag, 1u);
-  }
-  /* heads.  Tiles 0..2 are the policy logits, register 0 of tile 3 (h = 0) the value: the upper wavefront of a pair hands
-   * tile 2 and that register over (floats, in the exchange area), the lower one finishes the rows */
-  float *xf = reinterpret_cast<float *>(m3_lds + 3 * M3W_SLOT_WORDS) + rt * (17 * 64) + lane;
-  if (fh) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) xf[r * 64] = acc[0][r];
-    xf[16 * 64] = acc[1][0];
-  }
-  __syncthreads();
-  if (fh) return;
-  m3_f32x16 full[3];
-  full[0] = acc[0];
-  full[1] = acc[1];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) full[2][r] = xf[r * 64];
-  const float value_logit = xf[16 * 64];
-  float mx = -INFINITY;
-#pragma unroll
-  for (int T = 0; T < 3; ++T)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) mx = full[T][r] > mx ? full[T][r] : mx;
-  float o = __shfl_xor(mx, 32, 64);
-  mx = o > mx ? o : mx;
-  float sum = 0.0f;
-#pragma unroll
-  for (int T = 0; T < 3; ++T)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      full[T][r] = __builtin_amdgcn_exp2f((full[T][r] - mx) * 1.44269504088896340736f);
-      sum += full[T][r];
-    }
-  sum += __shfl_xor(sum, 32, 64);
-  const float inv = 1.0f / sum;
-  if (row < rows) {
-    const size_t orow = (size_t)(io.out_idx ? io.out_idx[row] : row);
-#pragma unroll
-    for (int T = 0; T < 3; ++T)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float4 p = make_float4(full[T][4 * g] * inv, full[T][4 * g + 1] * inv, full[T][4 * g + 2] * inv, full[T][4 * g + 3] * inv);
-        *reinterpret_cast<float4 *>(probs + orow * (size_t)io.probs_stride + 32 * T + 8 * g + 4 * h) = p;
-      }
-    if (h == 0) eval[orow * (size_t)io.eval_stride] = tanhf(value_logit);
-  }
-}
-template <bool F16>
-__global__ __launch_bounds__(512, 1) void co_k_mlp_forward_split_w(const float *__restrict__ in, const int32_t *__restrict__ d_rows,
-                                                                   const uint32_t *__restrict__ wfrag, float *__restrict__ eval,
-                                                                   float *__restrict__ probs, CoNetIO io, uint32_t *range_flag) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t m3_lds[]; /* three fragment slots, the exchange area, the bias ring */
-  const int rows = *d_rows;
-  const int row0 = blockIdx.x * M3_ROWS_PER_WG;
-  if (row0 >= rows) return;
-  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  if (wave & 1) m3w_body<F16, 1>(m3_lds, in, rows, row0, wfrag, eval, probs, io, range_flag, wave, lane);
-  else m3w_body<F16, 0>(m3_lds, in, rows, row0, wfrag, eval, probs, io, range_flag, wave, lane);
-}
-#define co_k_mlp_forward_h3w co_k_mlp_forward_split_w<true>
-#define co_k_mlp_forward_x3w co_k_mlp_forward_split_w<false>
-
 #define co_k_mlp_forward_x3 co_k_mlp_forward_split_t<2>
 #define co_k_mlp_forward_x6 co_k_mlp_forward_split_t<3>
 /* "f16x3": two fp16 terms per operand (22 significand bits), three MFMA products -- see nn_rescnn.hip */
@@ -709,13 +423,10 @@ struct MlpSplitNet : CoNet {
     rt_h2d(d_w, buf.data(), buf.size() * 4, s);
     if (f16) rt_malloc((void **)&d_range, 4, s);
     rt_sync(s);
-    if (f16) {
+    if (f16)
       RT_CHECK(hipFuncSetAttribute((const void *)co_k_mlp_forward_h3, hipFuncAttributeMaxDynamicSharedMemorySize, M3_LDS_BYTES(2)));
-      RT_CHECK(hipFuncSetAttribute((const void *)co_k_mlp_forward_h3w, hipFuncAttributeMaxDynamicSharedMemorySize, M3W_LDS_BYTES));
-    } else if (nt == 2) {
+    else if (nt == 2)
       RT_CHECK(hipFuncSetAttribute((const void *)co_k_mlp_forward_x3, hipFuncAttributeMaxDynamicSharedMemorySize, M3_LDS_BYTES(2)));
-      RT_CHECK(hipFuncSetAttribute((const void *)co_k_mlp_forward_x3w, hipFuncAttributeMaxDynamicSharedMemorySize, M3W_LDS_BYTES));
-    }
     else
       RT_CHECK(hipFuncSetAttribute((const void *)co_k_mlp_forward_x6, hipFuncAttributeMaxDynamicSharedMemorySize, M3_LDS_BYTES(3)));
   }
@@ -737,17 +448,8 @@ struct MlpSplitNet : CoNet {
                rt_stream_t s, const CoNetIO &io = CoNetIO()) override {
     int grid = (rows_cap + M3_ROWS_PER_WG - 1) / M3_ROWS_PER_WG;
     if (grid < 1) return;
-#ifndef CO_MLP_WIDE
-#define CO_MLP_WIDE 1 /* 0: a diagnostic build with the four-wavefront kernels of rounds 2-5 for the two-term kinds */
-#endif
-    if (f16 && CO_MLP_WIDE)
-      hipLaunchKernelGGL(co_k_mlp_forward_h3w, dim3(grid), dim3(512), M3W_LDS_BYTES, s, d_in, d_rows, (const uint32_t *)d_w, d_eval,
-                         d_probs, io, d_range);
-    else if (f16)
+    if (f16)
       hipLaunchKernelGGL(co_k_mlp_forward_h3, dim3(grid), dim3(256), M3_LDS_BYTES(2), s, d_in, d_rows, (const uint32_t *)d_w, d_eval,
-                         d_probs, io, d_range);
-    else if (nt == 2 && CO_MLP_WIDE)
-      hipLaunchKernelGGL(co_k_mlp_forward_x3w, dim3(grid), dim3(512), M3W_LDS_BYTES, s, d_in, d_rows, (const uint32_t *)d_w, d_eval,
                          d_probs, io, d_range);
     else if (nt == 2)
       hipLaunchKernelGGL(co_k_mlp_forward_x3, dim3(grid), dim3(256), M3_LDS_BYTES(2), s, d_in, d_rows, (const uint32_t *)d_w, d_eval,
