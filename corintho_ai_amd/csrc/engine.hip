@@ -998,78 +998,78 @@ struct ca_trainer {
     nets[slot]->forward(d_in, rows_cap, d_rows, d_eval, d_probs, stream);
   }
 
-  /* Fused training as independent pools of games on separate streams (DESIGN.md section 6):
-   * every pool runs the loop of main.pyx:142-168 on its own slice of the game arrays and of
-   * the batch buffers; the GPU overlaps one pool's search kernel with another's network
-   * kernel and fills launch tails.  Per-game results do not depend on the pooling. */
-  bool run_pools(int64_t max_iterations, int npools) {
-    const int poll = CO_POOL_POLL;
-    if ((int)pools.size() != npools) {
-      free_pools();
-      pools.resize(npools);
-      for (int p = 0; p < npools; ++p) {
-        Pool &q = pools[p];
-#ifdef CO_EXP_CU_MASK /* diagnostic build (profiles/r06_cu_mask.md): every pool's stream on its own share of the compute units */
-        rt_stream_create_masked(&q.st, p, npools, CO_EXP_CU_MASK);
+  /* the pools of a fused run: streams, events, the host words the counters are copied to, and -- with the evaluation
+   * cache -- ONE table for all of them plus every pool's index and counter arrays */
+  void pools_create(int npools) {
+    free_pools();
+    pools.resize(npools);
+    for (int p = 0; p < npools; ++p) {
+      Pool &q = pools[p];
+#ifdef CO_EXP_CU_MASK /* diagnostic build (profiles/r06_coresident.md): every pool's stream on its own share of the compute units */
+      rt_stream_create_masked(&q.st, p, npools, CO_EXP_CU_MASK);
 #else
-        rt_stream_create(&q.st);
+      rt_stream_create(&q.st);
 #endif
-        q.lo = (int)((int64_t)R * p / npools);
-        q.n = (int)((int64_t)R * (p + 1) / npools) - q.lo;
-        q.row_base = q.lo * spe;
-        for (int w = 0; w < 2; ++w) {
-          for (auto &e : q.ev[w]) rt_event_create(&e);
-          rt_event_create(&q.polled[w]);
-        }
-        rt_host_alloc((void **)&q.word, 32);
-        memset(q.word, 0, 32);
-        memset(&q.cache, 0, sizeof q.cache);
-        rt_event_create(&q.quiet);
-        if (use_cache()) {
-          if (p == 0) {
-            /* ONE table for all pools: a power of two of at least 8192 entries per slot (a 4096-game generation at 400
-             * simulations asks for ~4100 distinct positions per game), within 1/6 of the free device memory */
-            size_t want = (size_t)R * 8192, n = 1;
-            while (n < want) n <<= 1;
-            const size_t per = 16 + CO_CACHE_VAL_FLOATS * 4;
-            while (n > 1024 && n * per > rt_mem_free() / 6) n >>= 1;
-            if (cfg.eval_cache > 0) { /* given */
-              n = (size_t)1 << (cfg.eval_cache < 6 ? 6 : cfg.eval_cache > 30 ? 30 : cfg.eval_cache);
-              if (n * per > rt_mem_free() / 2)
-                throw EngineError(CA_ERR_ARG, "ca_config.eval_cache: a table of 2^" + std::to_string(cfg.eval_cache) +
-                                                  " entries does not fit in the free device memory");
-            }
-            q.c_entries = n;
-            rt_malloc((void **)&q.c_hdr, n * 16, q.st);
-            /* table values + one scratch element per request row of every pool */
-            rt_malloc((void **)&q.c_val, (n + (size_t)R * spe) * CO_CACHE_VAL_FLOATS * 4, q.st);
-            rt_malloc((void **)&q.c_done, 4 * CO_MAX_POOLS, q.st);
-          } else {
-            q.c_entries = pools[0].c_entries;
-            q.c_hdr = pools[0].c_hdr;
-            q.c_val = pools[0].c_val;
-            q.c_done = pools[0].c_done;
-          }
-          const size_t rows = (size_t)q.n * spe;
-          rt_malloc((void **)&q.c_in_idx, rows * 4, q.st);
-          rt_malloc((void **)&q.c_out_idx, rows * 4, q.st);
-          rt_malloc((void **)&q.c_count, 32, q.st);
-          rt_malloc((void **)&q.c_totals, 16, q.st);
-          q.cache.hdr = q.c_hdr;
-          q.cache.val = q.c_val;
-          q.cache.mask = (uint32_t)(q.c_entries - 1);
-          q.cache.scratch_base = (uint32_t)q.row_base;
-          q.cache.pool_bits = (uint32_t)p << CO_CACHE_POOL_SHIFT;
-          q.cache.done = q.c_done;
-          q.cache.in_idx = q.c_in_idx;
-          q.cache.out_idx = q.c_out_idx;
-          q.cache.count = q.c_count;
-          q.cache.totals = q.c_totals;
-          rt_sync(q.st);
-        }
+      q.lo = (int)((int64_t)R * p / npools);
+      q.n = (int)((int64_t)R * (p + 1) / npools) - q.lo;
+      q.row_base = q.lo * spe;
+      for (int w = 0; w < 2; ++w) {
+        for (auto &e : q.ev[w]) rt_event_create(&e);
+        rt_event_create(&q.polled[w]);
       }
-      cache_clean = true; /* freshly zeroed */
+      rt_host_alloc((void **)&q.word, 32);
+      memset(q.word, 0, 32);
+      memset(&q.cache, 0, sizeof q.cache);
+      rt_event_create(&q.quiet);
+      if (use_cache()) {
+        if (p == 0) {
+          /* ONE table for all pools: a power of two of at least 8192 entries per slot (a 4096-game generation at 400
+           * simulations asks for ~4100 distinct positions per game), within 1/6 of the free device memory */
+          size_t want = (size_t)R * 8192, n = 1;
+          while (n < want) n <<= 1;
+          const size_t per = 16 + CO_CACHE_VAL_FLOATS * 4;
+          while (n > 1024 && n * per > rt_mem_free() / 6) n >>= 1;
+          if (cfg.eval_cache > 0) { /* given */
+            n = (size_t)1 << (cfg.eval_cache < 6 ? 6 : cfg.eval_cache > 30 ? 30 : cfg.eval_cache);
+            if (n * per > rt_mem_free() / 2)
+              throw EngineError(CA_ERR_ARG, "ca_config.eval_cache: a table of 2^" + std::to_string(cfg.eval_cache) +
+                                                " entries does not fit in the free device memory");
+          }
+          q.c_entries = n;
+          rt_malloc((void **)&q.c_hdr, n * 16, q.st);
+          /* table values + one scratch element per request row of every pool */
+          rt_malloc((void **)&q.c_val, (n + (size_t)R * spe) * CO_CACHE_VAL_FLOATS * 4, q.st);
+          rt_malloc((void **)&q.c_done, 4 * CO_MAX_POOLS, q.st);
+        } else {
+          q.c_entries = pools[0].c_entries;
+          q.c_hdr = pools[0].c_hdr;
+          q.c_val = pools[0].c_val;
+          q.c_done = pools[0].c_done;
+        }
+        const size_t rows = (size_t)q.n * spe;
+        rt_malloc((void **)&q.c_in_idx, rows * 4, q.st);
+        rt_malloc((void **)&q.c_out_idx, rows * 4, q.st);
+        rt_malloc((void **)&q.c_count, 32, q.st);
+        rt_malloc((void **)&q.c_totals, 16, q.st);
+        q.cache.hdr = q.c_hdr;
+        q.cache.val = q.c_val;
+        q.cache.mask = (uint32_t)(q.c_entries - 1);
+        q.cache.scratch_base = (uint32_t)q.row_base;
+        q.cache.pool_bits = (uint32_t)p << CO_CACHE_POOL_SHIFT;
+        q.cache.done = q.c_done;
+        q.cache.in_idx = q.c_in_idx;
+        q.cache.out_idx = q.c_out_idx;
+        q.cache.count = q.c_count;
+        q.cache.totals = q.c_totals;
+        rt_sync(q.st);
+      }
     }
+    cache_clean = true; /* freshly zeroed */
+  }
+
+  /* a run starts: an emptied table when the generation does (or a new network came), the pools' host-side state.
+   * Returns whether the table was emptied here. */
+  bool pools_begin_run() {
     const bool cache_clean_now = use_cache() && !cache_clean;
     if (use_cache() && !cache_clean) {
       /* a generation starts with an empty table: nothing evaluated in an earlier generation is carried over */
@@ -1096,188 +1096,48 @@ struct ca_trainer {
       q.first_start = P.stagger_div > 0 ? (P.game_base + q.lo) / P.stagger_div : 0;
       if (cache_clean_now) q.c_inserted_est = 0;
     }
-    rt_sync(stream);
-    P.to_play = -1;
-    P.row_counter = nullptr;
-    P.fused_pack = 1;
-    P.defer_handover = 1;
-    int64_t it = 0;
-    int in_window = 0, window = 0;
-    bool all_finished = false;
-    std::string failure;
-    /* The host never waits for the window it has just queued: at the end of window w it queues
-     * an asynchronous copy of each pool's counter and then reads the copy made at the end of
-     * window w-1, so every stream always holds at least one window of work.  A pool is
-     * therefore seen to be finished one window late; the launches in between find no running
-     * game and no batch row. */
-    auto collect = [&](Pool &q, int parity) {
-      if (!q.launched[parity]) return;
-      rt_event_sync(q.polled[parity]);
-      unsigned long long c = q.word[parity];
-      const unsigned long long evaluated = q.cache.hdr ? q.word[2 + parity] & 0xFFFFFFFFull : c & 0xFFFFFFFFull;
-      q.running = (int)((c >> 32) & 0xFFFFFFull); /* (bits 56..: games of the iteration that held their leaves back, mcts.h co_step_tail) */
-      const bool holding = (c >> 56) != 0;
-      if (q.timed[parity]) {
-        /* one iteration per window is timed (three event records per launch pair cost 1-4 % of
-         * the wall time); its batch size is the counter word just read */
-        mcts_timed_ms += rt_event_elapsed_ms(q.ev[parity][0], q.ev[parity][1]);
-        pack_timed_ms += rt_event_elapsed_ms(q.ev[parity][1], q.ev[parity][2]); /* cache probe (nothing without a cache) */
-        nn_timed_ms += rt_event_elapsed_ms(q.ev[parity][2], q.ev[parity][3]);
-        nn_timed_rows += (int64_t)evaluated; /* rows the network kernel worked on */
-        q.c_inserted_est += (double)evaluated * poll; /* every evaluated row takes a table entry */
-        ++timed_launches;
-        q.timed[parity] = 0;
-      }
-      q.launched[parity] = 0;
-      q.finished = ((c >> 32) & 0xFFFFFFull) == 0;
-      if (!q.finished && (c & 0xFFFFFFFFull) == 0 && !holding) {
-        /* main.pyx:161-163 raises when NO game has a request.  A pool whose first game the
-         * staggered start (trainer.cpp:184-186) has not released yet has running games and no
-         * rows by construction: that is not the reference's error condition */
-        /* (an iteration whose games all stopped at their step budget has no rows either -- `holding`: that is not it) */
-        if (q.word_iter[parity] > q.first_start && ++q.idle > 16) failure = "No requests during training";
-      } else {
-        q.idle = 0;
-      }
-    };
-    /* the table was emptied in mid-generation (a new network, set_net): pending leaves point into its old contents */
-    bool emptied_before_resuming = cache_clean_now && iterations > 0;
-    long long guard_from = -1; /* the no-claim iteration behind the last emptying in mid-generation (EvalCache::guard_from) */
-    while (!all_finished && (max_iterations <= 0 || it < max_iterations)) {
-      const int parity = window & 1;
-      bool emptied = emptied_before_resuming; /* (EvalCache::no_claim) */
-      emptied_before_resuming = false;
-      if (pools[0].cache.hdr) {
-        double taken = 0;
-        for (auto &q : pools) taken += q.c_inserted_est;
-        if (taken > 0.5 * (double)pools[0].c_entries) {
-          /* the table is half full: start over (a long generation asks for far more positions than any table holds;
-           * what is asked for again is mostly recent -- the trees of the games in play).  Between two iterations of
-           * EVERY pool, when no entry is pending: each stream has the same iterations queued at this point; pool 0's
-           * stream waits for the others to get here, empties the table, and the others wait for that. */
-          for (int p = 1; p < npools; ++p) {
-            rt_event_record(pools[p].quiet, pools[p].st);
-            rt_stream_wait(pools[0].st, pools[p].quiet);
-          }
-          rt_memset(pools[0].c_hdr, 0, pools[0].c_entries * 16, pools[0].st);
-          rt_event_record(pools[0].quiet, pools[0].st);
-          for (int p = 1; p < npools; ++p) rt_stream_wait(pools[p].st, pools[0].quiet);
-          for (auto &q : pools) q.c_inserted_est = 0;
-          ++cache_clears;
-          emptied = true;
-        }
-      }
-      for (int p = 0; p < npools; ++p) {
-        Pool &q = pools[p];
-        if (q.finished) continue;
-        EngineParams pp = P;
-        pp.iteration = trainer_iteration;
-        /* Deferring the new mover's first searches to the next step (mcts.h co_game_step) balances
-         * the waves of a full launch but costs the game one more iteration per ply; once the pool
-         * has thinned out, an iteration is as long as its slowest wave anyway and the number of
-         * iterations of the longest game is what the generation waits for.  Per-game results do
-         * not depend on the choice. */
-        pp.defer_handover = q.running * 2 > q.n ? 1 : 0;
-        pp.pool_lo = q.lo;
-        pp.pool_n = q.n;
-        pp.pool_row_base = q.row_base;
-        pp.pack_counter = pack_counter.p + CO_PACK_STRIDE * p;
-        pp.work_counter = work_counter.p + (size_t)CO_WC_WORDS * p;
-        /* (Measured and not done: no automatic budget for a thin pool -- the last eighth of a pool's games, or a trainer of
-         * 64 -- on the reasoning that stopping the longest game's steps only adds iterations to its chain: 386.4 against 382.6
-         * ms per default generation, 120.7 against 115.3 with the MLP, 95.3 against 93.9 at 64 games.  A thin launch waits for
-         * its slowest wavefront like any other.) */
-        pp.cache = q.cache; /* (hdr null: no cache) */
-        pp.cache.no_claim = emptied ? 1u : 0u;
-        if (emptied) guard_from = trainer_iteration;
-        pp.cache.guard_pools = 0u;
-        if (guard_from >= 0 && trainer_iteration <= guard_from + 2 * poll + 1) {
-          /* (the streams are within two windows of each other: the host waits for window w - 1 before it queues w + 1) */
-          pp.cache.guard_from = (uint32_t)guard_from;
-          /* the OTHER pools only: this pool's own reads of the old contents happened in its launch of iteration
-           * guard_from, which stands in front of this launch in its stream -- with its own bit set, every wavefront
-           * that runs before the launch's first wave has stored done[p] would lose its claims for nothing */
-          for (int p2 = 0; p2 < npools; ++p2)
-            if (p2 != p && !pools[p2].finished) pp.cache.guard_pools |= 1u << p2;
-        }
-        const bool timed = in_window == poll - 1 || (max_iterations > 0 && it + 1 == max_iterations);
-        /* The network launch is sized by what the batch can hold: the games still running at the pool's last poll (they
-         * only become fewer) times the searches per evaluation.  In a generation's thin tail the throughput kernel is
-         * then not launched at all and the small-batch kernel's grid shrinks -- a launch whose workgroups all leave at
-         * once still costs their dispatch (for the pixel-major kernel: one 160 KB LDS allocation per 32 rows of capacity). */
-        const int cap_rows = (q.running < q.n ? (q.running > 0 ? q.running : 1) : q.n) * spe;
-        rt_event_t *e = q.ev[parity];
-        if (timed) rt_event_record(e[0], q.st);
-        RT_LAUNCH(co_k_mcts_step, ((q.n) + CO_K3_WAVES - 1) / CO_K3_WAVES, CO_WAVE * CO_K3_WAVES, q.st, pp);
-        if (timed) rt_event_record(e[1], q.st);
-        if (q.cache.hdr) {
-          /* the search kernel has resolved every request row to an element of the cache's value array; the network
-           * evaluates the rows whose position has no entry yet, reading them through in_idx and writing straight to
-           * out_idx */
-          if (timed) rt_event_record(e[2], q.st);
-          CoNetIO io;
-          io.in_idx = q.c_in_idx;
-          io.out_idx = q.c_out_idx;
-          io.eval_stride = CO_CACHE_VAL_FLOATS;
-          io.probs_stride = CO_CACHE_VAL_FLOATS;
-          io.alone = npools == 1;
-          net_used = true;
-          nets[0]->forward(req.p, cap_rows, (const int32_t *)(q.c_count + 4 * (trainer_iteration & 1)), q.c_val, q.c_val + 4, q.st, io);
-          if (timed) rt_event_record(e[3], q.st);
-        } else {
-          if (timed) rt_event_record(e[2], q.st);
-          const int32_t *d_rows = (const int32_t *)(pack_counter.p + CO_PACK_STRIDE * p + (trainer_iteration & 1));
-          CoNetIO io;
-          io.alone = npools == 1;
-          io.in_idx = row_idx.p + q.row_base; /* the rows stay where the games wrote them (co_step_tail) */
-          net_used = true;
-          nets[0]->forward(req.p, cap_rows, d_rows, nn_eval.p + q.row_base, nn_probs.p + (size_t)q.row_base * CO_NUM_MOVES, q.st, io);
-          if (timed) rt_event_record(e[3], q.st);
-        }
-        if (timed) q.timed[parity] = 1;
-        q.launched[parity] = in_window + 1;
-        ++mcts_launches;
-        ++nn_launches;
-      }
-      const int counter_slot = trainer_iteration & 1;
-      ++trainer_iteration;
-      ++iterations;
-      ++it;
-      ++in_window;
-      if (in_window == poll || (max_iterations > 0 && it == max_iterations)) {
-        for (auto &q : pools) {
-          if (q.finished) continue;
-          rt_d2h(&q.word[parity], pack_counter.p + CO_PACK_STRIDE * (&q - &pools[0]) + counter_slot, 8, q.st);
-          if (q.cache.hdr) rt_d2h(&q.word[2 + parity], q.c_count + 4 * counter_slot, 4, q.st);
-          q.word_iter[parity] = trainer_iteration - 1;
-          rt_event_record(q.polled[parity], q.st);
-        }
-        all_finished = true;
-        for (auto &q : pools) {
-          if (!q.finished) collect(q, parity ^ 1);
-          if (!q.finished) all_finished = false;
-        }
-        in_window = 0;
-        ++window;
-        if (!failure.empty()) break;
-      }
+    return cache_clean_now;
+  }
+
+  /* The host never waits for the window it has just queued: at the end of window w it queues
+   * an asynchronous copy of each pool's counter and then reads the copy made at the end of
+   * window w-1, so every stream always holds at least one window of work.  A pool is
+   * therefore seen to be finished one window late; the launches in between find no running
+   * game and no batch row. */
+  void pool_collect(Pool &q, int parity, int poll, std::string &failure) {
+    if (!q.launched[parity]) return;
+    rt_event_sync(q.polled[parity]);
+    unsigned long long c = q.word[parity];
+    const unsigned long long evaluated = q.cache.hdr ? q.word[2 + parity] & 0xFFFFFFFFull : c & 0xFFFFFFFFull;
+    q.running = (int)((c >> 32) & 0xFFFFFFull); /* (bits 56..: games of the iteration that held their leaves back, mcts.h co_step_tail) */
+    const bool holding = (c >> 56) != 0;
+    if (q.timed[parity]) {
+      /* one iteration per window is timed (three event records per launch pair cost 1-4 % of
+       * the wall time); its batch size is the counter word just read */
+      mcts_timed_ms += rt_event_elapsed_ms(q.ev[parity][0], q.ev[parity][1]);
+      pack_timed_ms += rt_event_elapsed_ms(q.ev[parity][1], q.ev[parity][2]); /* cache probe (nothing without a cache) */
+      nn_timed_ms += rt_event_elapsed_ms(q.ev[parity][2], q.ev[parity][3]);
+      nn_timed_rows += (int64_t)evaluated; /* rows the network kernel worked on */
+      q.c_inserted_est += (double)evaluated * poll; /* every evaluated row takes a table entry */
+      ++timed_launches;
+      q.timed[parity] = 0;
     }
-    /* drain: read what is still in flight (the last window, or both after an iteration cap).  EVERY pool's stream is
-     * synchronised here, whichever way the loop ended: that is what allows `guard_from` to be a local of this call -- a
-     * later call (an iteration-capped run resumed) starts with no launch of any pool in flight, so no pool can still be
-     * reading elements of a table emptied in an earlier call. */
-    for (auto &q : pools) {
-      rt_sync(q.st);
-      for (int w = 0; w < 2; ++w) collect(q, (window + w) & 1);
+    q.launched[parity] = 0;
+    q.finished = ((c >> 32) & 0xFFFFFFull) == 0;
+    if (!q.finished && (c & 0xFFFFFFFFull) == 0 && !holding) {
+      /* main.pyx:161-163 raises when NO game has a request.  A pool whose first game the
+       * staggered start (trainer.cpp:184-186) has not released yet has running games and no
+       * rows by construction: that is not the reference's error condition */
+      /* (an iteration whose games all stopped at their step budget has no rows either -- `holding`: that is not it) */
+      if (q.word_iter[parity] > q.first_start && ++q.idle > 16) failure = "No requests during training";
+    } else {
+      q.idle = 0;
     }
-    P.fused_pack = 0;
-    P.defer_handover = 0;
-    P.pool_lo = 0;
-    P.pool_n = R;
-    P.pool_row_base = 0;
-    P.pack_counter = pack_counter.p;
-    host_games_valid = false;
-    scan_valid = false;
+  }
+
+  /* a run is over (its streams are drained): device times from the timed launches, errors, the rows evaluated, the step
+   * budget's statistics */
+  void pools_finish_run(const std::string &failure) {
     if (timed_launches > 0) {
       /* device time by kernel family, estimated from the timed launches */
       mcts_ms = mcts_timed_ms * (double)mcts_launches / (double)timed_launches;
@@ -1303,7 +1163,7 @@ struct ca_trainer {
       }
     }
     {
-      /* step budget: [7] of a pool's words counts the steps that were cut, [3], [4] hold the last two budgets */
+      /* step budget: a pool's word CO_WC_CUTS counts the steps that were cut, CO_WC_BUDGET + {0, 1} hold the last two budgets */
       std::vector<unsigned long long> wc((size_t)CO_WC_WORDS * CO_MAX_POOLS);
       rt_d2h(wc.data(), work_counter.p, wc.size() * 8, stream);
       rt_sync(stream);
@@ -1312,6 +1172,174 @@ struct ca_trainer {
       step_budget_last = P.step_budget > 0 ? P.step_budget : (int64_t)std::max(wc[CO_WC_BUDGET], wc[CO_WC_BUDGET + 1]) / CO_STEP_UNITS_PER_CONFIG_UNIT;
     }
     if (timed_launches > 0) pack_ms = pack_timed_ms * (double)nn_launches / (double)timed_launches;
+  }
+
+  /* The table is half full: start over (returns true).  Between two iterations of EVERY pool, when no entry is pending. */
+  bool cache_empty_when_half_full(int npools) {
+    if (!pools[0].cache.hdr) return false;
+    double taken = 0;
+    for (auto &q : pools) taken += q.c_inserted_est;
+    if (taken > 0.5 * (double)pools[0].c_entries) {
+      /* the table is half full: start over (a long generation asks for far more positions than any table holds;
+       * what is asked for again is mostly recent -- the trees of the games in play).  Between two iterations of
+       * EVERY pool, when no entry is pending: each stream has the same iterations queued at this point; pool 0's
+       * stream waits for the others to get here, empties the table, and the others wait for that. */
+      for (int p = 1; p < npools; ++p) {
+        rt_event_record(pools[p].quiet, pools[p].st);
+        rt_stream_wait(pools[0].st, pools[p].quiet);
+      }
+      rt_memset(pools[0].c_hdr, 0, pools[0].c_entries * 16, pools[0].st);
+      rt_event_record(pools[0].quiet, pools[0].st);
+      for (int p = 1; p < npools; ++p) rt_stream_wait(pools[p].st, pools[0].quiet);
+      for (auto &q : pools) q.c_inserted_est = 0;
+      ++cache_clears;
+      return true;
+    }
+    return false;
+  }
+
+  /* one iteration of pool p on its stream: the search launch (with the step's share of the engine parameters: the pool's
+   * slice, its counters, the evaluation cache's claim rules) and the network launch behind it; `timed`: with HIP events */
+  void pool_queue_iteration(int p, int npools, bool emptied, long long &guard_from, int poll, int parity, int in_window, bool timed) {
+    Pool &q = pools[p];
+    if (q.finished) return;
+    EngineParams pp = P;
+    pp.iteration = trainer_iteration;
+    /* Deferring the new mover's first searches to the next step (mcts.h co_game_step) balances
+     * the waves of a full launch but costs the game one more iteration per ply; once the pool
+     * has thinned out, an iteration is as long as its slowest wave anyway and the number of
+     * iterations of the longest game is what the generation waits for.  Per-game results do
+     * not depend on the choice. */
+    pp.defer_handover = q.running * 2 > q.n ? 1 : 0;
+    pp.pool_lo = q.lo;
+    pp.pool_n = q.n;
+    pp.pool_row_base = q.row_base;
+    pp.pack_counter = pack_counter.p + CO_PACK_STRIDE * p;
+    pp.work_counter = work_counter.p + (size_t)CO_WC_WORDS * p;
+    /* (Measured and not done: no automatic budget for a thin pool -- the last eighth of a pool's games, or a trainer of
+     * 64 -- on the reasoning that stopping the longest game's steps only adds iterations to its chain: 386.4 against 382.6
+     * ms per default generation, 120.7 against 115.3 with the MLP, 95.3 against 93.9 at 64 games.  A thin launch waits for
+     * its slowest wavefront like any other.) */
+    pp.cache = q.cache; /* (hdr null: no cache) */
+    pp.cache.no_claim = emptied ? 1u : 0u;
+    if (emptied) guard_from = trainer_iteration;
+    pp.cache.guard_pools = 0u;
+    if (guard_from >= 0 && trainer_iteration <= guard_from + 2 * poll + 1) {
+      /* (the streams are within two windows of each other: the host waits for window w - 1 before it queues w + 1) */
+      pp.cache.guard_from = (uint32_t)guard_from;
+      /* the OTHER pools only: this pool's own reads of the old contents happened in its launch of iteration
+       * guard_from, which stands in front of this launch in its stream -- with its own bit set, every wavefront
+       * that runs before the launch's first wave has stored done[p] would lose its claims for nothing */
+      for (int p2 = 0; p2 < npools; ++p2)
+        if (p2 != p && !pools[p2].finished) pp.cache.guard_pools |= 1u << p2;
+    }
+    /* The network launch is sized by what the batch can hold: the games still running at the pool's last poll (they
+     * only become fewer) times the searches per evaluation.  In a generation's thin tail the throughput kernel is
+     * then not launched at all and the small-batch kernel's grid shrinks -- a launch whose workgroups all leave at
+     * once still costs their dispatch (for the pixel-major kernel: one 160 KB LDS allocation per 32 rows of capacity). */
+    const int cap_rows = (q.running < q.n ? (q.running > 0 ? q.running : 1) : q.n) * spe;
+    rt_event_t *e = q.ev[parity];
+    if (timed) rt_event_record(e[0], q.st);
+    RT_LAUNCH(co_k_mcts_step, ((q.n) + CO_K3_WAVES - 1) / CO_K3_WAVES, CO_WAVE * CO_K3_WAVES, q.st, pp);
+    if (timed) rt_event_record(e[1], q.st);
+    if (q.cache.hdr) {
+      /* the search kernel has resolved every request row to an element of the cache's value array; the network
+       * evaluates the rows whose position has no entry yet, reading them through in_idx and writing straight to
+       * out_idx */
+      if (timed) rt_event_record(e[2], q.st);
+      CoNetIO io;
+      io.in_idx = q.c_in_idx;
+      io.out_idx = q.c_out_idx;
+      io.eval_stride = CO_CACHE_VAL_FLOATS;
+      io.probs_stride = CO_CACHE_VAL_FLOATS;
+      io.alone = npools == 1;
+      net_used = true;
+      nets[0]->forward(req.p, cap_rows, (const int32_t *)(q.c_count + 4 * (trainer_iteration & 1)), q.c_val, q.c_val + 4, q.st, io);
+      if (timed) rt_event_record(e[3], q.st);
+    } else {
+      if (timed) rt_event_record(e[2], q.st);
+      const int32_t *d_rows = (const int32_t *)(pack_counter.p + CO_PACK_STRIDE * p + (trainer_iteration & 1));
+      CoNetIO io;
+      io.alone = npools == 1;
+      io.in_idx = row_idx.p + q.row_base; /* the rows stay where the games wrote them (co_step_tail) */
+      net_used = true;
+      nets[0]->forward(req.p, cap_rows, d_rows, nn_eval.p + q.row_base, nn_probs.p + (size_t)q.row_base * CO_NUM_MOVES, q.st, io);
+      if (timed) rt_event_record(e[3], q.st);
+    }
+    if (timed) q.timed[parity] = 1;
+    q.launched[parity] = in_window + 1;
+    ++mcts_launches;
+    ++nn_launches;
+  }
+
+  /* Fused training as independent pools of games on separate streams (DESIGN.md section 6):
+   * every pool runs the loop of main.pyx:142-168 on its own slice of the game arrays and of
+   * the batch buffers; the GPU overlaps one pool's search kernel with another's network
+   * kernel and fills launch tails.  Per-game results do not depend on the pooling. */
+  bool run_pools(int64_t max_iterations, int npools) {
+    const int poll = CO_POOL_POLL;
+    if ((int)pools.size() != npools) pools_create(npools);
+    const bool cache_clean_now = pools_begin_run();
+    rt_sync(stream);
+    P.to_play = -1;
+    P.row_counter = nullptr;
+    P.fused_pack = 1;
+    P.defer_handover = 1;
+    int64_t it = 0;
+    int in_window = 0, window = 0;
+    bool all_finished = false;
+    std::string failure;
+    /* the table was emptied in mid-generation (a new network, set_net): pending leaves point into its old contents */
+    bool emptied_before_resuming = cache_clean_now && iterations > 0;
+    long long guard_from = -1; /* the no-claim iteration behind the last emptying in mid-generation (EvalCache::guard_from) */
+    while (!all_finished && (max_iterations <= 0 || it < max_iterations)) {
+      const int parity = window & 1;
+      bool emptied = emptied_before_resuming; /* (EvalCache::no_claim) */
+      emptied_before_resuming = false;
+      if (cache_empty_when_half_full(npools)) emptied = true;
+      for (int p = 0; p < npools; ++p)
+        pool_queue_iteration(p, npools, emptied, guard_from, poll, parity, in_window,
+                             in_window == poll - 1 || (max_iterations > 0 && it + 1 == max_iterations));
+      const int counter_slot = trainer_iteration & 1;
+      ++trainer_iteration;
+      ++iterations;
+      ++it;
+      ++in_window;
+      if (in_window == poll || (max_iterations > 0 && it == max_iterations)) {
+        for (auto &q : pools) {
+          if (q.finished) continue;
+          rt_d2h(&q.word[parity], pack_counter.p + CO_PACK_STRIDE * (&q - &pools[0]) + counter_slot, 8, q.st);
+          if (q.cache.hdr) rt_d2h(&q.word[2 + parity], q.c_count + 4 * counter_slot, 4, q.st);
+          q.word_iter[parity] = trainer_iteration - 1;
+          rt_event_record(q.polled[parity], q.st);
+        }
+        all_finished = true;
+        for (auto &q : pools) {
+          if (!q.finished) pool_collect(q, parity ^ 1, poll, failure);
+          if (!q.finished) all_finished = false;
+        }
+        in_window = 0;
+        ++window;
+        if (!failure.empty()) break;
+      }
+    }
+    /* drain: read what is still in flight (the last window, or both after an iteration cap).  EVERY pool's stream is
+     * synchronised here, whichever way the loop ended: that is what allows `guard_from` to be a local of this call -- a
+     * later call (an iteration-capped run resumed) starts with no launch of any pool in flight, so no pool can still be
+     * reading elements of a table emptied in an earlier call. */
+    for (auto &q : pools) {
+      rt_sync(q.st);
+      for (int w = 0; w < 2; ++w) pool_collect(q, (window + w) & 1, poll, failure);
+    }
+    P.fused_pack = 0;
+    P.defer_handover = 0;
+    P.pool_lo = 0;
+    P.pool_n = R;
+    P.pool_row_base = 0;
+    P.pack_counter = pack_counter.p;
+    host_games_valid = false;
+    scan_valid = false;
+    pools_finish_run(failure);
     return finished;
   }
 
