@@ -2656,14 +2656,15 @@ CO_DEV void co_pool_housekeeping(const EngineParams &P, int g) {
       if (lane == 0) {
         P.pack_counter[(P.iteration + 1) & 1] = 0ull;
         if (P.work_counter) {
-          /* step budget that follows the games (EngineParams::step_budget_k16): this launch's first wavefront turns the
-           * scans of the launch before (complete: a kernel boundary lies between) into the budget of the launch after --
-           * the division is this one wavefront's, every other one reads a finished word */
+          /* step budget that follows the games (EngineParams::step_budget_k16): this launch's first wavefront turns what
+           * the steps of the launch before cost (CO_STEP_*: ticks of the real-time counter on the device, scans on the
+           * emulation build; complete: a kernel boundary lies between) into the budget of the launch after -- the division
+           * is this one wavefront's, every other one reads a finished word */
           const unsigned long long wc = P.work_counter[(P.iteration + 2) % 3];
           const uint32_t steps = (uint32_t)(wc >> 32), scans = (uint32_t)wc;
-          /* the mean, smoothed over ~8 launches (in 1/256 scans; [5 + parity] carries it from launch to launch): the games
-           * of a generation that started together also choose their moves together, and a launch of first steps on
-           * fresh roots (16 scans) says nothing about the launch two later */
+          /* the mean, smoothed over ~8 launches (in 1/256 units; CO_WC_MEAN + parity carries it from launch to launch): the
+           * games of a generation that started together also choose their moves together, and a launch of first steps on
+           * fresh roots says nothing about the launch two later */
           unsigned long long sm = P.work_counter[CO_WC_MEAN + ((P.iteration + 1) & 1)];
           if (steps > 0u) {
             const unsigned long long inst = ((unsigned long long)scans << 8) / steps;
@@ -2674,9 +2675,6 @@ CO_DEV void co_pool_housekeeping(const EngineParams &P, int g) {
             b = (uint32_t)((sm * (uint32_t)P.step_budget_k16) >> 12);
             if (b < CO_STEP_BUDGET_MIN) b = CO_STEP_BUDGET_MIN;
           }
-#if defined(CO_EMU) && defined(CO_DEBUG_BUDGET)
-          fprintf(stderr, "it %d steps %u scans %u mean %.1f -> budget %u\n", P.iteration, steps, scans, (double)sm / 256.0, b);
-#endif
           P.work_counter[CO_WC_MEAN + (P.iteration & 1)] = sm;
           P.work_counter[CO_WC_BUDGET + (P.iteration & 1)] = (unsigned long long)b;
           P.work_counter[(P.iteration + 1) % 3] = 0ull;
