@@ -196,7 +196,7 @@ def launch_ranks(args):
 
 def measured_traffic(kernel, args, net, npools):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
-    (profiles/r05_<net>_pmc.json, else an earlier round's; PMC counters cannot be collected from inside an un-profiled run).
+    (profiles/r06_<net>_pmc.json, else an earlier round's; PMC counters cannot be collected from inside an un-profiled run).
     Only valid for the workload those passes were taken on (the default one); otherwise null."""
     if (args.games, args.sims, args.spe) != (4096, 400, 16):
         return None
@@ -702,6 +702,8 @@ def main():
             nt = min(5, args.steps)
             dtc, ttc = run_generations(tr, "mlp12x100h3", nt, 1, 15000, False, weights=wt)
             rt_dom, rt_both = rooflines_of("mlp12x100h3", ttc, int(ttc.get("pools", 1)), wall_s=dtc)
+            for r_ in (rt_both["search"], rt_both["network"]):  # the counters of THIS workload (profiles/r06_mlp12x100h3_trained_pmc.json)
+                r_["traffic"] = measured_traffic(r_["kernel"], args, "mlp12x100h3_trained", int(ttc.get("pools", 1)))
             out["detail"]["trained_checkpoint"] = {
                 "net": "mlp12x100h3", "weights": "tests/golden/trained_last.npz (the reference's last TFLite checkpoint)",
                 "games_per_s": G * nt / dtc, "ms_per_step": dtc * 1e3 / nt, "steps": nt, "warmup": 1,
