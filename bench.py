@@ -425,7 +425,7 @@ def main():
                 "rows_evaluated_per_launch": totals["nn_rows_evaluated"] / max(totals["nn_launches"], 1)}
 
     STAT_KEYS = ("searches", "evals", "plies", "iterations", "mcts_ms", "nn_ms", "pack_ms", "nn_rows", "nn_rows_evaluated", "nn_launches",
-                 "mcts_launches", "timed_launches", "nn_timed_rows", "mcts_timed_ms", "nn_timed_ms")
+                 "mcts_launches", "timed_launches", "nn_timed_rows", "mcts_timed_ms", "nn_timed_ms", "steps_cut")
 
     def barrier():
         if use_dist:
@@ -463,7 +463,8 @@ def main():
             if timed:
                 st = trainer.stats()
                 for k in STAT_KEYS:
-                    totals[k] += st[k]
+                    totals[k] += st.get(k, 0)
+                totals["step_budget_last"] = st.get("step_budget_last", 0)
                 totals["pools"] = st["pools"]
                 totals["samples"] += trainer.num_samples()
                 totals["peak_arena_units"] = max(totals["peak_arena_units"], st["peak_arena_units"])
@@ -630,6 +631,12 @@ def main():
                                     "outputs (bit-identical: a row's outputs depend on the row only); emptied at every generation start",
                 "peak_arena_units_per_tree": totals["peak_arena_units"],
                 "network_batch": batch_fill(totals, G),
+                # ca_config.step_budget (automatic): game steps that stopped at their time budget and went on in the next iteration
+                "step_budget": {"steps_cut_per_step": totals["steps_cut"] / max(args.steps, 1),
+                                "game_steps_per_step": totals["evals"] / max(args.steps, 1) / args.spe,
+                                "last_budget_us": totals.get("step_budget_last", 0),
+                                "note": "a step past 1.5 x the running mean of its pool's steps holds its queued leaves back and resumes in the "
+                                        "next launch: identical per-game results, more and shorter iterations"},
                 "world_size": dist.get_world_size() if use_dist else 1,
                 "ranks_seen": ranks_seen,
                 "per_rank_games_per_s": per_rank,
@@ -709,6 +716,7 @@ def main():
                 "games_per_s": G * nt / dtc, "ms_per_step": dtc * 1e3 / nt, "steps": nt, "warmup": 1,
                 "plies_per_game": ttc["plies"] / max(G * nt, 1), "evals_per_game": ttc["evals"] / max(G * nt, 1),
                 "sims_per_s": ttc["searches"] / dtc, "iterations_per_step": ttc["iterations"] / nt,
+                "steps_cut_per_step": ttc["steps_cut"] / nt, "last_budget_us": ttc.get("step_budget_last", 0),
                 "device_ms_per_step": {"mcts": ttc["mcts_ms"] / nt, "network": ttc["nn_ms"] / nt},
                 "roofline": rt_dom, "roofline_search": rt_both["search"], "roofline_network": rt_both["network"]}
         if world == 1 and not args.no_configs and not emu and (G, args.sims, args.spe) == (4096, 400, 16):
